@@ -1,0 +1,262 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ FROM THE REAL REFERENCE.
+
+Run in the build container only (needs /root/reference; the GPU box never sees it):
+
+    python tests/golden/make_golden.py
+
+For every case it (1) builds the reference ``GeneralTransformer`` (helpers/models.py:278-361),
+(2) loads the oracle's closed-form weights into it, (3) runs forward + MSELoss + backward (+ a
+3-step AdamW trajectory for the pinned cases) with the reference code, (4) asserts the oracle
+restatement agrees to fp32 noise, and (5) stores inputs-free fixtures: the closed-form weight and
+input generators live in oracle/mivit_oracle.py, so a fixture holds only the reference's OUTPUTS
+(out, loss, gradient norms / samples / full tensors, hooked per-stage activations).
+Fixtures are tensors only (.npz) -- never pickled modules or reference source.
+"""
+import os
+import sys
+import json
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.abspath(os.path.join(HERE, "..", ".."))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference")
+
+from helpers import models as ref            # noqa: E402  (the real reference)
+from oracle import mivit_oracle as orc       # noqa: E402
+
+torch.manual_seed(0)
+torch.set_num_threads(8)
+
+ACT = {"relu": F.relu, "leaky_relu": F.leaky_relu, "gelu": F.gelu}
+EMB = {"linear": ref.LinearProjectionEmbedding, "cnn": ref.CNNEmbedding, "deepresnet": ref.DeepResNetEmbedding}
+
+# name -> (config kwargs, B, T, store_full_grads, training_mode, adamw_steps)
+CASES = {
+    # shipped PSFNoise transformer shape with the linear embedding (SURVEY 8c "ref-shape")
+    "ref_linear": (dict(embedding="linear", patch_size=9, embed_dim=64, num_heads=4, hidden_dim=128, num_layers=6),
+                   4, 30, True, True, 3),
+    "ref_cnn": (dict(embedding="cnn", patch_size=9, embed_dim=64, num_heads=4, hidden_dim=128, num_layers=2),
+                3, 30, True, True, 0),
+    "ref_deepresnet_train": (dict(embedding="deepresnet", patch_size=9, embed_dim=64, num_heads=4, hidden_dim=128,
+                                  num_layers=2), 2, 6, True, True, 0),
+    "ref_deepresnet_eval": (dict(embedding="deepresnet", patch_size=9, embed_dim=64, num_heads=4, hidden_dim=128,
+                                 num_layers=2), 2, 6, False, False, 0),
+    # BASELINE cfg 1/2
+    "c1": (dict(embedding="linear", patch_size=64, embed_dim=128, num_heads=4, hidden_dim=256, num_layers=4),
+           8, 32, False, True, 3),
+    # cfg 4 small frame, learned positional table on (Embeddings experiment)
+    "c4_small": (dict(embedding="linear", patch_size=16, embed_dim=512, num_heads=8, hidden_dim=1024, num_layers=4,
+                      use_pos_encoding=True), 2, 64, False, True, 0),
+    # cfg 5: images + 25 hand-crafted features, both fusion types
+    "c5_early": (dict(embedding="linear", patch_size=16, embed_dim=128, num_heads=4, hidden_dim=256, num_layers=2,
+                      use_global_features=True, fusion_type="early", global_feature_dim=25), 4, 32, False, True, 0),
+    "c5_late": (dict(embedding="linear", patch_size=16, embed_dim=128, num_heads=4, hidden_dim=256, num_layers=2,
+                     use_global_features=True, fusion_type="late", global_feature_dim=25), 4, 32, False, True, 0),
+    # constructor corners: mean-pool readout, pos-enc, other activations, small/large Embeddings variants
+    "meanpool_posenc_leaky": (dict(embedding="linear", patch_size=9, embed_dim=32, num_heads=2, hidden_dim=64,
+                                   num_layers=3, use_regression_token=False, use_pos_encoding=True,
+                                   activation="leaky_relu"), 3, 20, True, True, 0),
+    "gelu_large_heads": (dict(embedding="cnn", patch_size=9, embed_dim=128, num_heads=8, hidden_dim=256, num_layers=2,
+                              activation="gelu", use_pos_encoding=True), 2, 30, False, True, 0),
+    "multi_output": (dict(embedding="linear", patch_size=7, embed_dim=64, num_heads=4, hidden_dim=128, num_layers=1,
+                          output_dim=3), 5, 11, True, True, 0),
+}
+# Framerate-like ragged sequence lengths at 13x13 (trainSettingsFramerate.py:42, :157-166)
+for T in (6, 10, 15, 20, 30, 60):
+    CASES[f"framerate_T{T}"] = (dict(embedding="linear", patch_size=13, embed_dim=64, num_heads=4, hidden_dim=128,
+                                     num_layers=6), 3, T, False, True, 0)
+
+
+KINK_MARGIN = 4e-6
+
+
+def build_reference(cfg: orc.MiViTConfig):
+    from functools import partial
+    head = partial(ref.MLPHead, hidden_dim=cfg.head_hidden, output_dim=cfg.output_dim)
+    m = ref.GeneralTransformer(
+        embedding_cls=EMB[cfg.embedding],
+        embed_kwargs={"patch_size": cfg.patch_size, "embed_dim": cfg.embed_dim},
+        embed_dim=cfg.embed_dim, num_heads=cfg.num_heads, hidden_dim=cfg.hidden_dim,
+        num_layers=cfg.num_layers, mlp_head=head, tr_activation_fct=ACT[cfg.activation],
+        dropout=0.0, use_pos_encoding=cfg.use_pos_encoding, use_regression_token=cfg.use_regression_token,
+        single_prediction=True, use_global_features=cfg.use_global_features,
+        fusion_type=cfg.fusion_type, global_feature_dim=cfg.global_feature_dim)
+    return m
+
+
+def sample_idx(n, k=256):
+    """Deterministic sample positions inside a flat tensor of n elements."""
+    if n <= k:
+        return np.arange(n)
+    return (np.arange(k, dtype=np.int64) * 2654435761 % n).astype(np.int64)
+
+
+def rel(a, b):
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def run_case(name, spec):
+    kw, B, T, full, training, nsteps = spec
+    cfg = orc.MiViTConfig(**kw)
+    params = orc.closed_form_params(cfg)
+    # pick the first input salt whose ReLU pre-activations all stay clear of zero (see min_kink_margin)
+    for salt in range(64):
+        x, labels, feats = orc.closed_form_batch(B, T, cfg.patch_size, cfg.global_feature_dim, salt=salt)
+        margin = orc.min_kink_margin(params, cfg, x, feats, training=training)
+        if margin > KINK_MARGIN or cfg.embedding == "deepresnet":
+            break
+    else:
+        raise RuntimeError(f"{name}: no salt with kink margin > {KINK_MARGIN}")
+    if cfg.output_dim > 1:
+        labels = labels.repeat(1, cfg.output_dim) * torch.linspace(0.5, 1.0, cfg.output_dim)
+
+    m = build_reference(cfg)
+    sd = m.state_dict()
+    shapes = orc.param_shapes(cfg)
+    trainable = [k for k, _ in m.named_parameters()]
+    assert trainable == list(shapes), f"{name}: oracle key order != reference named_parameters order"
+    for k, v in sd.items():
+        if k.endswith("num_batches_tracked"):
+            continue
+        assert tuple(v.shape) == tuple(params[k].shape), (name, k, v.shape, params[k].shape)
+    m.load_state_dict({**{k: v for k, v in sd.items() if k.endswith("num_batches_tracked")}, **params})
+    m.train(training)
+
+    # hooks: per-stage activations of encoder layer 0 (and embedding / final norm)
+    acts = {}
+    def hook(tag):
+        def f(_m, _i, o):
+            acts[tag] = o.detach().clone()
+        return f
+    hs = [m.embedding.register_forward_hook(hook("embed")), m.norm.register_forward_hook(hook("embed_ln")),
+          m.transformer.norm.register_forward_hook(hook("final"))]
+    l0 = m.transformer.encoder_layers[0]
+    for tag, mod in (("q", l0.self_attn.q_proj), ("k", l0.self_attn.k_proj), ("v", l0.self_attn.v_proj),
+                     ("attn_out", l0.self_attn.out_proj), ("x1", l0.norm1), ("u", l0.feed_forward.fc1),
+                     ("ffn", l0.feed_forward.fc2), ("x2", l0.norm2)):
+        hs.append(mod.register_forward_hook(hook(tag)))
+
+    out = m(x, feats) if cfg.use_global_features else m(x)
+    loss = nn.MSELoss()(out, labels)
+    m.zero_grad()
+    loss.backward()
+    for h in hs:
+        h.remove()
+    grads = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+
+    # ---- oracle vs reference (this is what pins the oracle) ----
+    trace = {}
+    o_out = orc.forward(params, cfg, x, feats, training=training, trace=trace)
+    o_out2, o_loss, o_grads = orc.loss_and_grads(params, cfg, x, labels, feats, training=training)
+    e_out = rel(o_out, out.detach())
+    e_loss = abs(float(o_loss) - float(loss)) / abs(float(loss))
+    # k_proj.bias has an analytically ZERO gradient (softmax is shift-invariant along keys), so both
+    # sides hold pure rounding noise there: scale each tensor's error by the global gradient scale too.
+    gscale = max(float(g.abs().max()) for g in grads.values())
+    e_grad = max(float((o_grads[k] - grads[k]).abs().max()) / (float(grads[k].abs().max()) + 1e-3 * gscale)
+                 for k in grads)
+    l0t = trace["layers"][0]
+    Bq, S, E = acts["q"].shape
+    Hh = cfg.num_heads
+    checks = {
+        "embed": rel(trace["embed"], acts["embed"]), "embed_ln": rel(trace["embed_ln"], acts["embed_ln"]),
+        "q": rel(l0t["q"].permute(0, 2, 1, 3).reshape(Bq, S, E), acts["q"]),
+        "attn_out": rel(l0t["attn_out"], acts["attn_out"]), "x1": rel(l0t["x1"], acts["x1"]),
+        "u": rel(l0t["u"], acts["u"]), "x2": rel(l0t["x2"], acts["x2"]), "final": rel(trace["final"], acts["final"]),
+    }
+    worst = max([e_out, e_loss, e_grad] + list(checks.values()))
+    print(f"{name:24s} params={sum(v.numel() for v in grads.values()):9d} loss={float(loss):.6f} "
+          f"salt={salt} margin={margin:.1e} oracle-vs-ref: out {e_out:.1e} loss {e_loss:.1e} grad {e_grad:.1e} stages {max(checks.values()):.1e}")
+    if e_grad > 1e-5:
+        for k in grads:
+            e = float((o_grads[k] - grads[k]).abs().max()) / (float(grads[k].abs().max()) + 1e-3 * gscale)
+            if e > 1e-5:
+                print("    worst-grad", k, e, float(grads[k].abs().max()), gscale)
+    # conv-stack gradients (DeepResNet) carry more fp32 summation noise than the GEMM-only cases
+    assert worst < (1e-4 if cfg.embedding == "deepresnet" else 2e-5), (name, e_out, e_loss, e_grad, checks)
+
+    fx = {"out": out.detach().numpy(), "loss": np.float64(loss.item()), "labels": labels.numpy()}
+    for k, g in grads.items():
+        flat = g.reshape(-1).numpy()
+        fx["gnorm/" + k] = np.float64(np.linalg.norm(flat.astype(np.float64)))
+        fx["gsamp/" + k] = flat[sample_idx(flat.size)]
+        if full:
+            fx["grad/" + k] = g.numpy()
+    # per-stage activations: full for small cases, sampled for large
+    for tag, a in acts.items():
+        flat = a.reshape(-1).numpy()
+        if full and flat.size <= 200_000:
+            fx["act/" + tag] = a.numpy()
+        fx["actnorm/" + tag] = np.float64(np.linalg.norm(flat.astype(np.float64)))
+        fx["actsamp/" + tag] = flat[sample_idx(flat.size)]
+    if cfg.embedding == "deepresnet" and training:
+        for k, v in m.state_dict().items():
+            if k.endswith("running_mean") or k.endswith("running_var"):
+                fx["bnstat/" + k] = v.numpy()
+
+    # ---- 3 reference AdamW steps: pins the optimizer glue (trainSettingsPSFNoise.py:119-120) ----
+    if nsteps:
+        m2 = build_reference(cfg)
+        m2.load_state_dict(params)
+        m2.train(True)
+        opt = torch.optim.AdamW(m2.parameters(), lr=1e-4)
+        sch = torch.optim.lr_scheduler.StepLR(opt, step_size=5, gamma=0.9)
+        traj = []
+        for _ in range(nsteps):
+            opt.zero_grad()
+            ls = nn.MSELoss()(m2(x), labels)
+            ls.backward()
+            opt.step()
+            traj.append(ls.item())
+        sch.step()
+        fx["adamw_losses"] = np.array(traj, dtype=np.float64)
+        for k, p in m2.named_parameters():
+            fx["adamw_pnorm/" + k] = np.float64(p.detach().double().norm().item())
+            flat = p.detach().reshape(-1).numpy()
+            fx["adamw_psamp/" + k] = flat[sample_idx(flat.size)]
+
+    meta = {"config": cfg.to_dict(), "B": B, "T": T, "salt": salt, "kink_margin": margin, "training": training, "full_grads": full,
+            "adamw_steps": nsteps, "torch": torch.__version__}
+    fx["meta"] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **fx)
+    return worst
+
+
+def param_count_pins():
+    """Known-answer parameter counts the reference's own artefacts print."""
+    pins = {}
+    base = dict(patch_size=9, num_heads=4)
+    c = orc.MiViTConfig(embedding="deepresnet", embed_dim=64, hidden_dim=128, num_layers=6, **base)
+    pins["vit_deepresnet_noposenc"] = (c, 506081)            # train_resultsPSFNoise.ipynb cell 4
+    for tag, (E, H, Fh, L, n) in {"small": (32, 2, 64, 3, 326593), "normal": (64, 4, 128, 6, 514273),
+                                  "large": (128, 8, 256, 12, 1928161)}.items():  # ProjectReport Table 1
+        c = orc.MiViTConfig(embedding="deepresnet", patch_size=9, embed_dim=E, num_heads=H, hidden_dim=Fh,
+                            num_layers=L, use_pos_encoding=True)
+        pins["embeddings_" + tag] = (c, n)
+    out = {}
+    for k, (c, n) in pins.items():
+        m = build_reference(c)
+        got = sum(p.numel() for p in m.parameters() if p.requires_grad)
+        mine = sum(int(np.prod(s)) for s in orc.param_shapes(c).values())
+        assert got == n == mine, (k, got, n, mine)
+        out[k] = {"config": c.to_dict(), "count": n}
+    with open(os.path.join(HERE, "param_counts.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print("parameter-count pins OK:", {k: v["count"] for k, v in out.items()})
+
+
+if __name__ == "__main__":
+    only = sys.argv[1:]
+    param_count_pins()
+    worst = 0.0
+    for nm, spec in CASES.items():
+        if only and nm not in only:
+            continue
+        worst = max(worst, run_case(nm, spec))
+    print(f"all cases: oracle agrees with the reference to {worst:.2e} (relative, max over outputs/grads/stages)")
