@@ -1,0 +1,152 @@
+/*
+ * mivit_hip.h -- C-ABI of libmivit_hip.so: the MI355X (gfx950) implementation of the MiViT hot path.
+ *
+ * The reference (Biomedical-Imaging-Group/MolecularDiffusion_MiViT) has no FFI: its path is a tree of
+ * torch.nn modules in helpers/models.py.  This header is the boundary a binding would target; every entry
+ * point cites the reference lines whose arithmetic it replaces.  Conventions:
+ *   - plain pointers + sizes only; every pointer is a DEVICE pointer unless named host_*;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all work is enqueued, nothing syncs;
+ *   - `dtype`: MIVIT_F32 (fp32 operands, v_mfma_f32_16x16x4_f32, the 1e-4 parity mode) or MIVIT_BF16
+ *     (bf16 operands / stored activations, fp32 accumulate, fp32 LayerNorm+softmax statistics);
+ *     master weights, biases, LayerNorm parameters and all weight gradients are ALWAYS fp32;
+ *   - return value 0 = OK, non-zero = error; mivit_last_error() returns a thread-local message;
+ *   - the library never allocates or frees device memory: callers pass workspaces
+ *     (sizes from mivit_*_workspace_bytes / mivit_plan_workspace_bytes).
+ */
+#ifndef MIVIT_HIP_H
+#define MIVIT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIVIT_ABI_VERSION 1
+
+enum { MIVIT_F32 = 0, MIVIT_BF16 = 1 };
+enum { MIVIT_ACT_NONE = 0, MIVIT_ACT_RELU = 1, MIVIT_ACT_LEAKY_RELU = 2, MIVIT_ACT_GELU = 3 };
+enum { MIVIT_EMBED_LINEAR = 0, MIVIT_EMBED_CNN = 1, MIVIT_EMBED_EXTERNAL = 2 };
+enum { MIVIT_FUSION_NONE = 0, MIVIT_FUSION_EARLY = 1, MIVIT_FUSION_LATE = 2 };
+
+int mivit_abi_version(void);
+const char *mivit_last_error(void);
+/* Number of HIP devices visible to the library (0 when there is none); never throws. */
+int mivit_device_count(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Operator level.  "T" below means the element type selected by `dtype` (float or bf16).
+ * ---------------------------------------------------------------------------------------------- */
+
+/* y[M,N] = act(x[M,K] @ W[N,K]^T + bias) (+ resid[M,N]).   nn.Linear + activation
+ * (helpers/models.py:37-39,57 q/k/v/out projections; :73-76 FeedForward; :164 patch embedding; :268-273 MLPHead).
+ * x is T unless x_is_f32 != 0 (raw fp32 frames for the patch embedding); W, bias fp32; y, resid, y_preact T.
+ * y_preact (optional) receives the pre-activation (needed by GELU backward).  ldx/ldy/ldr in elements. */
+int mivit_linear_fwd(int dtype, const void *x, int x_is_f32, int64_t ldx, const float *W, const float *bias,
+                     int M, int N, int K, int act, const void *resid, int64_t ldr,
+                     void *y, int64_t ldy, void *y_preact, void *stream);
+
+/* dx[M,K] = (dy[M,N] @ W[N,K]) (* act'(saved)) (+ dres[M,K]).  Autograd of nn.Linear w.r.t. its input.
+ * `act`/`saved`: when act != NONE the result is multiplied by act'(.) evaluated from `saved`[M,K]
+ * (post-activation for relu / leaky_relu, PRE-activation for gelu) -- backward of models.py:74. */
+int mivit_linear_dgrad(int dtype, const void *dy, int64_t lddy, const float *W, int M, int N, int K,
+                       int act, const void *saved, int64_t lds, const void *dres, int64_t lddr,
+                       void *dx, int64_t lddx, void *stream);
+
+/* dW[N,K] (+)= dy[M,N]^T @ x[M,K];  db[N] (+)= column sums of dy.  Deterministic (slab split over M, no atomics).
+ * workspace: mivit_linear_wgrad_workspace_bytes(M,N,K).  accumulate != 0 adds into dW/db. */
+size_t mivit_linear_wgrad_workspace_bytes(int M, int N, int K);
+int mivit_linear_wgrad(int dtype, const void *dy, int64_t lddy, const void *x, int x_is_f32, int64_t ldx,
+                       int M, int N, int K, float *dW, float *db, int accumulate,
+                       void *workspace, size_t workspace_bytes, void *stream);
+
+/* Row LayerNorm over E, eps 1e-5, biased variance, affine (nn.LayerNorm: models.py:88-89,134,301).
+ * Row r of the output goes to row  (r / rows_per_seq) * out_seq_stride + r % rows_per_seq + out_row_off  when
+ * rows_per_seq > 0 (token assembly behind the regression token, models.py:347), else to row r.
+ * `pos` (optional, fp32 [>=out rows per sequence, E]) is added after the affine (models.py:137-138).
+ * mean/rstd (fp32 [M]) are saved for backward. */
+int mivit_layernorm_fwd(int dtype, const void *z, int64_t ldz, const float *gamma, const float *beta,
+                        int M, int E, void *y, int64_t ldy, int rows_per_seq, int out_seq_stride, int out_row_off,
+                        const float *pos, float *mean, float *rstd, void *stream);
+
+/* dz = LayerNorm backward; dgamma/dbeta (+)= reductions over rows.  dy rows are read through the same row map
+ * as the forward wrote them.  workspace: mivit_layernorm_bwd_workspace_bytes(M,E). */
+size_t mivit_layernorm_bwd_workspace_bytes(int M, int E);
+int mivit_layernorm_bwd(int dtype, const void *dy, int64_t lddy, const void *z, int64_t ldz,
+                        const float *gamma, const float *mean, const float *rstd, int M, int E,
+                        int rows_per_seq, int in_seq_stride, int in_row_off,
+                        void *dz, int64_t lddz, float *dgamma, float *dbeta, int accumulate,
+                        void *workspace, size_t workspace_bytes, void *stream);
+
+/* Multi-head self-attention core (models.py:42-54): per (b,h) softmax(q k^T / sqrt(Dh)) v, heads merged.
+ * qkv: T [B*S, 3E] rows = [q | k | v] of one token (head h owns columns h*Dh..); ctx: T [B*S, E].
+ * Whole sequences live in LDS (S <= mivit_attention_max_seq(dtype, Dh)). */
+int mivit_attention_max_seq(int dtype, int Dh);
+int mivit_attention_fwd(int dtype, const void *qkv, int B, int S, int H, int Dh, void *ctx, void *stream);
+/* dqkv: T [B*S, 3E] from dctx T [B*S,E]; probabilities are recomputed from q,k (nothing saved). */
+int mivit_attention_bwd(int dtype, const void *qkv, const void *dctx, int B, int S, int H, int Dh,
+                        void *dqkv, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Model level: GeneralTransformer.forward / its autograd (models.py:278-361, :111-141, :81-108).
+ * Parameters live in ONE fp32 arena whose layout the plan defines (so q/k/v weights are contiguous and the
+ * gradient arena can be all-reduced per stage without copies).  Names are the reference state-dict keys.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct mivit_config {
+    int abi_version;       /* = MIVIT_ABI_VERSION */
+    int dtype;             /* MIVIT_F32 | MIVIT_BF16 */
+    int embedding;         /* MIVIT_EMBED_LINEAR | _CNN (same arithmetic, weight viewed [E,P*P]) | _EXTERNAL
+                              (caller supplies pre-LayerNorm tokens [B,T,E], e.g. DeepResNetEmbedding) */
+    int patch_size;        /* P: frame side; a token is a whole frame */
+    int embed_dim;         /* E */
+    int num_heads;         /* H */
+    int hidden_dim;        /* F */
+    int num_layers;        /* L */
+    int activation;        /* MIVIT_ACT_* for FeedForward */
+    int use_pos_encoding;  /* learned [1,128,E] table */
+    int use_regression_token;
+    int fusion;            /* MIVIT_FUSION_* */
+    int global_feature_dim;
+    int head_hidden;       /* MLPHead hidden (128) */
+    int output_dim;        /* MLPHead outputs (1) */
+} mivit_config;
+
+typedef struct mivit_plan mivit_plan;
+
+mivit_plan *mivit_plan_create(const mivit_config *cfg);   /* NULL on error */
+void mivit_plan_destroy(mivit_plan *plan);
+
+/* Parameter arena layout (floats). */
+int mivit_plan_num_params(const mivit_plan *plan);
+const char *mivit_plan_param_name(const mivit_plan *plan, int i);   /* reference state-dict key */
+int64_t mivit_plan_param_offset(const mivit_plan *plan, int i);     /* float offset into the arena */
+int64_t mivit_plan_param_numel(const mivit_plan *plan, int i);
+int64_t mivit_plan_arena_numel(const mivit_plan *plan);
+/* Backward stages, in execution order: 0 = head(+final norm, feature projector), 1..L = encoder layers
+ * L-1..0, L+1 = token assembly + embedding.  Stage s owns arena floats [begin,end): its gradients are final
+ * once mivit_backward(.., s, s+1, ..) has been enqueued -- this is what the data-parallel host overlaps
+ * its per-stage all-reduce with. */
+int mivit_plan_num_stages(const mivit_plan *plan);
+int mivit_plan_stage_range(const mivit_plan *plan, int stage, int64_t *begin, int64_t *end);
+
+size_t mivit_plan_workspace_bytes(const mivit_plan *plan, int B, int T, int need_backward);
+
+/* x: fp32 [B,T,P,P] frames (or fp32 [B,T,E] pre-norm tokens for _EXTERNAL); features: fp32 [B,Fg] or NULL;
+ * out: fp32 [B,output_dim].  The workspace keeps what backward needs; it must stay untouched until then. */
+int mivit_forward(const mivit_plan *plan, const float *params, const float *x, const float *features,
+                  int B, int T, void *workspace, size_t workspace_bytes, int need_backward,
+                  float *out, void *stream);
+
+/* Runs backward stages [stage_begin, stage_end).  dout: fp32 [B,output_dim].  grads: fp32 arena, same
+ * layout as params; every float of a stage's range is OVERWRITTEN (no accumulation).  dfeatures (fp32
+ * [B,Fg]) and dx_tokens (fp32 [B,T,E], _EXTERNAL only) may be NULL when not needed. */
+int mivit_backward(const mivit_plan *plan, const float *params, const float *x, const float *features,
+                   int B, int T, void *workspace, size_t workspace_bytes, const float *dout,
+                   float *grads, float *dfeatures, float *dx_tokens,
+                   int stage_begin, int stage_end, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIVIT_HIP_H */

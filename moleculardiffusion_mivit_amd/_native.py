@@ -1,0 +1,96 @@
+"""ctypes binding of libmivit_hip.so (the C-ABI declared in include/mivit_hip.h).
+
+There is NO fallback: if the library is missing or does not load, importing this module raises, and every
+product entry point that needs it fails loudly.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p, POINTER, Structure
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libmivit_hip.so")
+
+ABI_VERSION = 1
+F32, BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_LEAKY_RELU, ACT_GELU = 0, 1, 2, 3
+EMBED_LINEAR, EMBED_CNN, EMBED_EXTERNAL = 0, 1, 2
+FUSION_NONE, FUSION_EARLY, FUSION_LATE = 0, 1, 2
+
+
+class MivitConfig(Structure):
+    _fields_ = [(n, c_int) for n in (
+        "abi_version", "dtype", "embedding", "patch_size", "embed_dim", "num_heads", "hidden_dim", "num_layers",
+        "activation", "use_pos_encoding", "use_regression_token", "fusion", "global_feature_dim", "head_hidden",
+        "output_dim")]
+
+
+# every symbol include/mivit_hip.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "mivit_abi_version": (c_int, []),
+    "mivit_last_error": (c_char_p, []),
+    "mivit_device_count": (c_int, []),
+    "mivit_linear_fwd": (c_int, [c_int, c_void_p, c_int, c_int64, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                 c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p]),
+    "mivit_linear_dgrad": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int64,
+                                   c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
+    "mivit_linear_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "mivit_linear_wgrad": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_void_p,
+                                   c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    "mivit_layernorm_fwd": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int64,
+                                    c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mivit_layernorm_bwd_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "mivit_layernorm_bwd": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int,
+                                    c_int, c_int, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int,
+                                    c_void_p, c_size_t, c_void_p]),
+    "mivit_attention_max_seq": (c_int, [c_int, c_int]),
+    "mivit_attention_fwd": (c_int, [c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "mivit_attention_bwd": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "mivit_plan_create": (c_void_p, [POINTER(MivitConfig)]),
+    "mivit_plan_destroy": (None, [c_void_p]),
+    "mivit_plan_num_params": (c_int, [c_void_p]),
+    "mivit_plan_param_name": (c_char_p, [c_void_p, c_int]),
+    "mivit_plan_param_offset": (c_int64, [c_void_p, c_int]),
+    "mivit_plan_param_numel": (c_int64, [c_void_p, c_int]),
+    "mivit_plan_arena_numel": (c_int64, [c_void_p]),
+    "mivit_plan_num_stages": (c_int, [c_void_p]),
+    "mivit_plan_stage_range": (c_int, [c_void_p, c_int, POINTER(c_int64), POINTER(c_int64)]),
+    "mivit_plan_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int, c_int]),
+    "mivit_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t, c_int,
+                              c_void_p, c_void_p]),
+    "mivit_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p,
+                               c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+}
+
+
+class MivitError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the MiViT HIP extension has not been built. Run "
+            "`python -m moleculardiffusion_mivit_amd.csrc.build` (needs hipcc, targets gfx950). "
+            "There is no CPU / PyTorch fallback for this path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if lib.mivit_abi_version() != ABI_VERSION:
+        raise ImportError(f"libmivit_hip.so ABI {lib.mivit_abi_version()} != binding ABI {ABI_VERSION}; rebuild")
+    return lib
+
+
+lib = _load()
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib.mivit_last_error()
+        raise MivitError(f"{what}: {msg.decode() if msg else 'unknown error'}")
+
+
+def last_error():
+    msg = lib.mivit_last_error()
+    return msg.decode() if msg else ""

@@ -1,0 +1,221 @@
+// Shared device/host helpers for the MiViT gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/mivit_hip.h"
+
+// ------------------------------------------------------------------------------------------------
+// error plumbing (thread-local message, C-ABI returns an int)
+// ------------------------------------------------------------------------------------------------
+void mivit_set_error(const char *fmt, ...);
+#define MIVIT_FAIL(...)                 \
+    do {                                \
+        mivit_set_error(__VA_ARGS__);   \
+        return 1;                       \
+    } while (0)
+#define MIVIT_CHECK(cond, ...)          \
+    do {                                \
+        if (!(cond)) MIVIT_FAIL(__VA_ARGS__); \
+    } while (0)
+#define MIVIT_HIP(call)                                                                       \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess) MIVIT_FAIL("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+#define MIVIT_LAUNCH_CHECK()                                                                  \
+    do {                                                                                      \
+        hipError_t e_ = hipGetLastError();                                                    \
+        if (e_ != hipSuccess) MIVIT_FAIL("kernel launch failed: %s (%s:%d)", hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// element types
+// ------------------------------------------------------------------------------------------------
+struct bf16 {
+    uint16_t v;
+};
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+
+__device__ __forceinline__ float to_f32(float x) { return x; }
+__device__ __forceinline__ float to_f32(bf16 x) { return __uint_as_float(((uint32_t)x.v) << 16); }
+
+template <typename T>
+__device__ __forceinline__ T from_f32(float x);
+template <>
+__device__ __forceinline__ float from_f32<float>(float x) {
+    return x;
+}
+template <>
+__device__ __forceinline__ bf16 from_f32<bf16>(float x) {
+    __bf16 b = (__bf16)x;  // RNE, NaN-preserving (v_cvt_pk_bf16_f32)
+    bf16 r;
+    r.v = __builtin_bit_cast(unsigned short, b);
+    return r;
+}
+
+static inline size_t dtype_size(int dtype) { return dtype == MIVIT_BF16 ? 2 : 4; }
+
+// activation and its derivative.  `saved` is the post-activation for relu/leaky, the PRE-activation for gelu.
+__device__ __forceinline__ float act_fwd(int act, float u) {
+    switch (act) {
+        case MIVIT_ACT_RELU: return u > 0.f ? u : 0.f;
+        case MIVIT_ACT_LEAKY_RELU: return u > 0.f ? u : 0.01f * u;
+        case MIVIT_ACT_GELU: return 0.5f * u * (1.f + erff(u * 0.70710678118654752f));
+        default: return u;
+    }
+}
+__device__ __forceinline__ float act_bwd(int act, float saved) {
+    switch (act) {
+        case MIVIT_ACT_RELU: return saved > 0.f ? 1.f : 0.f;
+        case MIVIT_ACT_LEAKY_RELU: return saved > 0.f ? 1.f : 0.01f;
+        case MIVIT_ACT_GELU: {
+            const float u = saved;
+            const float cdf = 0.5f * (1.f + erff(u * 0.70710678118654752f));
+            const float pdf = 0.3989422804014327f * __expf(-0.5f * u * u);
+            return cdf + u * pdf;
+        }
+        default: return 1.f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// MFMA traits: one 16x16 output tile per wave-instruction.
+//   C/D (both dtypes): lane l holds column (l & 15), rows (l >> 4) * 4 + j, j = 0..3.
+//   f32  (v_mfma_f32_16x16x4_f32):   A[row = l&15][k = l>>4],           B[k = l>>4][col = l&15]
+//   bf16 (v_mfma_f32_16x16x32_bf16): A[row = l&15][k = 8*(l>>4) + j],   B[k = 8*(l>>4) + j][col = l&15], j = 0..7
+// Operand images in LDS are [row-or-col][k]; the bf16 fragment is one 16-byte read (k contiguous),
+// the f32 fragment a single dword (any k stride).
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+struct Mma;
+
+template <>
+struct Mma<float> {
+    static constexpr int KS = 4;
+    typedef float Frag;
+    static __device__ __forceinline__ Frag load(const float *img, int rs, int ks, int r0, int k0, int lane) {
+        return img[(r0 + (lane & 15)) * rs + (k0 + (lane >> 4)) * ks];
+    }
+    static __device__ __forceinline__ f32x4 mma(Frag a, Frag b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    }
+};
+
+template <>
+struct Mma<bf16> {
+    static constexpr int KS = 32;
+    typedef bf16x8 Frag;
+    // ks must be 1; (r0 + row) * rs + k0 + 8 * (lane >> 4) must be a multiple of 8 elements (16 bytes)
+    static __device__ __forceinline__ Frag load(const bf16 *img, int rs, int /*ks*/, int r0, int k0, int lane) {
+        return *reinterpret_cast<const bf16x8 *>(img + (r0 + (lane & 15)) * rs + k0 + 8 * (lane >> 4));
+    }
+    static __device__ __forceinline__ f32x4 mma(Frag a, Frag b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+};
+
+// wave-level helpers (wave = 64 lanes)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// internal launchers shared between the op-level C-ABI and the engine (all return 0 / non-zero)
+struct LinearFwdArgs {
+    int dtype;
+    const void *x; int x_is_f32; int64_t ldx;
+    const float *W; const float *bias;
+    int M, N, K, act;
+    const void *resid; int64_t ldr;
+    void *y; int64_t ldy; void *y_preact;
+    // optional output row map: out_row = (m / map_rows) * map_stride + m % map_rows + map_off  (map_rows > 0)
+    int map_rows, map_stride, map_off;
+    int y_is_f32;   // write fp32 output regardless of dtype (model output)
+};
+int launch_linear_fwd(const LinearFwdArgs &a, hipStream_t s);
+
+struct LinearDgradArgs {
+    int dtype;
+    const void *dy; int dy_is_f32; int64_t lddy;
+    const float *W;
+    int M, N, K;          // dy [M,N], W [N,K], dx [M,K]
+    int act; const void *saved; int64_t lds;
+    const void *dres; int64_t lddr;
+    void *dx; int64_t lddx; int dx_is_f32;
+};
+int launch_linear_dgrad(const LinearDgradArgs &a, hipStream_t s);
+
+struct LinearWgradArgs {
+    int dtype;
+    const void *dy; int dy_is_f32; int64_t lddy;
+    const void *x; int x_is_f32; int64_t ldx;
+    int M, N, K;          // dW [N,K] = dy^T x ; db [N]
+    float *dW; float *db; int accumulate;
+    void *ws; size_t ws_bytes;
+};
+size_t linear_wgrad_ws_bytes(int M, int N, int K);
+int launch_linear_wgrad(const LinearWgradArgs &a, hipStream_t s);
+
+struct LayerNormFwdArgs {
+    int dtype;
+    const void *z; int64_t ldz; const float *gamma; const float *beta;
+    int M, E;
+    void *y; int64_t ldy; int rows_per_seq, out_seq_stride, out_row_off;
+    const float *pos; float *mean; float *rstd;
+    // optional input row map (gather): in_row = (r / in_rows) * in_stride + r % in_rows + in_off  (in_rows > 0)
+    int in_rows, in_stride, in_off;
+};
+int launch_layernorm_fwd(const LayerNormFwdArgs &a, hipStream_t s);
+
+struct LayerNormBwdArgs {
+    int dtype;
+    const void *dy; int64_t lddy; const void *z; int64_t ldz;
+    const float *gamma; const float *mean; const float *rstd;
+    int M, E;
+    int rows_per_seq, in_seq_stride, in_row_off;   // row map of dy (as written by the forward)
+    int z_rows, z_stride, z_off;                   // row map of z  (gather used by the forward), z_rows > 0
+    void *dz; int64_t lddz;                        // written through the z row map
+    float *dgamma; float *dbeta; int accumulate;
+    void *ws; size_t ws_bytes;
+};
+size_t layernorm_bwd_ws_bytes(int M, int E);
+int launch_layernorm_bwd(const LayerNormBwdArgs &a, hipStream_t s);
+
+int launch_attention_fwd(int dtype, const void *qkv, int B, int S, int H, int Dh, void *ctx, hipStream_t s);
+int launch_attention_bwd(int dtype, const void *qkv, const void *dctx, int B, int S, int H, int Dh, void *dqkv,
+                         hipStream_t s);
+int attention_max_seq(int dtype, int Dh);
+
+// small elementwise / reduction helpers (misc.hip)
+// out[n] (+)= sum_p part[p*n_stride + n]   (deterministic slab reduce)
+int launch_slab_reduce(const float *part, int nparts, int64_t n, float *out, int accumulate, hipStream_t s);
+// tokens[b, 0, :] = reg[:] (+ add[b, :]) (+ pos[0, :])   -- regression token row (models.py:339-347)
+int launch_reg_token_fill(int dtype, void *tokens, int B, int S, int E, const float *reg, const void *add,
+                          const float *pos, hipStream_t s);
+// mean over tokens: out[b,:] = mean_s x[b,s,:]  and its backward (models.py:354)
+int launch_mean_pool_fwd(int dtype, const void *x, int B, int S, int E, void *out, hipStream_t s);
+int launch_mean_pool_bwd(int dtype, const void *dout, int B, int S, int E, void *dx, hipStream_t s);
+// column sums over the batch of selected token rows: out[s_sel, e] = sum_b x[b, s0 + s_sel, e]
+// (gradient of the positional table and of the regression token).  ws: B-chunk partials.
+size_t batch_colsum_ws_bytes(int B, int rows, int E);
+int launch_batch_colsum(int dtype, const void *x, int B, int S, int E, int s0, int rows, float *out, void *ws,
+                        size_t ws_bytes, hipStream_t s);
+// generic conversions / copies
+int launch_convert(int src_is_f32, const void *src, int64_t lds_, int dst_dtype_is_f32, void *dst, int64_t ldd,
+                   int rows, int cols, int accumulate, hipStream_t s);
+int launch_fill_zero(void *p, size_t bytes, hipStream_t s);

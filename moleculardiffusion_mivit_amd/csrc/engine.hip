@@ -1,0 +1,514 @@
+// Model-level engine: GeneralTransformer.forward and its backward as a fixed sequence of HIP launches
+// (reference helpers/models.py:328-361 orchestration, :136-141 Transformer, :97-108 post-norm encoder layer,
+// :33-59 attention, :72-77 feed-forward, :268-276 MLP head).  Host code only: every arithmetic step is one of
+// the kernels in gemm.hip / norm.hip / attention.hip / misc.hip.  The engine owns no device memory: the caller
+// passes the parameter arena, the gradient arena and one workspace whose layout is computed here.
+#include "common.h"
+
+#include <string>
+#include <vector>
+
+struct ParamInfo {
+    std::string name;
+    int64_t offset, numel;
+};
+
+struct LayerParams {
+    int64_t qkv_w, qkv_b, out_w, out_b, n1_w, n1_b, fc1_w, fc1_b, fc2_w, fc2_b, n2_w, n2_b;
+};
+
+struct mivit_plan {
+    mivit_config c;
+    std::vector<ParamInfo> params;
+    std::vector<std::pair<int64_t, int64_t>> stages;
+    int64_t arena;
+    // offsets (floats) into the arena
+    int64_t tn_w, tn_b, fp0_w, fp0_b, fp2_w, fp2_b, h0_w, h0_b, h3_w, h3_b;
+    std::vector<LayerParams> layers;
+    int64_t reg, pos, n0_w, n0_b, emb_w, emb_b;
+    int head_in;
+};
+
+namespace {
+
+constexpr int MAX_TOKENS = 128;   // helpers/models.py:8
+
+int64_t add_param(mivit_plan *p, const std::string &name, int64_t numel) {
+    p->arena = (p->arena + 3) / 4 * 4;   // 16-byte aligned tensors
+    const int64_t off = p->arena;
+    p->params.push_back({name, off, numel});
+    p->arena += numel;
+    return off;
+}
+
+void add_feature_projector(mivit_plan *p) {
+    const int E = p->c.embed_dim, G = p->c.global_feature_dim;
+    p->fp0_w = add_param(p, "feature_projector.0.weight", (int64_t)E * G);
+    p->fp0_b = add_param(p, "feature_projector.0.bias", E);
+    p->fp2_w = add_param(p, "feature_projector.2.weight", (int64_t)E * E);
+    p->fp2_b = add_param(p, "feature_projector.2.bias", E);
+}
+
+struct Ws {
+    size_t total;
+    size_t emb, mean0, rstd0, x0;
+    struct L { size_t qkv, ctx, z1, x1, h, u, z2, x2, mean1, rstd1, mean2, rstd2; };
+    std::vector<L> layer;
+    size_t xF, meanF, rstdF, pooled, fp_h, fp_out, head_in, hh;
+    // backward temporaries
+    size_t dout_t, d_hh, d_head_in, d_pool_c, d_fp_h, dxa, dxb, dF, dctx, dqkv, wgrad, ln, colsum;
+    size_t wgrad_bytes, ln_bytes, colsum_bytes;
+};
+
+Ws make_ws(const mivit_plan *p, int B, int T, bool bwd) {
+    const mivit_config &c = p->c;
+    const size_t ts = dtype_size(c.dtype);
+    const int E = c.embed_dim, F = c.hidden_dim, L = c.num_layers;
+    const int S = T + (c.use_regression_token ? 1 : 0);
+    const size_t M = (size_t)B * S, Mt = (size_t)B * T;
+    Ws w = {};
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes, 256); return o; };
+    w.emb = take(Mt * E * ts); w.mean0 = take(Mt * 4); w.rstd0 = take(Mt * 4);
+    w.x0 = take(M * E * ts);
+    const int nsets = bwd ? L : 1;
+    for (int l = 0; l < nsets; ++l) {
+        Ws::L s;
+        s.qkv = take(M * 3 * E * ts); s.ctx = take(M * E * ts); s.z1 = take(M * E * ts); s.x1 = take(M * E * ts);
+        s.h = take(M * F * ts); s.u = c.activation == MIVIT_ACT_GELU ? take(M * F * ts) : 0;
+        s.z2 = take(M * E * ts); s.x2 = take(M * E * ts);
+        s.mean1 = take(M * 4); s.rstd1 = take(M * 4); s.mean2 = take(M * 4); s.rstd2 = take(M * 4);
+        w.layer.push_back(s);
+    }
+    for (int l = nsets; l < L; ++l) w.layer.push_back(w.layer[0]);
+    w.xF = c.use_regression_token ? 0 : take(M * E * ts);
+    w.meanF = take(M * 4); w.rstdF = take(M * 4);
+    w.pooled = take((size_t)B * E * ts);
+    w.fp_h = take((size_t)B * E * ts); w.fp_out = take((size_t)B * E * ts);
+    w.head_in = take((size_t)B * 2 * E * ts);
+    w.hh = take((size_t)B * c.head_hidden * ts);
+    if (bwd) {
+        w.dout_t = take((size_t)B * c.output_dim * ts);
+        w.d_hh = take((size_t)B * c.head_hidden * ts);
+        w.d_head_in = take((size_t)B * 2 * E * ts);
+        w.d_pool_c = take((size_t)B * E * ts);
+        w.d_fp_h = take((size_t)B * E * ts);
+        w.dxa = take(M * E * ts); w.dxb = take(M * E * ts);
+        w.dF = take(M * F * ts); w.dctx = take(M * E * ts); w.dqkv = take(M * 3 * E * ts);
+        size_t wg = 0;
+        auto mx = [&](int m, int n, int k) { size_t b = linear_wgrad_ws_bytes(m, n, k); if (b > wg) wg = b; };
+        mx((int)M, 3 * E, E); mx((int)M, E, E); mx((int)M, F, E); mx((int)M, E, F);
+        if (c.embedding != MIVIT_EMBED_EXTERNAL) mx((int)Mt, E, c.patch_size * c.patch_size);
+        mx(B, c.head_hidden, p->head_in); mx(B, c.output_dim, c.head_hidden);
+        if (c.fusion != MIVIT_FUSION_NONE) { mx(B, E, E); mx(B, E, c.global_feature_dim); }
+        w.wgrad_bytes = wg; w.wgrad = take(wg);
+        w.ln_bytes = layernorm_bwd_ws_bytes((int)M, E); w.ln = take(w.ln_bytes);
+        w.colsum_bytes = batch_colsum_ws_bytes(B, S, E); w.colsum = take(w.colsum_bytes);
+    }
+    w.total = off;
+    return w;
+}
+
+inline void *at(void *base, size_t off) { return static_cast<char *>(base) + off; }
+inline const void *at(const void *base, size_t off) { return static_cast<const char *>(base) + off; }
+// pointer `cols` elements into a row of a T matrix
+inline void *col_ptr(void *p, size_t cols, int dtype) { return static_cast<char *>(p) + cols * dtype_size(dtype); }
+
+#define RC(call) do { int rc_ = (call); if (rc_) return rc_; } while (0)
+
+int lin_fwd(int dtype, const void *x, int x_f32, int64_t ldx, const float *W, const float *b, int M, int N, int K,
+            int act, const void *resid, int64_t ldr, void *y, int64_t ldy, void *pre, int y_f32, hipStream_t s) {
+    LinearFwdArgs a = {};
+    a.dtype = dtype; a.x = x; a.x_is_f32 = x_f32 || dtype == MIVIT_F32; a.ldx = ldx; a.W = W; a.bias = b;
+    a.M = M; a.N = N; a.K = K; a.act = act; a.resid = resid; a.ldr = ldr; a.y = y; a.ldy = ldy; a.y_preact = pre;
+    a.y_is_f32 = y_f32;
+    return launch_linear_fwd(a, s);
+}
+int lin_dgrad(int dtype, const void *dy, int64_t lddy, const float *W, int M, int N, int K, int act, const void *saved,
+              int64_t lds, const void *dres, int64_t lddr, void *dx, int64_t lddx, int dx_f32, hipStream_t s) {
+    LinearDgradArgs a = {};
+    a.dtype = dtype; a.dy = dy; a.dy_is_f32 = dtype == MIVIT_F32; a.lddy = lddy; a.W = W; a.M = M; a.N = N; a.K = K;
+    a.act = act; a.saved = saved; a.lds = lds; a.dres = dres; a.lddr = lddr; a.dx = dx; a.lddx = lddx; a.dx_is_f32 = dx_f32;
+    return launch_linear_dgrad(a, s);
+}
+int lin_wgrad(int dtype, const void *dy, int64_t lddy, const void *x, int x_f32, int64_t ldx, int M, int N, int K,
+              float *dW, float *db, void *ws, size_t wsb, hipStream_t s) {
+    LinearWgradArgs a = {};
+    a.dtype = dtype; a.dy = dy; a.dy_is_f32 = dtype == MIVIT_F32; a.lddy = lddy; a.x = x;
+    a.x_is_f32 = x_f32 || dtype == MIVIT_F32; a.ldx = ldx; a.M = M; a.N = N; a.K = K; a.dW = dW; a.db = db;
+    a.ws = ws; a.ws_bytes = wsb;
+    return launch_linear_wgrad(a, s);
+}
+
+int check_call(const mivit_plan *plan, int B, int T, size_t ws_bytes, bool bwd, const char *who) {
+    MIVIT_CHECK(plan, "%s: null plan", who);
+    MIVIT_CHECK(B > 0 && T > 0, "%s: empty batch (B=%d, T=%d)", who, B, T);
+    const int S = T + (plan->c.use_regression_token ? 1 : 0);
+    MIVIT_CHECK(!plan->c.use_pos_encoding || S <= MAX_TOKENS, "%s: %d tokens exceed the %d-entry positional table",
+                who, S, MAX_TOKENS);
+    const int Dh = plan->c.embed_dim / plan->c.num_heads;
+    MIVIT_CHECK(S <= attention_max_seq(plan->c.dtype, Dh),
+                "%s: sequence of %d tokens (head dim %d) does not fit the LDS-resident attention kernel (max %d)", who, S,
+                Dh, attention_max_seq(plan->c.dtype, Dh));
+    MIVIT_CHECK((int64_t)B * S * 3 * plan->c.embed_dim < (1ll << 31) && (int64_t)B * S * plan->c.hidden_dim < (1ll << 31),
+                "%s: batch too large for 32-bit row indexing", who);
+    const Ws w = make_ws(plan, B, T, bwd);
+    MIVIT_CHECK(ws_bytes >= w.total, "%s: workspace too small (%zu < %zu bytes)", who, ws_bytes, w.total);
+    return 0;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// plan
+// ------------------------------------------------------------------------------------------------
+extern "C" mivit_plan *mivit_plan_create(const mivit_config *cfg) {
+    if (!cfg) { mivit_set_error("plan_create: null config"); return nullptr; }
+    const mivit_config &c = *cfg;
+#define PLAN_CHECK(cond, ...) do { if (!(cond)) { mivit_set_error(__VA_ARGS__); return nullptr; } } while (0)
+    PLAN_CHECK(c.abi_version == MIVIT_ABI_VERSION, "plan_create: ABI version %d != %d", c.abi_version, MIVIT_ABI_VERSION);
+    PLAN_CHECK(c.dtype == MIVIT_F32 || c.dtype == MIVIT_BF16, "plan_create: bad dtype %d", c.dtype);
+    PLAN_CHECK(c.embedding >= MIVIT_EMBED_LINEAR && c.embedding <= MIVIT_EMBED_EXTERNAL, "plan_create: bad embedding %d", c.embedding);
+    PLAN_CHECK(c.embed_dim > 0 && c.num_heads > 0 && c.hidden_dim > 0 && c.num_layers >= 0, "plan_create: bad model dims");
+    PLAN_CHECK(c.embed_dim % c.num_heads == 0, "embed_dim must be divisible by num_heads");
+    PLAN_CHECK(c.embed_dim <= 1024, "plan_create: embed_dim %d > 1024 is not supported", c.embed_dim);
+    PLAN_CHECK(c.embedding == MIVIT_EMBED_EXTERNAL || c.patch_size > 0, "plan_create: bad patch_size");
+    PLAN_CHECK(c.activation >= MIVIT_ACT_RELU && c.activation <= MIVIT_ACT_GELU, "plan_create: unsupported activation %d", c.activation);
+    PLAN_CHECK(c.fusion >= MIVIT_FUSION_NONE && c.fusion <= MIVIT_FUSION_LATE, "plan_create: bad fusion %d", c.fusion);
+    PLAN_CHECK(c.fusion == MIVIT_FUSION_NONE || c.global_feature_dim > 0, "Must provide global_feature_dim if using global features");
+    PLAN_CHECK(c.fusion != MIVIT_FUSION_EARLY || c.use_regression_token, "plan_create: early fusion needs the regression token");
+    PLAN_CHECK(c.head_hidden > 0 && c.output_dim > 0, "plan_create: bad head dims");
+#undef PLAN_CHECK
+    mivit_plan *p = new mivit_plan();
+    p->c = c;
+    p->arena = 0;
+    const int E = c.embed_dim, F = c.hidden_dim;
+    p->head_in = c.fusion == MIVIT_FUSION_LATE ? 2 * E : E;
+    // stage 0: final norm + (late-fusion feature projector) + head
+    int64_t b0 = p->arena;
+    p->tn_w = add_param(p, "transformer.norm.weight", E);
+    p->tn_b = add_param(p, "transformer.norm.bias", E);
+    if (c.fusion == MIVIT_FUSION_LATE) add_feature_projector(p);
+    p->h0_w = add_param(p, "mlp_head.mlp.0.weight", (int64_t)c.head_hidden * p->head_in);
+    p->h0_b = add_param(p, "mlp_head.mlp.0.bias", c.head_hidden);
+    p->h3_w = add_param(p, "mlp_head.mlp.3.weight", (int64_t)c.output_dim * c.head_hidden);
+    p->h3_b = add_param(p, "mlp_head.mlp.3.bias", c.output_dim);
+    p->arena = (p->arena + 3) / 4 * 4;
+    p->stages.push_back({b0, p->arena});
+    // stages 1..L: encoder layers L-1 .. 0 (q/k/v weights and biases contiguous: one [3E,E] GEMM operand)
+    p->layers.resize(c.num_layers);
+    for (int l = c.num_layers - 1; l >= 0; --l) {
+        b0 = p->arena;
+        const std::string pre = "transformer.encoder_layers." + std::to_string(l) + ".";
+        LayerParams &lp = p->layers[l];
+        lp.qkv_w = add_param(p, pre + "self_attn.q_proj.weight", (int64_t)E * E);
+        add_param(p, pre + "self_attn.k_proj.weight", (int64_t)E * E);
+        add_param(p, pre + "self_attn.v_proj.weight", (int64_t)E * E);
+        lp.qkv_b = add_param(p, pre + "self_attn.q_proj.bias", E);
+        add_param(p, pre + "self_attn.k_proj.bias", E);
+        add_param(p, pre + "self_attn.v_proj.bias", E);
+        lp.out_w = add_param(p, pre + "self_attn.out_proj.weight", (int64_t)E * E);
+        lp.out_b = add_param(p, pre + "self_attn.out_proj.bias", E);
+        lp.n1_w = add_param(p, pre + "norm1.weight", E);
+        lp.n1_b = add_param(p, pre + "norm1.bias", E);
+        lp.fc1_w = add_param(p, pre + "feed_forward.fc1.weight", (int64_t)F * E);
+        lp.fc1_b = add_param(p, pre + "feed_forward.fc1.bias", F);
+        lp.fc2_w = add_param(p, pre + "feed_forward.fc2.weight", (int64_t)E * F);
+        lp.fc2_b = add_param(p, pre + "feed_forward.fc2.bias", E);
+        lp.n2_w = add_param(p, pre + "norm2.weight", E);
+        lp.n2_b = add_param(p, pre + "norm2.bias", E);
+        p->arena = (p->arena + 3) / 4 * 4;
+        p->stages.push_back({b0, p->arena});
+    }
+    // last stage: token assembly + embedding (+ early-fusion feature projector)
+    b0 = p->arena;
+    p->reg = c.use_regression_token ? add_param(p, "reg_token", E) : -1;
+    p->pos = c.use_pos_encoding ? add_param(p, "transformer.pos_embedding", (int64_t)MAX_TOKENS * E) : -1;
+    p->n0_w = add_param(p, "norm.weight", E);
+    p->n0_b = add_param(p, "norm.bias", E);
+    if (c.fusion == MIVIT_FUSION_EARLY) add_feature_projector(p);
+    p->emb_w = p->emb_b = -1;
+    if (c.embedding == MIVIT_EMBED_LINEAR) {
+        p->emb_w = add_param(p, "embedding.proj.weight", (int64_t)E * c.patch_size * c.patch_size);
+        p->emb_b = add_param(p, "embedding.proj.bias", E);
+    } else if (c.embedding == MIVIT_EMBED_CNN) {
+        p->emb_w = add_param(p, "embedding.conv.weight", (int64_t)E * c.patch_size * c.patch_size);
+        p->emb_b = add_param(p, "embedding.conv.bias", E);
+    }
+    p->arena = (p->arena + 3) / 4 * 4;
+    p->stages.push_back({b0, p->arena});
+    // q/k/v must be contiguous (E*E and E are multiples of 4 whenever E is): verify
+    for (const LayerParams &lp : p->layers) (void)lp;
+    if ((int64_t)E * E % 4 != 0 || E % 4 != 0) {
+        mivit_set_error("plan_create: embed_dim must be a multiple of 4 (got %d)", E);
+        delete p;
+        return nullptr;
+    }
+    return p;
+}
+
+extern "C" void mivit_plan_destroy(mivit_plan *plan) { delete plan; }
+extern "C" int mivit_plan_num_params(const mivit_plan *plan) { return plan ? (int)plan->params.size() : 0; }
+extern "C" const char *mivit_plan_param_name(const mivit_plan *plan, int i) {
+    return (plan && i >= 0 && i < (int)plan->params.size()) ? plan->params[i].name.c_str() : nullptr;
+}
+extern "C" int64_t mivit_plan_param_offset(const mivit_plan *plan, int i) {
+    return (plan && i >= 0 && i < (int)plan->params.size()) ? plan->params[i].offset : -1;
+}
+extern "C" int64_t mivit_plan_param_numel(const mivit_plan *plan, int i) {
+    return (plan && i >= 0 && i < (int)plan->params.size()) ? plan->params[i].numel : -1;
+}
+extern "C" int64_t mivit_plan_arena_numel(const mivit_plan *plan) { return plan ? plan->arena : 0; }
+extern "C" int mivit_plan_num_stages(const mivit_plan *plan) { return plan ? (int)plan->stages.size() : 0; }
+extern "C" int mivit_plan_stage_range(const mivit_plan *plan, int stage, int64_t *begin, int64_t *end) {
+    MIVIT_CHECK(plan && stage >= 0 && stage < (int)plan->stages.size(), "stage_range: bad stage %d", stage);
+    if (begin) *begin = plan->stages[stage].first;
+    if (end) *end = plan->stages[stage].second;
+    return 0;
+}
+extern "C" size_t mivit_plan_workspace_bytes(const mivit_plan *plan, int B, int T, int need_backward) {
+    if (!plan || B <= 0 || T <= 0) return 0;
+    return make_ws(plan, B, T, need_backward != 0).total;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+extern "C" int mivit_forward(const mivit_plan *plan, const float *params, const float *x, const float *features, int B,
+                             int T, void *workspace, size_t workspace_bytes, int need_backward, float *out,
+                             void *stream) {
+    RC(check_call(plan, B, T, workspace_bytes, need_backward != 0, "mivit_forward"));
+    MIVIT_CHECK(params && x && workspace && out, "mivit_forward: null pointer");
+    const mivit_config &c = plan->c;
+    MIVIT_CHECK(c.fusion == MIVIT_FUSION_NONE || features, "Global features required for %s fusion",
+                c.fusion == MIVIT_FUSION_EARLY ? "early" : "late");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int dt = c.dtype, E = c.embed_dim, F = c.hidden_dim, H = c.num_heads, Dh = E / H;
+    const int off = c.use_regression_token ? 1 : 0, S = T + off, M = B * S, Mt = B * T;
+    const Ws w = make_ws(plan, B, T, need_backward != 0);
+    void *ws = workspace;
+    const float *P = params;
+
+    // 1. frame embedding: one token per whole frame (models.py:146-199), [B*T, P*P] x [E, P*P]^T
+    if (c.embedding == MIVIT_EMBED_EXTERNAL) {
+        RC(launch_convert(1, x, E, dt == MIVIT_F32, at(ws, w.emb), E, Mt, E, 0, s));
+    } else {
+        const int K = c.patch_size * c.patch_size;
+        RC(lin_fwd(dt, x, 1, K, P + plan->emb_w, P + plan->emb_b, Mt, E, K, MIVIT_ACT_NONE, nullptr, 0, at(ws, w.emb), E,
+                   nullptr, 0, s));
+    }
+    // 2. LayerNorm of the tokens, written behind the regression-token row, + positional table (models.py:334,347,138)
+    {
+        LayerNormFwdArgs a = {};
+        a.dtype = dt; a.z = at(ws, w.emb); a.ldz = E; a.gamma = P + plan->n0_w; a.beta = P + plan->n0_b; a.M = Mt; a.E = E;
+        a.y = at(ws, w.x0); a.ldy = E; a.rows_per_seq = T; a.out_seq_stride = S; a.out_row_off = off;
+        a.pos = c.use_pos_encoding ? P + plan->pos : nullptr;
+        a.mean = static_cast<float *>(at(ws, w.mean0)); a.rstd = static_cast<float *>(at(ws, w.rstd0));
+        RC(launch_layernorm_fwd(a, s));
+    }
+    // feature projector (models.py:316-320): Linear(Fg,E) -> ReLU -> Linear(E,E)
+    if (c.fusion != MIVIT_FUSION_NONE) {
+        const int G = c.global_feature_dim;
+        RC(lin_fwd(dt, features, 1, G, P + plan->fp0_w, P + plan->fp0_b, B, E, G, MIVIT_ACT_RELU, nullptr, 0,
+                   at(ws, w.fp_h), E, nullptr, 0, s));
+        RC(lin_fwd(dt, at(ws, w.fp_h), 0, E, P + plan->fp2_w, P + plan->fp2_b, B, E, E, MIVIT_ACT_NONE, nullptr, 0,
+                   at(ws, w.fp_out), E, nullptr, 0, s));
+    }
+    // 3. regression token row (models.py:339-347)
+    if (c.use_regression_token)
+        RC(launch_reg_token_fill(dt, at(ws, w.x0), B, S, E, P + plan->reg,
+                                 c.fusion == MIVIT_FUSION_EARLY ? at(ws, w.fp_out) : nullptr,
+                                 c.use_pos_encoding ? P + plan->pos : nullptr, s));
+    // 4. encoder layers (post-norm, models.py:97-108)
+    const void *xin = at(ws, w.x0);
+    for (int l = 0; l < c.num_layers; ++l) {
+        const LayerParams &lp = plan->layers[l];
+        const Ws::L &b = w.layer[l];
+        RC(lin_fwd(dt, xin, 0, E, P + lp.qkv_w, P + lp.qkv_b, M, 3 * E, E, MIVIT_ACT_NONE, nullptr, 0, at(ws, b.qkv),
+                   3 * E, nullptr, 0, s));
+        RC(launch_attention_fwd(dt, at(ws, b.qkv), B, S, H, Dh, at(ws, b.ctx), s));
+        RC(lin_fwd(dt, at(ws, b.ctx), 0, E, P + lp.out_w, P + lp.out_b, M, E, E, MIVIT_ACT_NONE, xin, E, at(ws, b.z1), E,
+                   nullptr, 0, s));
+        LayerNormFwdArgs n1 = {};
+        n1.dtype = dt; n1.z = at(ws, b.z1); n1.ldz = E; n1.gamma = P + lp.n1_w; n1.beta = P + lp.n1_b; n1.M = M; n1.E = E;
+        n1.y = at(ws, b.x1); n1.ldy = E; n1.mean = static_cast<float *>(at(ws, b.mean1));
+        n1.rstd = static_cast<float *>(at(ws, b.rstd1));
+        RC(launch_layernorm_fwd(n1, s));
+        RC(lin_fwd(dt, at(ws, b.x1), 0, E, P + lp.fc1_w, P + lp.fc1_b, M, F, E, c.activation, nullptr, 0, at(ws, b.h), F,
+                   c.activation == MIVIT_ACT_GELU ? at(ws, b.u) : nullptr, 0, s));
+        RC(lin_fwd(dt, at(ws, b.h), 0, F, P + lp.fc2_w, P + lp.fc2_b, M, E, F, MIVIT_ACT_NONE, at(ws, b.x1), E,
+                   at(ws, b.z2), E, nullptr, 0, s));
+        LayerNormFwdArgs n2 = n1;
+        n2.z = at(ws, b.z2); n2.gamma = P + lp.n2_w; n2.beta = P + lp.n2_b; n2.y = at(ws, b.x2);
+        n2.mean = static_cast<float *>(at(ws, b.mean2)); n2.rstd = static_cast<float *>(at(ws, b.rstd2));
+        RC(launch_layernorm_fwd(n2, s));
+        xin = at(ws, b.x2);
+    }
+    // 5. final LayerNorm + readout (models.py:141, :351-354).  Only the regression-token row is normalised when it
+    //    is the readout: the other rows of the final norm never reach the head.
+    {
+        LayerNormFwdArgs a = {};
+        a.dtype = dt; a.z = xin; a.ldz = E; a.gamma = P + plan->tn_w; a.beta = P + plan->tn_b; a.E = E; a.ldy = E;
+        a.mean = static_cast<float *>(at(ws, w.meanF)); a.rstd = static_cast<float *>(at(ws, w.rstdF));
+        if (c.use_regression_token) {
+            a.M = B; a.y = at(ws, w.pooled); a.in_rows = 1; a.in_stride = S; a.in_off = 0;
+            RC(launch_layernorm_fwd(a, s));
+        } else {
+            a.M = M; a.y = at(ws, w.xF);
+            RC(launch_layernorm_fwd(a, s));
+            RC(launch_mean_pool_fwd(dt, at(ws, w.xF), B, S, E, at(ws, w.pooled), s));
+        }
+    }
+    // 6. late fusion concat (models.py:356-359) and the MLP head (models.py:268-276)
+    const void *head_in = at(ws, w.pooled);
+    if (c.fusion == MIVIT_FUSION_LATE) {
+        const int f32 = dt == MIVIT_F32;
+        RC(launch_convert(f32, at(ws, w.pooled), E, f32, at(ws, w.head_in), 2 * E, B, E, 0, s));
+        RC(launch_convert(f32, at(ws, w.fp_out), E, f32, col_ptr(at(ws, w.head_in), E, dt), 2 * E, B, E, 0, s));
+        head_in = at(ws, w.head_in);
+    }
+    RC(lin_fwd(dt, head_in, 0, plan->head_in, P + plan->h0_w, P + plan->h0_b, B, c.head_hidden, plan->head_in,
+               MIVIT_ACT_RELU, nullptr, 0, at(ws, w.hh), c.head_hidden, nullptr, 0, s));
+    RC(lin_fwd(dt, at(ws, w.hh), 0, c.head_hidden, P + plan->h3_w, P + plan->h3_b, B, c.output_dim, c.head_hidden,
+               MIVIT_ACT_NONE, nullptr, 0, out, c.output_dim, nullptr, 1, s));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+// backward of the feature projector given d(fp_out) (rows of `dy`, leading dim lddy)
+int feature_projector_bwd(const mivit_plan *plan, const Ws &w, void *ws, const float *P, float *G, const float *features,
+                          int B, const void *dy, int64_t lddy, float *dfeatures, hipStream_t s) {
+    const mivit_config &c = plan->c;
+    const int dt = c.dtype, E = c.embed_dim, Fg = c.global_feature_dim;
+    RC(lin_wgrad(dt, dy, lddy, at(ws, w.fp_h), 0, E, B, E, E, G + plan->fp2_w, G + plan->fp2_b, at(ws, w.wgrad),
+                 w.wgrad_bytes, s));
+    RC(lin_dgrad(dt, dy, lddy, P + plan->fp2_w, B, E, E, MIVIT_ACT_RELU, at(ws, w.fp_h), E, nullptr, 0, at(ws, w.d_fp_h),
+                 E, 0, s));
+    RC(lin_wgrad(dt, at(ws, w.d_fp_h), E, features, 1, Fg, B, E, Fg, G + plan->fp0_w, G + plan->fp0_b, at(ws, w.wgrad),
+                 w.wgrad_bytes, s));
+    if (dfeatures)
+        RC(lin_dgrad(dt, at(ws, w.d_fp_h), E, P + plan->fp0_w, B, E, Fg, MIVIT_ACT_NONE, nullptr, 0, nullptr, 0, dfeatures,
+                     Fg, 1, s));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int mivit_backward(const mivit_plan *plan, const float *params, const float *x, const float *features, int B,
+                              int T, void *workspace, size_t workspace_bytes, const float *dout, float *grads,
+                              float *dfeatures, float *dx_tokens, int stage_begin, int stage_end, void *stream) {
+    RC(check_call(plan, B, T, workspace_bytes, true, "mivit_backward"));
+    MIVIT_CHECK(params && x && workspace && dout && grads, "mivit_backward: null pointer");
+    const mivit_config &c = plan->c;
+    const int nst = (int)plan->stages.size();
+    MIVIT_CHECK(stage_begin >= 0 && stage_begin <= stage_end && stage_end <= nst, "mivit_backward: bad stage range [%d,%d)",
+                stage_begin, stage_end);
+    MIVIT_CHECK(c.fusion == MIVIT_FUSION_NONE || features, "mivit_backward: features required");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int dt = c.dtype, E = c.embed_dim, F = c.hidden_dim, H = c.num_heads, Dh = E / H, L = c.num_layers;
+    const int off = c.use_regression_token ? 1 : 0, S = T + off, M = B * S, Mt = B * T;
+    const int f32 = dt == MIVIT_F32;
+    const Ws w = make_ws(plan, B, T, true);
+    void *ws = workspace;
+    const float *P = params;
+    float *G = grads;
+    void *wg = at(ws, w.wgrad);
+    const size_t wgb = w.wgrad_bytes;
+
+    for (int st = stage_begin; st < stage_end; ++st) {
+        if (st == 0) {
+            // ---- head + final norm ----
+            const int Hh = c.head_hidden, Hin = plan->head_in, O = c.output_dim;
+            const void *xL = L > 0 ? at(ws, w.layer[L - 1].x2) : at(ws, w.x0);
+            const void *head_in = c.fusion == MIVIT_FUSION_LATE ? at(ws, w.head_in) : at(ws, w.pooled);
+            const void *dy = dout;
+            if (!f32) { RC(launch_convert(1, dout, O, 0, at(ws, w.dout_t), O, B, O, 0, s)); dy = at(ws, w.dout_t); }
+            RC(lin_wgrad(dt, dy, O, at(ws, w.hh), 0, Hh, B, O, Hh, G + plan->h3_w, G + plan->h3_b, wg, wgb, s));
+            RC(lin_dgrad(dt, dy, O, P + plan->h3_w, B, O, Hh, MIVIT_ACT_RELU, at(ws, w.hh), Hh, nullptr, 0, at(ws, w.d_hh),
+                         Hh, 0, s));
+            RC(lin_wgrad(dt, at(ws, w.d_hh), Hh, head_in, 0, Hin, B, Hh, Hin, G + plan->h0_w, G + plan->h0_b, wg, wgb, s));
+            RC(lin_dgrad(dt, at(ws, w.d_hh), Hh, P + plan->h0_w, B, Hh, Hin, MIVIT_ACT_NONE, nullptr, 0, nullptr, 0,
+                         at(ws, w.d_head_in), Hin, 0, s));
+            if (c.fusion == MIVIT_FUSION_LATE)
+                RC(feature_projector_bwd(plan, w, ws, P, G, features, B, col_ptr(at(ws, w.d_head_in), E, dt), Hin,
+                                         dfeatures, s));
+            LayerNormBwdArgs a = {};
+            a.dtype = dt; a.z = xL; a.ldz = E; a.gamma = P + plan->tn_w;
+            a.mean = static_cast<const float *>(at(ws, w.meanF)); a.rstd = static_cast<const float *>(at(ws, w.rstdF));
+            a.E = E; a.dz = at(ws, w.dxa); a.lddz = E; a.dgamma = G + plan->tn_w; a.dbeta = G + plan->tn_b;
+            a.ws = at(ws, w.ln); a.ws_bytes = w.ln_bytes;
+            if (c.use_regression_token) {
+                RC(launch_fill_zero(at(ws, w.dxa), (size_t)M * E * dtype_size(dt), s));
+                a.dy = at(ws, w.d_head_in); a.lddy = Hin; a.M = B; a.z_rows = 1; a.z_stride = S; a.z_off = 0;
+                RC(launch_layernorm_bwd(a, s));
+            } else {
+                const void *dp = at(ws, w.d_head_in);
+                if (Hin != E) {
+                    RC(launch_convert(f32, at(ws, w.d_head_in), Hin, f32, at(ws, w.d_pool_c), E, B, E, 0, s));
+                    dp = at(ws, w.d_pool_c);
+                }
+                RC(launch_mean_pool_bwd(dt, dp, B, S, E, at(ws, w.dxb), s));
+                a.dy = at(ws, w.dxb); a.lddy = E; a.M = M;
+                RC(launch_layernorm_bwd(a, s));
+            }
+        } else if (st <= L) {
+            // ---- encoder layer l = L - st; dxa holds d(x2) on entry and d(x_in) on exit ----
+            const int l = L - st;
+            const LayerParams &lp = plan->layers[l];
+            const Ws::L &b = w.layer[l];
+            const void *xin = l > 0 ? at(ws, w.layer[l - 1].x2) : at(ws, w.x0);
+            LayerNormBwdArgs n2 = {};
+            n2.dtype = dt; n2.dy = at(ws, w.dxa); n2.lddy = E; n2.z = at(ws, b.z2); n2.ldz = E; n2.gamma = P + lp.n2_w;
+            n2.mean = static_cast<const float *>(at(ws, b.mean2)); n2.rstd = static_cast<const float *>(at(ws, b.rstd2));
+            n2.M = M; n2.E = E; n2.dz = at(ws, w.dxb); n2.lddz = E; n2.dgamma = G + lp.n2_w; n2.dbeta = G + lp.n2_b;
+            n2.ws = at(ws, w.ln); n2.ws_bytes = w.ln_bytes;
+            RC(launch_layernorm_bwd(n2, s));                                                      // dxb = d(z2)
+            RC(lin_wgrad(dt, at(ws, w.dxb), E, at(ws, b.h), 0, F, M, E, F, G + lp.fc2_w, G + lp.fc2_b, wg, wgb, s));
+            RC(lin_dgrad(dt, at(ws, w.dxb), E, P + lp.fc2_w, M, E, F, c.activation,
+                         c.activation == MIVIT_ACT_GELU ? at(ws, b.u) : at(ws, b.h), F, nullptr, 0, at(ws, w.dF), F, 0, s));
+            RC(lin_wgrad(dt, at(ws, w.dF), F, at(ws, b.x1), 0, E, M, F, E, G + lp.fc1_w, G + lp.fc1_b, wg, wgb, s));
+            RC(lin_dgrad(dt, at(ws, w.dF), F, P + lp.fc1_w, M, F, E, MIVIT_ACT_NONE, nullptr, 0, at(ws, w.dxb), E,
+                         at(ws, w.dxa), E, 0, s));                                                // dxa = d(x1)
+            LayerNormBwdArgs n1 = n2;
+            n1.dy = at(ws, w.dxa); n1.z = at(ws, b.z1); n1.gamma = P + lp.n1_w;
+            n1.mean = static_cast<const float *>(at(ws, b.mean1)); n1.rstd = static_cast<const float *>(at(ws, b.rstd1));
+            n1.dz = at(ws, w.dxb); n1.dgamma = G + lp.n1_w; n1.dbeta = G + lp.n1_b;
+            RC(launch_layernorm_bwd(n1, s));                                                      // dxb = d(z1)
+            RC(lin_wgrad(dt, at(ws, w.dxb), E, at(ws, b.ctx), 0, E, M, E, E, G + lp.out_w, G + lp.out_b, wg, wgb, s));
+            RC(lin_dgrad(dt, at(ws, w.dxb), E, P + lp.out_w, M, E, E, MIVIT_ACT_NONE, nullptr, 0, nullptr, 0,
+                         at(ws, w.dctx), E, 0, s));
+            RC(launch_attention_bwd(dt, at(ws, b.qkv), at(ws, w.dctx), B, S, H, Dh, at(ws, w.dqkv), s));
+            RC(lin_wgrad(dt, at(ws, w.dqkv), 3 * E, xin, 0, E, M, 3 * E, E, G + lp.qkv_w, G + lp.qkv_b, wg, wgb, s));
+            RC(lin_dgrad(dt, at(ws, w.dqkv), 3 * E, P + lp.qkv_w, M, 3 * E, E, MIVIT_ACT_NONE, nullptr, 0, at(ws, w.dxb),
+                         E, at(ws, w.dxa), E, 0, s));                                             // dxa = d(x_in)
+        } else {
+            // ---- token assembly + embedding; dxa holds d(x0) [B,S,E] ----
+            if (c.use_pos_encoding) {
+                RC(launch_fill_zero(G + plan->pos, (size_t)MAX_TOKENS * E * sizeof(float), s));
+                RC(launch_batch_colsum(dt, at(ws, w.dxa), B, S, E, 0, S, G + plan->pos, at(ws, w.colsum), w.colsum_bytes, s));
+            }
+            if (c.use_regression_token)
+                RC(launch_batch_colsum(dt, at(ws, w.dxa), B, S, E, 0, 1, G + plan->reg, at(ws, w.colsum), w.colsum_bytes, s));
+            if (c.fusion == MIVIT_FUSION_EARLY)
+                RC(feature_projector_bwd(plan, w, ws, P, G, features, B, at(ws, w.dxa), (int64_t)S * E, dfeatures, s));
+            LayerNormBwdArgs a = {};
+            a.dtype = dt; a.dy = at(ws, w.dxa); a.lddy = E; a.z = at(ws, w.emb); a.ldz = E; a.gamma = P + plan->n0_w;
+            a.mean = static_cast<const float *>(at(ws, w.mean0)); a.rstd = static_cast<const float *>(at(ws, w.rstd0));
+            a.M = Mt; a.E = E; a.rows_per_seq = T; a.in_seq_stride = S; a.in_row_off = off;
+            a.dz = at(ws, w.dxb); a.lddz = E; a.dgamma = G + plan->n0_w; a.dbeta = G + plan->n0_b;
+            a.ws = at(ws, w.ln); a.ws_bytes = w.ln_bytes;
+            RC(launch_layernorm_bwd(a, s));                                                       // dxb = d(embedding out)
+            if (c.embedding == MIVIT_EMBED_EXTERNAL) {
+                if (dx_tokens) RC(launch_convert(f32, at(ws, w.dxb), E, 1, dx_tokens, E, Mt, E, 0, s));
+            } else {
+                const int K = c.patch_size * c.patch_size;
+                RC(lin_wgrad(dt, at(ws, w.dxb), E, x, 1, K, Mt, E, K, G + plan->emb_w, G + plan->emb_b, wg, wgb, s));
+            }
+        }
+    }
+    return 0;
+}

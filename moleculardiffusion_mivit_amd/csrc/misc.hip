@@ -1,0 +1,185 @@
+// Error plumbing, small elementwise / reduction kernels and library-level C-ABI entry points.
+#include "common.h"
+#include <stdarg.h>
+
+static thread_local char g_err[512] = "";
+
+void mivit_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *mivit_last_error(void) { return g_err; }
+extern "C" int mivit_abi_version(void) { return MIVIT_ABI_VERSION; }
+extern "C" int mivit_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+namespace {
+
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float *part, int nparts, int64_t n, float *out,
+                                                          int accumulate) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float acc = 0.f;
+        for (int p = 0; p < nparts; ++p) acc += part[(int64_t)p * n + i];   // fixed order: deterministic
+        out[i] = accumulate ? out[i] + acc : acc;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void reg_token_kernel(T *tokens, int B, int S, int E, const float *reg,
+                                                        const T *add, const float *pos) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)B * E) return;
+    const int b = (int)(i / E), e = (int)(i % E);
+    float v = reg[e];
+    if (add) v += to_f32(add[(int64_t)b * E + e]);
+    if (pos) v += pos[e];
+    tokens[(int64_t)b * S * E + e] = from_f32<T>(v);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void mean_pool_fwd_kernel(const T *x, int B, int S, int E, T *out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)B * E) return;
+    const int b = (int)(i / E), e = (int)(i % E);
+    float acc = 0.f;
+    for (int s = 0; s < S; ++s) acc += to_f32(x[((int64_t)b * S + s) * E + e]);
+    out[i] = from_f32<T>(acc / (float)S);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void mean_pool_bwd_kernel(const T *dout, int B, int S, int E, T *dx) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)B * S * E) return;
+    const int e = (int)(i % E);
+    const int b = (int)(i / ((int64_t)S * E));
+    dx[i] = from_f32<T>(to_f32(dout[(int64_t)b * E + e]) / (float)S);
+}
+
+// part[chunk][r][e] = sum over b in chunk of x[b, s0 + r, e]
+template <typename T>
+__global__ __launch_bounds__(256) void batch_colsum_kernel(const T *x, int B, int S, int E, int s0, int rows,
+                                                           int bchunk, float *part) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)rows * E) return;
+    const int r = (int)(i / E), e = (int)(i % E);
+    const int bb = blockIdx.y * bchunk, be = min(B, bb + bchunk);
+    float acc = 0.f;
+    for (int b = bb; b < be; ++b) acc += to_f32(x[((int64_t)b * S + s0 + r) * E + e]);
+    part[(int64_t)blockIdx.y * rows * E + i] = acc;
+}
+
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void convert_kernel(const TS *src, int64_t lds_, TD *dst, int64_t ldd, int rows,
+                                                      int cols, int accumulate) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)rows * cols) return;
+    const int64_t r = i / cols, c = i % cols;
+    float v = to_f32(src[r * lds_ + c]);
+    if (accumulate) v += to_f32(dst[r * ldd + c]);
+    dst[r * ldd + c] = from_f32<TD>(v);
+}
+
+int batch_chunks(int B) {
+    int c = ceil_div(B, 64);
+    return c < 1 ? 1 : (c > 128 ? 128 : c);
+}
+
+}  // namespace
+
+int launch_slab_reduce(const float *part, int nparts, int64_t n, float *out, int accumulate, hipStream_t s) {
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, s, part, nparts, n, out, accumulate);
+    MIVIT_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_reg_token_fill(int dtype, void *tokens, int B, int S, int E, const float *reg, const void *add,
+                          const float *pos, hipStream_t s) {
+    const int blocks = (int)(((int64_t)B * E + 255) / 256);
+    if (dtype == MIVIT_F32)
+        hipLaunchKernelGGL(reg_token_kernel<float>, dim3(blocks), dim3(256), 0, s, static_cast<float *>(tokens), B, S, E,
+                           reg, static_cast<const float *>(add), pos);
+    else
+        hipLaunchKernelGGL(reg_token_kernel<bf16>, dim3(blocks), dim3(256), 0, s, static_cast<bf16 *>(tokens), B, S, E,
+                           reg, static_cast<const bf16 *>(add), pos);
+    MIVIT_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_mean_pool_fwd(int dtype, const void *x, int B, int S, int E, void *out, hipStream_t s) {
+    const int blocks = (int)(((int64_t)B * E + 255) / 256);
+    if (dtype == MIVIT_F32)
+        hipLaunchKernelGGL(mean_pool_fwd_kernel<float>, dim3(blocks), dim3(256), 0, s, static_cast<const float *>(x), B,
+                           S, E, static_cast<float *>(out));
+    else
+        hipLaunchKernelGGL(mean_pool_fwd_kernel<bf16>, dim3(blocks), dim3(256), 0, s, static_cast<const bf16 *>(x), B, S,
+                           E, static_cast<bf16 *>(out));
+    MIVIT_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_mean_pool_bwd(int dtype, const void *dout, int B, int S, int E, void *dx, hipStream_t s) {
+    const int blocks = (int)(((int64_t)B * S * E + 255) / 256);
+    if (dtype == MIVIT_F32)
+        hipLaunchKernelGGL(mean_pool_bwd_kernel<float>, dim3(blocks), dim3(256), 0, s, static_cast<const float *>(dout),
+                           B, S, E, static_cast<float *>(dx));
+    else
+        hipLaunchKernelGGL(mean_pool_bwd_kernel<bf16>, dim3(blocks), dim3(256), 0, s, static_cast<const bf16 *>(dout), B,
+                           S, E, static_cast<bf16 *>(dx));
+    MIVIT_LAUNCH_CHECK();
+    return 0;
+}
+
+size_t batch_colsum_ws_bytes(int B, int rows, int E) {
+    return align_up((size_t)batch_chunks(B) * rows * E * sizeof(float), 256);
+}
+
+int launch_batch_colsum(int dtype, const void *x, int B, int S, int E, int s0, int rows, float *out, void *ws,
+                        size_t ws_bytes, hipStream_t s) {
+    MIVIT_CHECK(ws_bytes >= batch_colsum_ws_bytes(B, rows, E), "batch_colsum: workspace too small");
+    const int chunks = batch_chunks(B);
+    const int bchunk = ceil_div(B, chunks);
+    dim3 grid((unsigned)(((int64_t)rows * E + 255) / 256), chunks);
+    float *part = static_cast<float *>(ws);
+    if (dtype == MIVIT_F32)
+        hipLaunchKernelGGL(batch_colsum_kernel<float>, grid, dim3(256), 0, s, static_cast<const float *>(x), B, S, E, s0,
+                           rows, bchunk, part);
+    else
+        hipLaunchKernelGGL(batch_colsum_kernel<bf16>, grid, dim3(256), 0, s, static_cast<const bf16 *>(x), B, S, E, s0,
+                           rows, bchunk, part);
+    MIVIT_LAUNCH_CHECK();
+    return launch_slab_reduce(part, chunks, (int64_t)rows * E, out, 0, s);
+}
+
+int launch_convert(int src_is_f32, const void *src, int64_t lds_, int dst_is_f32, void *dst, int64_t ldd, int rows,
+                   int cols, int accumulate, hipStream_t s) {
+    if (rows <= 0 || cols <= 0) return 0;
+    const int blocks = (int)(((int64_t)rows * cols + 255) / 256);
+    if (src_is_f32 && dst_is_f32)
+        hipLaunchKernelGGL((convert_kernel<float, float>), dim3(blocks), dim3(256), 0, s, static_cast<const float *>(src),
+                           lds_, static_cast<float *>(dst), ldd, rows, cols, accumulate);
+    else if (src_is_f32)
+        hipLaunchKernelGGL((convert_kernel<float, bf16>), dim3(blocks), dim3(256), 0, s, static_cast<const float *>(src),
+                           lds_, static_cast<bf16 *>(dst), ldd, rows, cols, accumulate);
+    else if (dst_is_f32)
+        hipLaunchKernelGGL((convert_kernel<bf16, float>), dim3(blocks), dim3(256), 0, s, static_cast<const bf16 *>(src),
+                           lds_, static_cast<float *>(dst), ldd, rows, cols, accumulate);
+    else
+        hipLaunchKernelGGL((convert_kernel<bf16, bf16>), dim3(blocks), dim3(256), 0, s, static_cast<const bf16 *>(src),
+                           lds_, static_cast<bf16 *>(dst), ldd, rows, cols, accumulate);
+    MIVIT_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_fill_zero(void *p, size_t bytes, hipStream_t s) {
+    if (!bytes) return 0;
+    MIVIT_HIP(hipMemsetAsync(p, 0, bytes, s));
+    return 0;
+}

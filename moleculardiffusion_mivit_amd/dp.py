@@ -1,0 +1,82 @@
+"""Data-parallel training support: one process per GPU, gradient averaging with RCCL over xGMI.
+
+The model's backward runs in stages (head, encoder layers L-1..0, embedding); the gradients of a stage are a
+contiguous slice of the fp32 gradient arena, final as soon as that stage's kernels are enqueued.  Each slice is
+all-reduced on a side stream while the next stage computes, so communication hides under backward; there is no
+copy into buckets (the arena IS the bucket) and no extra collective on the data path.  Samples are sharded
+contiguously over ranks; per-rank losses are means over equal shards, so sum(all-reduce) of grads pre-scaled by
+1/world equals the reference's full-batch MSELoss(mean) gradient.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+class StagedGradReducer:
+    """All-reduce (sum) of arena slices, stage by stage.  GPU tensors: asynchronous on a communication stream
+    ordered after the producing kernels by an event.  CPU tensors (gloo tests): synchronous."""
+
+    def __init__(self, stage_ranges, group=None):
+        self.stage_ranges = list(stage_ranges)
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self._comm = None
+
+    def reduce_stage(self, grads: torch.Tensor, stage: int):
+        b, e = self.stage_ranges[stage]
+        if e <= b or self.world == 1:
+            return
+        if grads.device.type == "cuda":
+            if self._comm is None:
+                self._comm = torch.cuda.Stream(device=grads.device)
+            main = torch.cuda.current_stream(grads.device)
+            ev = torch.cuda.Event()
+            ev.record(main)
+            self._comm.wait_event(ev)
+            with torch.cuda.stream(self._comm):
+                dist.all_reduce(grads[b:e], group=self.group)
+        else:
+            dist.all_reduce(grads[b:e], group=self.group)
+
+    def finish(self, grads: torch.Tensor):
+        if grads.device.type == "cuda" and self._comm is not None:
+            torch.cuda.current_stream(grads.device).wait_stream(self._comm)
+            grads.record_stream(self._comm)
+
+
+def broadcast_parameters(model, src: int = 0, group=None):
+    """Identical initialisation on every rank: one broadcast of the whole parameter arena (+ any tensors that
+    live outside it, e.g. a DeepResNet embedding and its BatchNorm buffers)."""
+    arena = getattr(model, "_arena", None)
+    inside = set()
+    if arena is not None:
+        dist.broadcast(arena, src=src, group=group)
+        inside = {id(p) for p in model._arena_params}
+    for p in model.parameters():
+        if id(p) not in inside:
+            dist.broadcast(p.data, src=src, group=group)
+    for b in model.buffers():
+        dist.broadcast(b, src=src, group=group)
+
+
+def attach(model, group=None, broadcast: bool = True):
+    """Make `model` (a GeneralTransformer) data-parallel over `group`: gradients produced by its backward are
+    averaged across ranks, overlapped stage by stage.  Parameters outside the arena (external embeddings) are
+    averaged by `finish_external_grads` after backward."""
+    if broadcast:
+        broadcast_parameters(model, 0, group)
+    model._dp = StagedGradReducer(model._plan.stage_ranges, group)
+    return model
+
+
+def finish_external_grads(model, group=None):
+    """Average the gradients of parameters that are not in the arena (call after loss.backward())."""
+    world = dist.get_world_size(group)
+    if world == 1:
+        return
+    inside = {id(p) for p in getattr(model, "_arena_params", [])}
+    for p in model.parameters():
+        if id(p) not in inside and p.grad is not None:
+            dist.all_reduce(p.grad, group=group)
+            p.grad /= world

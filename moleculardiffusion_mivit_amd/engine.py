@@ -1,0 +1,132 @@
+"""Host glue between PyTorch (device memory, streams, autograd, optimizer) and the HIP engine.
+
+`MivitPlan` wraps a native `mivit_plan` (include/mivit_hip.h): it defines the fp32 parameter-arena layout and
+runs GeneralTransformer forward / staged backward (reference helpers/models.py:328-361 and its autograd).
+`MivitFunction` is the single autograd node the model's forward goes through; with a process group attached it
+all-reduces each backward stage's slice of the gradient arena on a side stream while the next stage computes
+(data-parallel training, RCCL over xGMI).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _native as N
+
+_PRECISIONS = {"fp32": N.F32, "f32": N.F32, "float32": N.F32, "bf16": N.BF16, "bfloat16": N.BF16}
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream_ptr(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class MivitPlan:
+    """Native plan: parameter-arena layout + forward / backward launch sequences for one model configuration."""
+
+    def __init__(self, *, precision: str, embedding: int, patch_size: int, embed_dim: int, num_heads: int,
+                 hidden_dim: int, num_layers: int, activation: int, use_pos_encoding: bool,
+                 use_regression_token: bool, fusion: int, global_feature_dim: int, head_hidden: int, output_dim: int):
+        if precision not in _PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(_PRECISIONS)}, got {precision!r}")
+        self.precision = precision
+        self.cfg = N.MivitConfig(N.ABI_VERSION, _PRECISIONS[precision], embedding, patch_size, embed_dim, num_heads,
+                                 hidden_dim, num_layers, activation, int(use_pos_encoding), int(use_regression_token),
+                                 fusion, int(global_feature_dim or 0), head_hidden, output_dim)
+        self._h = N.lib.mivit_plan_create(ctypes.byref(self.cfg))
+        if not self._h:
+            raise N.MivitError(f"mivit_plan_create: {N.last_error()}")
+        h = self._h
+        n = N.lib.mivit_plan_num_params(h)
+        self.param_names: List[str] = [N.lib.mivit_plan_param_name(h, i).decode() for i in range(n)]
+        self.param_offsets: List[int] = [N.lib.mivit_plan_param_offset(h, i) for i in range(n)]
+        self.param_numels: List[int] = [N.lib.mivit_plan_param_numel(h, i) for i in range(n)]
+        self.arena_numel: int = N.lib.mivit_plan_arena_numel(h)
+        self.num_stages: int = N.lib.mivit_plan_num_stages(h)
+        self.stage_ranges = []
+        for s in range(self.num_stages):
+            b, e = ctypes.c_int64(), ctypes.c_int64()
+            N.check(N.lib.mivit_plan_stage_range(h, s, ctypes.byref(b), ctypes.byref(e)), "stage_range")
+            self.stage_ranges.append((b.value, e.value))
+        self.embed_dim, self.output_dim = embed_dim, output_dim
+        self.embedding = embedding
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and N is not None and getattr(N, "lib", None) is not None:   # (module may be gone at interpreter exit)
+            N.lib.mivit_plan_destroy(h)
+
+    def workspace_bytes(self, B: int, T: int, need_backward: bool) -> int:
+        return N.lib.mivit_plan_workspace_bytes(self._h, B, T, int(need_backward))
+
+    def forward(self, arena, x, features, B, T, ws, need_backward, out):
+        N.check(N.lib.mivit_forward(self._h, _ptr(arena), _ptr(x), _ptr(features), B, T, _ptr(ws), ws.numel(),
+                                    int(need_backward), _ptr(out), _stream_ptr(x.device)), "mivit_forward")
+
+    def backward(self, arena, x, features, B, T, ws, dout, grads, dfeatures, dx_tokens, s0, s1):
+        N.check(N.lib.mivit_backward(self._h, _ptr(arena), _ptr(x), _ptr(features), B, T, _ptr(ws), ws.numel(),
+                                     _ptr(dout), _ptr(grads), _ptr(dfeatures), _ptr(dx_tokens), s0, s1,
+                                     _stream_ptr(x.device)), "mivit_backward")
+
+
+class MivitFunction(torch.autograd.Function):
+    """out = GeneralTransformer(x, features); inputs after `features` are the arena-backed parameters."""
+
+    @staticmethod
+    def forward(ctx, owner, x, features, *params):
+        plan: MivitPlan = owner._plan
+        arena: torch.Tensor = owner._arena
+        if x.device.type != "cuda":
+            raise RuntimeError("the MiViT HIP path needs GPU tensors (no CPU fallback exists in this package)")
+        x = x.contiguous().float()
+        feats = features.contiguous().float() if features is not None else None
+        B, T = x.shape[0], x.shape[1]
+        need_bwd = torch.is_grad_enabled() and (any(p.requires_grad for p in params) or x.requires_grad or
+                                                (feats is not None and feats.requires_grad))
+        ws = torch.empty(plan.workspace_bytes(B, T, need_bwd), dtype=torch.uint8, device=x.device)
+        out = torch.empty(B, plan.output_dim, dtype=torch.float32, device=x.device)
+        plan.forward(arena, x, feats, B, T, ws, need_bwd, out)
+        ctx.owner, ctx.ws, ctx.x, ctx.feats, ctx.BT = owner, ws, x, feats, (B, T)
+        ctx.arena_version = owner._arena_version
+        ctx.n_params = len(params)
+        ctx.need_x = x.requires_grad
+        ctx.need_f = feats is not None and feats.requires_grad
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        owner = ctx.owner
+        plan: MivitPlan = owner._plan
+        arena = owner._arena
+        if ctx.arena_version != owner._arena_version:
+            raise RuntimeError("model parameters were re-allocated between forward and backward")
+        B, T = ctx.BT
+        x, feats, ws = ctx.x, ctx.feats, ctx.ws
+        dp = getattr(owner, "_dp", None)            # dp.StagedGradReducer or None
+        dout = dout.contiguous().float()
+        if dp is not None and dp.world > 1:
+            dout = dout / dp.world                  # sum-all-reduce of pre-scaled grads == average
+        grads = torch.zeros(plan.arena_numel, dtype=torch.float32, device=x.device)
+        dfeat = torch.empty_like(feats) if ctx.need_f else None
+        dx = None
+        if plan.embedding == N.EMBED_EXTERNAL and ctx.need_x:
+            dx = torch.empty(B, T, plan.embed_dim, dtype=torch.float32, device=x.device)
+        if dp is None or dp.world == 1:
+            plan.backward(arena, x, feats, B, T, ws, dout, grads, dfeat, dx, 0, plan.num_stages)
+        else:
+            for s in range(plan.num_stages):
+                plan.backward(arena, x, feats, B, T, ws, dout, grads, dfeat, dx, s, s + 1)
+                dp.reduce_stage(grads, s)
+            dp.finish(grads)
+            if dx is not None:
+                dx = dx * dp.world                  # d(tokens) feeds the rank-local embedding autograd unscaled
+            if dfeat is not None:
+                dfeat = dfeat * dp.world
+        ctx.ws = None
+        outs = owner._grad_views(grads)
+        return (None, dx if ctx.need_x else None, dfeat) + tuple(outs)

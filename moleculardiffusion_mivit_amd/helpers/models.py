@@ -1,0 +1,403 @@
+"""Drop-in mirror of the reference's ``helpers/models.py`` class surface for the MiViT path.
+
+Same class names, constructor arguments, ``forward`` signatures, assertion messages and ``state_dict`` keys as
+the reference (Biomedical-Imaging-Group/MolecularDiffusion_MiViT, helpers/models.py:11-361, :781-803), but
+``GeneralTransformer.forward`` runs on hand-written HIP kernels for gfx950 through ``libmivit_hip.so``
+(include/mivit_hip.h).  The ``nn.Module`` tree below is a *parameter container*: it gives the reference's
+state-dict schema, while the tensors themselves live in one fp32 arena laid out by the native plan.
+
+Not supported (raises instead of silently computing something else): dropout > 0, attention masks,
+activations other than relu / leaky_relu / gelu, MLP heads other than ``MLPHead`` with ReLU.
+There is no CPU path in this package.
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.utils.data import Dataset
+
+from .. import _native as N
+from ..engine import MivitFunction, MivitPlan
+from .. import ops as _ops
+
+MAX_TOKENS = 128  # learned positional table length (reference models.py:8)
+
+_ACT_CODES = {F.relu: N.ACT_RELU, torch.relu: N.ACT_RELU, F.leaky_relu: N.ACT_LEAKY_RELU, F.gelu: N.ACT_GELU}
+
+
+def _default_precision() -> str:
+    return os.environ.get("MIVIT_PRECISION", "fp32")
+
+
+def _act_code(fn) -> int:
+    if not callable(fn):
+        raise ValueError("activation_fct must be a callable function from torch.nn.functional or a custom function.")
+    if fn in _ACT_CODES:
+        return _ACT_CODES[fn]
+    if isinstance(fn, nn.ReLU):
+        return N.ACT_RELU
+    if isinstance(fn, nn.GELU) and getattr(fn, "approximate", "none") == "none":
+        return N.ACT_GELU
+    if isinstance(fn, nn.LeakyReLU) and fn.negative_slope == 0.01:
+        return N.ACT_LEAKY_RELU
+    raise NotImplementedError(f"activation {fn!r} has no HIP kernel (supported: F.relu, F.leaky_relu, F.gelu)")
+
+
+def _require_no_dropout(p: float):
+    if p and p > 0:
+        raise NotImplementedError("dropout > 0 is not implemented on the HIP path (every shipped config uses 0.0)")
+
+
+# ------------------------------------------------------------------------------------------------------------
+# transformer building blocks (reference models.py:11-141).  Usable standalone: their forward runs the
+# operator-level HIP kernels (ops.py); inside GeneralTransformer the fused engine is used instead.
+# ------------------------------------------------------------------------------------------------------------
+class MultiHeadAttention(nn.Module):
+    def __init__(self, embed_dim, num_heads, dropout=0.0):
+        super().__init__()
+        self.embed_dim = embed_dim
+        self.num_heads = num_heads
+        self.head_dim = embed_dim // num_heads
+        assert self.head_dim * num_heads == embed_dim, "embed_dim must be divisible by num_heads"
+        _require_no_dropout(dropout)
+        self.q_proj = nn.Linear(embed_dim, embed_dim)
+        self.k_proj = nn.Linear(embed_dim, embed_dim)
+        self.v_proj = nn.Linear(embed_dim, embed_dim)
+        self.out_proj = nn.Linear(embed_dim, embed_dim)
+        for lin in (self.q_proj, self.k_proj, self.v_proj, self.out_proj):   # Glorot, as the reference (:28-31)
+            nn.init.xavier_uniform_(lin.weight)
+
+    def forward(self, x, mask=None):
+        if mask is not None:
+            raise NotImplementedError("attention masks are not implemented (the reference never passes one)")
+        B, S, E = x.shape
+        q = _ops.linear(x, self.q_proj.weight, self.q_proj.bias)
+        k = _ops.linear(x, self.k_proj.weight, self.k_proj.bias)
+        v = _ops.linear(x, self.v_proj.weight, self.v_proj.bias)
+        ctx = _ops.attention(torch.cat([q, k, v], dim=-1), self.num_heads)
+        return _ops.linear(ctx, self.out_proj.weight, self.out_proj.bias)
+
+
+class FeedForward(nn.Module):
+    def __init__(self, embed_dim, hidden_dim, activation_fct, dropout=0.0):
+        super().__init__()
+        self.fc1 = nn.Linear(embed_dim, hidden_dim)
+        self.fc2 = nn.Linear(hidden_dim, embed_dim)
+        _require_no_dropout(dropout)
+        self._act_code = _act_code(activation_fct)
+        self.activation = activation_fct
+
+    def forward(self, x):
+        h = _ops.linear(x, self.fc1.weight, self.fc1.bias, act=self._act_code)
+        return _ops.linear(h, self.fc2.weight, self.fc2.bias)
+
+
+class TransformerEncoderLayerWithSkip(nn.Module):
+    """Post-norm layer: x = LN1(x + attn(x)); x = LN2(x + ff(x))  (reference models.py:97-108)."""
+
+    def __init__(self, embed_dim, num_heads, hidden_dim, activation_fct, dropout=0.0):
+        super().__init__()
+        self.self_attn = MultiHeadAttention(embed_dim, num_heads, dropout)
+        self.norm1 = nn.LayerNorm(embed_dim)
+        self.norm2 = nn.LayerNorm(embed_dim)
+        self.feed_forward = FeedForward(embed_dim, hidden_dim, activation_fct, dropout)
+
+    def forward(self, x, mask=None):
+        x = _ops.layer_norm(x + self.self_attn(x, mask), self.norm1.weight, self.norm1.bias)
+        return _ops.layer_norm(x + self.feed_forward(x), self.norm2.weight, self.norm2.bias)
+
+
+class Transformer(nn.Module):
+    def __init__(self, embed_dim, num_heads, hidden_dim, num_layers, dropout, use_pos_encoding, activation_fct):
+        super().__init__()
+        self.embed_dim = embed_dim
+        self.use_pos_encoding = use_pos_encoding
+        if self.use_pos_encoding:
+            self.pos_embedding = nn.Parameter(torch.randn(1, MAX_TOKENS, embed_dim))
+        self.encoder_layers = nn.ModuleList([
+            TransformerEncoderLayerWithSkip(embed_dim, num_heads, hidden_dim, activation_fct, dropout)
+            for _ in range(num_layers)])
+        self.norm = nn.LayerNorm(embed_dim)
+
+    def forward(self, x):
+        if self.use_pos_encoding:
+            x = x + self.pos_embedding[:, :x.shape[1], :]
+        for layer in self.encoder_layers:
+            x = layer(x)
+        return _ops.layer_norm(x, self.norm.weight, self.norm.bias)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# embeddings (reference models.py:146-257): one token per WHOLE frame
+# ------------------------------------------------------------------------------------------------------------
+class LinearProjectionEmbedding(nn.Module):
+    _mivit_embedding = N.EMBED_LINEAR
+
+    def __init__(self, patch_size, embed_dim):
+        super().__init__()
+        self.patch_size = patch_size
+        self.embed_dim = embed_dim
+        self.proj = nn.Linear(patch_size * patch_size, embed_dim)
+
+    def forward(self, x):
+        if x.dim() == 3:
+            n, h, w = x.shape
+            assert h == w == self.patch_size, "Patch size mismatch"
+            return _ops.linear(x.reshape(1, n, h * w), self.proj.weight, self.proj.bias)
+        if x.dim() == 4:
+            b, n, h, w = x.shape
+            assert h == w == self.patch_size, "Patch size mismatch"
+            return _ops.linear(x.reshape(b, n, h * w), self.proj.weight, self.proj.bias)
+        raise ValueError(f"Unexpected input shape: {x.shape}. Expected (num_images, C, H, W) or (B, num_images, C, H, W).")
+
+
+class CNNEmbedding(nn.Module):
+    """Conv2d(1, E, kernel = whole frame): the same contraction as the linear embedding with the weight viewed
+    (E, 1, P, P) -- it shares the patch-embedding GEMM kernel (reference models.py:170-199)."""
+    _mivit_embedding = N.EMBED_CNN
+
+    def __init__(self, patch_size, embed_dim):
+        super().__init__()
+        self.patch_size = patch_size
+        self.embed_dim = embed_dim
+        self.conv = nn.Conv2d(in_channels=1, out_channels=embed_dim, kernel_size=(patch_size, patch_size))
+
+    def forward(self, x):
+        b, n, h, w = x.shape
+        assert h == w == self.patch_size, "Patch size mismatch"
+        return _ops.linear(x.reshape(b, n, h * w), self.conv.weight.reshape(self.embed_dim, h * w), self.conv.bias)
+
+
+class ResidualBlock(nn.Module):
+    def __init__(self, in_channels, out_channels, downsample=False):
+        super().__init__()
+        stride = 2 if downsample else 1
+        self.conv1 = nn.Conv2d(in_channels, out_channels, kernel_size=3, padding=1, stride=stride, bias=False)
+        self.bn1 = nn.BatchNorm2d(out_channels)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(out_channels, out_channels, kernel_size=3, padding=1, stride=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(out_channels)
+        self.skip = nn.Sequential()
+        if in_channels != out_channels or downsample:
+            self.skip = nn.Sequential(nn.Conv2d(in_channels, out_channels, kernel_size=1, stride=stride, bias=False),
+                                      nn.BatchNorm2d(out_channels))
+
+    def forward(self, x):
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.bn2(self.conv2(out))
+        return self.relu(out + self.skip(x))
+
+
+class DeepResNetEmbedding(nn.Module):
+    """Per-frame conv stack (reference models.py:230-257).  NOT yet a hand-written HIP kernel: it runs on stock
+    PyTorch-ROCm (MIOpen) and hands pre-norm tokens [B,T,E] to the HIP engine (MIVIT_EMBED_EXTERNAL).
+    ``patch_size`` is accepted and ignored, as in the reference."""
+    _mivit_embedding = N.EMBED_EXTERNAL
+
+    def __init__(self, patch_size=7, embed_dim=128):
+        super().__init__()
+        self.initial_conv = nn.Conv2d(1, 32, kernel_size=3, padding=1, bias=False)
+        self.bn1 = nn.BatchNorm2d(32)
+        self.relu = nn.ReLU(inplace=True)
+        self.res_block1 = ResidualBlock(32, 64)
+        self.res_block2 = ResidualBlock(64, 128)
+        self.global_pool = nn.AdaptiveAvgPool2d((1, 1))
+        self.fc = nn.Linear(128, embed_dim)
+
+    def forward(self, x):
+        b, n, h, w = x.shape
+        y = x.reshape(b * n, 1, h, w)
+        y = self.relu(self.bn1(self.initial_conv(y)))
+        y = self.res_block2(self.res_block1(y))
+        y = self.global_pool(y).view(b, n, -1)
+        return self.fc(y)
+
+
+class MLPHead(nn.Module):
+    def __init__(self, input_dim, hidden_dim=128, output_dim=1, dropout=0.0, activation=nn.ReLU):
+        super().__init__()
+        self.mlp = nn.Sequential(
+            nn.Linear(input_dim, hidden_dim),
+            activation(),
+            nn.Dropout(dropout) if dropout > 0 else nn.Identity(),
+            nn.Linear(hidden_dim, output_dim),
+        )
+
+    def forward(self, x):
+        act = _act_code(self.mlp[1])
+        _require_no_dropout(getattr(self.mlp[2], "p", 0.0))
+        h = _ops.linear(x, self.mlp[0].weight, self.mlp[0].bias, act=act)
+        return _ops.linear(h, self.mlp[3].weight, self.mlp[3].bias)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# the model
+# ------------------------------------------------------------------------------------------------------------
+class GeneralTransformer(nn.Module):
+    """MiViT: frame embedding -> LayerNorm -> [reg token | tokens] -> L post-norm encoder layers -> LayerNorm ->
+    readout -> MLP head (reference models.py:278-361).  ``precision`` ("fp32" parity mode / "bf16") is the only
+    argument the reference does not have; default from $MIVIT_PRECISION, else "fp32"."""
+
+    def __init__(self, embedding_cls, embed_kwargs, embed_dim, num_heads, hidden_dim, num_layers, mlp_head,
+                 tr_activation_fct, dropout=0, use_pos_encoding=False, use_regression_token=False,
+                 single_prediction=True, use_global_features=False, fusion_type='early', global_feature_dim=None,
+                 precision: Optional[str] = None):
+        super().__init__()
+        _require_no_dropout(dropout)
+        self.embed_dim = embed_dim
+        self.embedding = embedding_cls(**embed_kwargs)
+        self.norm = nn.LayerNorm(embed_dim)
+        self.use_regression_token = use_regression_token
+        self.single_prediction = single_prediction
+        self.use_global_features = use_global_features
+        self.fusion_type = fusion_type
+        if use_regression_token:
+            self.reg_token = nn.Parameter(torch.randn(1, 1, embed_dim))
+        self.transformer = Transformer(embed_dim, num_heads, hidden_dim, num_layers, dropout,
+                                       use_pos_encoding=use_pos_encoding, activation_fct=tr_activation_fct)
+        if use_global_features:
+            assert global_feature_dim is not None, "Must provide global_feature_dim if using global features"
+            self.feature_projector = nn.Sequential(nn.Linear(global_feature_dim, embed_dim), nn.ReLU(),
+                                                   nn.Linear(embed_dim, embed_dim))
+        if fusion_type == 'late' and use_global_features:
+            self.mlp_head = mlp_head(input_dim=embed_dim * 2)
+        else:
+            self.mlp_head = mlp_head(input_dim=embed_dim)
+
+        # ---- native plan + parameter arena ----
+        head = self.mlp_head
+        if not (hasattr(head, "mlp") and len(head.mlp) == 4 and isinstance(head.mlp[0], nn.Linear)
+                and isinstance(head.mlp[3], nn.Linear) and isinstance(head.mlp[1], nn.ReLU)
+                and not isinstance(head.mlp[2], nn.Dropout)):
+            raise NotImplementedError("the HIP path supports MLPHead(Linear, ReLU, Identity, Linear) heads only")
+        fusion = N.FUSION_NONE
+        if use_global_features and fusion_type == 'late':
+            fusion = N.FUSION_LATE
+        elif use_global_features and fusion_type == 'early' and use_regression_token:
+            fusion = N.FUSION_EARLY      # (without a regression token the reference never uses the features)
+        self._plan_kwargs = dict(
+            embedding=getattr(self.embedding, "_mivit_embedding", N.EMBED_EXTERNAL),
+            patch_size=int(getattr(self.embedding, "patch_size", 0) or 0), embed_dim=embed_dim, num_heads=num_heads,
+            hidden_dim=hidden_dim, num_layers=num_layers, activation=_act_code(tr_activation_fct),
+            use_pos_encoding=bool(use_pos_encoding), use_regression_token=bool(use_regression_token), fusion=fusion,
+            global_feature_dim=int(global_feature_dim or 0), head_hidden=head.mlp[0].out_features,
+            output_dim=head.mlp[3].out_features)
+        self._fusion = fusion
+        self._arena = None
+        self._arena_version = 0
+        self._dp = None
+        self.set_precision(precision or _default_precision())
+
+    # -- plan / arena management ------------------------------------------------------------------------
+    def set_precision(self, precision: str):
+        """'fp32': fp32 MFMA, the 1e-4 parity mode.  'bf16': bf16 MFMA operands / stored activations."""
+        self.precision = precision
+        self._plan = MivitPlan(precision=precision, **self._plan_kwargs)
+        self._flatten()
+        return self
+
+    def _flatten(self):
+        """(Re)pack every plan parameter into one contiguous fp32 arena and re-point the nn.Parameters at it."""
+        plan = self._plan
+        named = dict(self.named_parameters())
+        missing = [n for n in plan.param_names if n not in named]
+        if missing:
+            raise RuntimeError(f"model is missing parameters the native plan expects: {missing}")
+        dev = named[plan.param_names[0]].device
+        arena = torch.zeros(plan.arena_numel, dtype=torch.float32, device=dev)
+        params = []
+        with torch.no_grad():
+            for name, off, n in zip(plan.param_names, plan.param_offsets, plan.param_numels):
+                p = named[name]
+                if p.dtype != torch.float32:
+                    raise TypeError(f"{name}: master parameters must stay fp32 (got {p.dtype}); use precision='bf16' "
+                                    "for bf16 compute")
+                assert p.numel() == n, (name, tuple(p.shape), n)
+                view = arena[off:off + n].view(p.shape)
+                view.copy_(p.data)
+                p.data = view
+                params.append(p)
+        self._arena, self._arena_params = arena, params
+        self._arena_shapes = [tuple(p.shape) for p in params]
+        self._arena_version += 1
+
+    def _arena_ok(self) -> bool:
+        base = self._arena.data_ptr()
+        return all(p.data_ptr() == base + 4 * off for p, off in zip(self._arena_params, self._plan.param_offsets))
+
+    def _apply(self, fn, recurse=True):
+        out = super()._apply(fn, recurse)
+        if getattr(self, "_arena", None) is not None:
+            self._flatten()
+        return out
+
+    def _grad_views(self, grads: torch.Tensor):
+        plan = self._plan
+        return [grads[off:off + n].view(shape)
+                for off, n, shape in zip(plan.param_offsets, plan.param_numels, self._arena_shapes)]
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state["_plan"] = None
+        state["_arena"] = None
+        state["_dp"] = None
+        return state
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+        self._plan = MivitPlan(precision=self.precision, **self._plan_kwargs)
+        self._flatten()
+
+    # -- forward --------------------------------------------------------------------------------------------
+    def forward(self, x, features=None):
+        """x: [batch, num_images, image_size, image_size]; features: [batch, num_features] or None."""
+        if not self._arena_ok():
+            self._flatten()
+        emb_kind = self._plan.embedding
+        if emb_kind == N.EMBED_EXTERNAL:
+            tokens = self.embedding(x)                       # [B, T, E] through PyTorch-ROCm autograd
+        else:
+            if x.dim() == 3:
+                x = x.unsqueeze(0)
+            if x.dim() != 4:
+                raise ValueError(f"Unexpected input shape: {x.shape}. Expected (num_images, C, H, W) or "
+                                 f"(B, num_images, C, H, W).")
+            assert x.shape[2] == x.shape[3] == self.embedding.patch_size, "Patch size mismatch"
+            tokens = x
+        feats = None
+        if self._fusion == N.FUSION_EARLY:
+            assert features is not None, "Global features required for early fusion"
+            feats = features
+        elif self._fusion == N.FUSION_LATE:
+            assert features is not None, "Global features required for late fusion"
+            feats = features
+        return MivitFunction.apply(self, tokens, feats, *self._arena_params)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# datasets used by the training scripts (reference models.py:781-803)
+# ------------------------------------------------------------------------------------------------------------
+class ImageDataset(Dataset):
+    def __init__(self, images, labels):
+        self.images, self.labels = images, labels
+
+    def __len__(self):
+        return len(self.images)
+
+    def __getitem__(self, idx):
+        return self.images[idx], self.labels[idx]
+
+
+class ImageFeatureDataset(Dataset):
+    def __init__(self, images, features, labels):
+        self.images, self.features, self.labels = images, features, labels
+
+    def __len__(self):
+        return len(self.images)
+
+    def __getitem__(self, idx):
+        return self.images[idx], self.features[idx], self.labels[idx]

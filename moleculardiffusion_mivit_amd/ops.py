@@ -1,0 +1,159 @@
+"""Operator-level autograd wrappers over the C-ABI kernels (include/mivit_hip.h, "Operator level").
+
+Each function mirrors one torch op of the reference path (nn.Linear(+activation), nn.LayerNorm, the attention
+core of MultiHeadAttention) and differentiates through the matching hand-written backward kernels.  Tensors must
+be on the GPU; x may be float32 (fp32 MFMA) or bfloat16 (bf16 MFMA); weights / LayerNorm parameters are fp32.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import _native as N
+
+
+def _dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return N.F32
+    if t.dtype == torch.bfloat16:
+        return N.BF16
+    raise TypeError(f"unsupported dtype {t.dtype} (float32 or bfloat16)")
+
+
+def _gpu(*ts):
+    for t in ts:
+        if t is not None and t.device.type != "cuda":
+            raise RuntimeError("MiViT HIP operators need GPU tensors (no CPU fallback exists in this package)")
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _s(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+class _Linear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, W, b, act):
+        _gpu(x, W, b)
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1]).contiguous()
+        W = W.contiguous().float()
+        bb = b.contiguous().float() if b is not None else None
+        M, K = x2.shape
+        Nn = W.shape[0]
+        y = torch.empty(M, Nn, dtype=x2.dtype, device=x2.device)
+        pre = torch.empty_like(y) if act == N.ACT_GELU else None
+        N.check(N.lib.mivit_linear_fwd(_dt(x2), _p(x2), 0, K, _p(W), _p(bb), M, Nn, K, act, None, 0, _p(y), Nn,
+                                       _p(pre), _s(x2)), "mivit_linear_fwd")
+        ctx.save_for_backward(x2, W, pre if pre is not None else y)
+        ctx.act, ctx.shp, ctx.has_b = act, shp, b is not None
+        return y.reshape(*shp[:-1], Nn)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, W, saved = ctx.saved_tensors
+        M, K = x2.shape
+        Nn = W.shape[0]
+        dy2 = dy.reshape(M, Nn).contiguous().to(x2.dtype)
+        dt = _dt(x2)
+        if ctx.act != N.ACT_NONE:   # fold act' into dy first: d(pre) = dy * act'(saved)
+            # the dgrad kernel applies act' to ITS output; here act sits on the linear's output, so use a tiny
+            # identity-dgrad trick-free path: elementwise in torch (glue) -- kept out of the fused engine path.
+            if ctx.act == N.ACT_RELU:
+                dy2 = dy2 * (saved > 0).to(dy2.dtype)
+            elif ctx.act == N.ACT_LEAKY_RELU:
+                dy2 = dy2 * torch.where(saved > 0, 1.0, 0.01).to(dy2.dtype)
+            else:
+                u = saved.float()
+                cdf = 0.5 * (1 + torch.erf(u * 0.7071067811865476))
+                pdf = torch.exp(-0.5 * u * u) * 0.3989422804014327
+                dy2 = (dy2.float() * (cdf + u * pdf)).to(dy2.dtype)
+            dy2 = dy2.contiguous()
+        dx = torch.empty_like(x2)
+        N.check(N.lib.mivit_linear_dgrad(dt, _p(dy2), Nn, _p(W), M, Nn, K, N.ACT_NONE, None, 0, None, 0, _p(dx), K,
+                                         _s(x2)), "mivit_linear_dgrad")
+        dW = torch.empty_like(W)
+        db = torch.empty(Nn, dtype=torch.float32, device=W.device) if ctx.has_b else None
+        wsb = N.lib.mivit_linear_wgrad_workspace_bytes(M, Nn, K)
+        ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=W.device)
+        N.check(N.lib.mivit_linear_wgrad(dt, _p(dy2), Nn, _p(x2), 0, K, M, Nn, K, _p(dW), _p(db), 0, _p(ws), ws.numel(),
+                                         _s(x2)), "mivit_linear_wgrad")
+        return dx.reshape(ctx.shp), dW, db, None
+
+
+def linear(x, W, b=None, act=N.ACT_NONE):
+    """act(x @ W^T + b): nn.Linear (+ relu / leaky_relu / gelu)."""
+    return _Linear.apply(x, W, b, act)
+
+
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b):
+        _gpu(x, w, b)
+        shp = x.shape
+        E = shp[-1]
+        x2 = x.reshape(-1, E).contiguous()
+        w, b = w.contiguous().float(), b.contiguous().float()
+        M = x2.shape[0]
+        y = torch.empty_like(x2)
+        mean = torch.empty(M, dtype=torch.float32, device=x2.device)
+        rstd = torch.empty_like(mean)
+        N.check(N.lib.mivit_layernorm_fwd(_dt(x2), _p(x2), E, _p(w), _p(b), M, E, _p(y), E, 0, 0, 0, None, _p(mean),
+                                          _p(rstd), _s(x2)), "mivit_layernorm_fwd")
+        ctx.save_for_backward(x2, w, mean, rstd)
+        ctx.shp = shp
+        return y.reshape(shp)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w, mean, rstd = ctx.saved_tensors
+        M, E = x2.shape
+        dy2 = dy.reshape(M, E).contiguous().to(x2.dtype)
+        dx = torch.empty_like(x2)
+        dg = torch.empty(E, dtype=torch.float32, device=x2.device)
+        db = torch.empty_like(dg)
+        wsb = N.lib.mivit_layernorm_bwd_workspace_bytes(M, E)
+        ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=x2.device)
+        N.check(N.lib.mivit_layernorm_bwd(_dt(x2), _p(dy2), E, _p(x2), E, _p(w), _p(mean), _p(rstd), M, E, 0, 0, 0,
+                                          _p(dx), E, _p(dg), _p(db), 0, _p(ws), ws.numel(), _s(x2)),
+                "mivit_layernorm_bwd")
+        return dx.reshape(ctx.shp), dg, db
+
+
+def layer_norm(x, weight, bias):
+    """nn.LayerNorm over the last dimension (eps 1e-5)."""
+    return _LayerNorm.apply(x, weight, bias)
+
+
+class _Attention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, H):
+        _gpu(qkv)
+        B, S, E3 = qkv.shape
+        E = E3 // 3
+        qkv = qkv.contiguous()
+        out = torch.empty(B, S, E, dtype=qkv.dtype, device=qkv.device)
+        N.check(N.lib.mivit_attention_fwd(_dt(qkv), _p(qkv), B, S, H, E // H, _p(out), _s(qkv)), "mivit_attention_fwd")
+        ctx.save_for_backward(qkv)
+        ctx.H = H
+        return out
+
+    @staticmethod
+    def backward(ctx, dctx):
+        (qkv,) = ctx.saved_tensors
+        B, S, E3 = qkv.shape
+        E = E3 // 3
+        dctx = dctx.contiguous().to(qkv.dtype)
+        dqkv = torch.empty_like(qkv)
+        N.check(N.lib.mivit_attention_bwd(_dt(qkv), _p(qkv), _p(dctx), B, S, ctx.H, E // ctx.H, _p(dqkv), _s(qkv)),
+                "mivit_attention_bwd")
+        return dqkv, None
+
+
+def attention(qkv, num_heads):
+    """softmax(q k^T / sqrt(Dh)) v per head, heads merged.  qkv: [B, S, 3E] = [q | k | v] per token."""
+    return _Attention.apply(qkv, num_heads)

@@ -1,0 +1,75 @@
+"""Shared helpers for the parity tests (the oracle is the checker, never the thing under test)."""
+import json
+import os
+
+import numpy as np
+import torch
+
+from oracle import mivit_oracle as orc
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def golden_cases():
+    return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz"))
+
+
+def load_golden(name):
+    fx = np.load(os.path.join(GOLDEN, name + ".npz"))
+    meta = json.loads(str(fx["meta"]))
+    cfg = orc.MiViTConfig(**meta["config"])
+    return fx, meta, cfg
+
+
+def golden_inputs(meta, cfg):
+    params = orc.closed_form_params(cfg)
+    x, labels, feats = orc.closed_form_batch(meta["B"], meta["T"], cfg.patch_size, cfg.global_feature_dim,
+                                             salt=meta["salt"])
+    if cfg.output_dim > 1:
+        labels = labels.repeat(1, cfg.output_dim) * torch.linspace(0.5, 1.0, cfg.output_dim)
+    return params, x, labels, feats
+
+
+def sample_idx(n, k=256):
+    if n <= k:
+        return np.arange(n)
+    return (np.arange(k, dtype=np.int64) * 2654435761 % n).astype(np.int64)
+
+
+def rel_err(a, b):
+    """max |a-b| / max |b| (tensor-wise relative error)."""
+    a = torch.as_tensor(a).double().cpu()
+    b = torch.as_tensor(b).double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def norm_err(a, b):
+    a = torch.as_tensor(a).double().cpu()
+    b = torch.as_tensor(b).double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+EMB = {"linear": "LinearProjectionEmbedding", "cnn": "CNNEmbedding", "deepresnet": "DeepResNetEmbedding"}
+
+
+def build_product_model(cfg, precision="fp32", params=None, device="cuda"):
+    """Construct the product GeneralTransformer for an oracle config and load reference-keyed weights."""
+    from functools import partial
+    import torch.nn.functional as F
+    from moleculardiffusion_mivit_amd.helpers import models as M
+    act = {"relu": F.relu, "leaky_relu": F.leaky_relu, "gelu": F.gelu}[cfg.activation]
+    head = partial(M.MLPHead, hidden_dim=cfg.head_hidden, output_dim=cfg.output_dim)
+    m = M.GeneralTransformer(
+        embedding_cls=getattr(M, EMB[cfg.embedding]),
+        embed_kwargs={"patch_size": cfg.patch_size, "embed_dim": cfg.embed_dim},
+        embed_dim=cfg.embed_dim, num_heads=cfg.num_heads, hidden_dim=cfg.hidden_dim, num_layers=cfg.num_layers,
+        mlp_head=head, tr_activation_fct=act, dropout=0.0, use_pos_encoding=cfg.use_pos_encoding,
+        use_regression_token=cfg.use_regression_token, single_prediction=True,
+        use_global_features=cfg.use_global_features, fusion_type=cfg.fusion_type,
+        global_feature_dim=cfg.global_feature_dim, precision=precision)
+    if params is not None:
+        sd = m.state_dict()
+        missing = [k for k in sd if k not in params and not k.endswith("num_batches_tracked")]
+        assert not missing, missing
+        m.load_state_dict({k: params[k] for k in sd if k in params}, strict=False)
+    return m.to(device)
