@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""MiViT training-throughput benchmark (BASELINE.json metric: training image-sequences/sec).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One step = zero_grad + forward + MSELoss + backward (+ per-stage gradient all-reduce over RCCL when N > 1) +
+AdamW.step, on the PSFNoise 32-frame 64x64 configuration (ViT depth 4, dim 128, 4 heads, hidden 256, linear frame
+embedding, regression token) -- BASELINE.json configs[1] -- with synthetic sequences already resident in HBM.
+Weak scaling: the per-GPU batch is fixed, each rank draws its own shard (seed + rank).
+Prints ONE JSON line on rank 0 (see the contract in the task prompt), including `roofline` for the dominant
+kernel (timed with hipEvents inside the library over the timed region) and `cpu_baseline` (the oracle's plain
+PyTorch CPU restatement timed on this host, rank 0, N = 1 only).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+MFMA_PEAK = {"bf16": 2500.0, "fp32": 157.3}   # dense TFLOP/s
+
+CFG = dict(patch_size=64, embed_dim=128, num_heads=4, hidden_dim=256, num_layers=4, frames=32)
+
+
+def synth(B, T, P, seed, device):
+    """Synthetic PSF-blob sequences generated ON the GPU: background N(0.2, 0.06^2) + one Gaussian spot
+    doing Brownian motion with D ~ U(0.1, 10); label D / 10."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    D = torch.rand(B, generator=g, device=device) * 9.9 + 0.1
+    steps = torch.randn(B, T, 2, generator=g, device=device) * torch.sqrt(2 * D * 0.01).view(B, 1, 1) * (P / 9.0)
+    pos = torch.cumsum(steps, dim=1)
+    pos = pos - pos.mean(dim=1, keepdim=True) + (P - 1) / 2.0
+    yy = torch.arange(P, dtype=torch.float32, device=device).view(1, 1, P, 1)
+    xx = torch.arange(P, dtype=torch.float32, device=device).view(1, 1, 1, P)
+    sig = 1.1 * P / 9.0
+    x = torch.randn(B, T, P, P, generator=g, device=device) * 0.06 + 0.2
+    x += 0.6 * torch.exp(-((yy - pos[..., 1].view(B, T, 1, 1)) ** 2 + (xx - pos[..., 0].view(B, T, 1, 1)) ** 2)
+                         / (2 * sig * sig))
+    return x.contiguous(), (D / 10.0).view(B, 1).contiguous()
+
+
+def flops_per_seq(T, P, E, H, Fh, L, head_hidden=128):
+    S = T + 1
+    embed = 2 * T * P * P * E
+    layer = 6 * S * E * E + 4 * S * S * E + 2 * S * E * E + 4 * S * E * Fh
+    head = 2 * E * head_hidden + 2 * head_hidden
+    return {"embed_fwd": embed, "attn_mlp_fwd": L * layer, "total_fwd": embed + L * layer + head}
+
+
+def cpu_baseline(seconds=12.0):
+    """The oracle's plain-PyTorch fp32 restatement of the same step on the host cores (kind = 'port')."""
+    from oracle import mivit_oracle as orc
+    cfg = orc.MiViTConfig(embedding="linear", patch_size=CFG["patch_size"], embed_dim=CFG["embed_dim"],
+                          num_heads=CFG["num_heads"], hidden_dim=CFG["hidden_dim"], num_layers=CFG["num_layers"])
+    torch.manual_seed(0)
+    m = orc.OracleModule(cfg, seed=0)
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-4)
+    B = 32
+    x, y, _ = orc.synthetic_batch(B, CFG["frames"], CFG["patch_size"], seed=1234)
+
+    def step():
+        opt.zero_grad()
+        loss = F.mse_loss(m(x), y)
+        loss.backward()
+        opt.step()
+    for _ in range(2):
+        step()
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        step()
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": round(n * B / dt, 2), "unit": "sequences/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} steps of batch {B} ({n * B} sequences, {dt:.1f} s) of the same 32x64x64 depth-4 dim-128 "
+                      f"train step, oracle/mivit_oracle.py on torch CPU fp32"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch-per-gpu", type=int, default=int(os.environ.get("MIVIT_BENCH_BATCH", 2048)))
+    ap.add_argument("--precision", default=os.environ.get("MIVIT_BENCH_PRECISION", "bf16"), choices=["bf16", "fp32"])
+    ap.add_argument("--resident-batches", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--breakdown", action="store_true", help="print the per-kernel-category time table to stderr")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            print(f"bench.py: --gpus {args.gpus} needs the torch.distributed.run launcher (WORLD_SIZE=1 here)",
+                  file=sys.stderr)
+            sys.exit(2)
+    import torch.distributed as dist
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    from moleculardiffusion_mivit_amd import _native as N
+    from moleculardiffusion_mivit_amd import dp
+    from moleculardiffusion_mivit_amd.helpers.models import GeneralTransformer, LinearProjectionEmbedding, MLPHead
+
+    T, P, E, H, Fh, L = (CFG["frames"], CFG["patch_size"], CFG["embed_dim"], CFG["num_heads"], CFG["hidden_dim"],
+                         CFG["num_layers"])
+    torch.manual_seed(0)
+    model = GeneralTransformer(LinearProjectionEmbedding, {"patch_size": P, "embed_dim": E}, E, H, Fh, L, MLPHead,
+                               F.relu, dropout=0.0, use_pos_encoding=False, use_regression_token=True,
+                               precision=args.precision).to(dev)
+    model.train()
+    if world > 1:
+        dp.attach(model)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, fused=True)
+    Bg = args.batch_per_gpu
+    data = [synth(Bg, T, P, 1234 + rank + 1000 * i, dev) for i in range(args.resident_batches)]
+    loss_fn = torch.nn.MSELoss()
+
+    def step(i):
+        x, y = data[i % len(data)]
+        opt.zero_grad(set_to_none=True)
+        loss = loss_fn(model(x), y)
+        loss.backward()
+        opt.step()
+        return loss
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- warmup; the last warmup steps time every kernel category to find the dominant one ----
+    nprof = min(2, args.warmup)
+    for i in range(args.warmup - nprof):
+        step(i)
+    torch.cuda.synchronize()
+    N.lib.mivit_profile_enable(ctypes.c_uint64((1 << len(N.PROF_TAGS)) - 1))
+    for i in range(nprof):
+        step(i)
+    torch.cuda.synchronize()
+    cat = {}
+    for t, name in enumerate(N.PROF_TAGS):
+        ms, cnt = ctypes.c_double(), ctypes.c_int()
+        N.lib.mivit_profile_collect(t, ctypes.byref(ms), ctypes.byref(cnt))
+        cat[name] = (ms.value / max(nprof, 1), cnt.value // max(nprof, 1))
+    dominant = max(("embed_fwd", "embed_wgrad", "linear_fwd", "linear_dgrad", "linear_wgrad", "attn_fwd", "attn_bwd"),
+                   key=lambda k: cat[k][0] / max(cat[k][1], 1)) if nprof else "embed_fwd"
+    if args.breakdown and rank == 0:
+        tot = sum(v[0] for v in cat.values())
+        for k, (ms, c) in sorted(cat.items(), key=lambda kv: -kv[1][0]):
+            print(f"  {k:14s} {ms:9.3f} ms/step  {c:4d} launches/step  {100 * ms / max(tot, 1e-9):5.1f}%", file=sys.stderr)
+    dom_tag = N.PROF_TAGS.index(dominant)
+    N.lib.mivit_profile_enable(ctypes.c_uint64(1 << dom_tag))
+
+    # ---- timed region: EXACTLY --steps steps ----
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ms, cnt = ctypes.c_double(), ctypes.c_int()
+    N.lib.mivit_profile_collect(dom_tag, ctypes.byref(ms), ctypes.byref(cnt))
+    N.lib.mivit_profile_enable(ctypes.c_uint64(0))
+
+    # ---- val MSE(D) on a held-out synthetic shard (pred * 10 vs D; trainModelsPSFNoise.py:224-229) ----
+    model.eval()
+    with torch.no_grad():
+        xv, yv = synth(min(Bg, 1024), T, P, 99991 + rank, dev)
+        val_mse = float(F.mse_loss(model(xv) * 10.0, yv * 10.0))
+
+    if rank == 0:
+        seqs = args.steps * Bg * world
+        fl = flops_per_seq(T, P, E, H, Fh, L)
+        k_ms = ms.value / max(cnt.value, 1)
+        roof = None
+        if cnt.value:
+            if dominant in ("embed_fwd", "embed_wgrad"):
+                # algorithmic bytes per launch: the fp32 frames of the per-GPU batch, read once, + weight + output
+                ts = 2 if args.precision == "bf16" else 4
+                byt = Bg * T * P * P * 4 + E * P * P * 4 + Bg * T * E * ts
+                ach = byt / (k_ms * 1e-3) / 1e9
+                roof = {"kernel": dominant, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                        "launch_ms": round(k_ms, 4), "launches_timed": cnt.value,
+                        "algorithmic_bytes_per_launch": byt}
+            else:
+                S = T + 1
+                per = {"linear_fwd": (6 + 2) * S * E * E + 4 * S * E * Fh, "linear_dgrad": (6 + 2) * S * E * E + 4 * S * E * Fh,
+                       "linear_wgrad": (6 + 2) * S * E * E + 4 * S * E * Fh, "attn_fwd": 4 * S * S * E,
+                       "attn_bwd": 10 * S * S * E}[dominant]
+                launches_per_layer = {"linear_fwd": 4, "linear_dgrad": 4, "linear_wgrad": 4, "attn_fwd": 1, "attn_bwd": 1}[dominant]
+                fl_launch = per * Bg / launches_per_layer
+                ach = fl_launch / (k_ms * 1e-3) / 1e12
+                pk = MFMA_PEAK[args.precision]
+                roof = {"kernel": dominant, "bound": "mfma", "achieved": round(ach, 2), "peak": pk, "unit": "TFLOP/s",
+                        "frac": round(ach / pk, 4), "traffic": None, "launch_ms": round(k_ms, 4),
+                        "launches_timed": cnt.value}
+        line = {
+            "metric": "training image-sequences/sec", "value": round(seqs / dt, 1), "unit": "sequences/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision,
+            "data": "synthetic",
+            "config": {"workload": "PSFNoise 32-frame 64x64 sequences, MiViT depth=4 dim=128 heads=4 hidden=256, linear "
+                                   "frame embedding + regression token; train step = fwd + MSE + bwd + AdamW",
+                       "per_gpu_batch": Bg, "global_batch": Bg * world, "frames": T, "frame": f"{P}x{P}",
+                       "parallelism": f"dp{world}", "input_dtype": "f32 frames resident in HBM"},
+            "val_mse_D": round(val_mse, 4),
+            "model_tflops": round(3 * fl["total_fwd"] * seqs / dt / 1e12, 2),
+            "attn_mlp_mfma_frac": round(3 * fl["attn_mlp_fwd"] * seqs / dt / 1e12 / world / MFMA_PEAK[args.precision], 5),
+            "roofline": roof,
+            "kernel_ms_per_step": {k: round(v[0], 4) for k, v in cat.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

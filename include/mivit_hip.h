@@ -146,6 +146,29 @@ int mivit_backward(const mivit_plan *plan, const float *params, const float *x, 
                    float *grads, float *dfeatures, float *dx_tokens,
                    int stage_begin, int stage_end, void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * In-library kernel timing (used by bench.py for the roofline line): when a tag's bit is set in `tag_mask`, the
+ * MAIN kernel of every launch in that category is bracketed by a hipEvent pair on the launch stream.
+ * mivit_profile_collect waits for the recorded events, returns their summed duration and count, and resets
+ * the tag.  Tags refer to the model-level engine's launches (operator-level calls are tagged MIVIT_PROF_OP).
+ * ---------------------------------------------------------------------------------------------- */
+enum {
+    MIVIT_PROF_EMBED_FWD = 0,   /* patch-embedding GEMM  [B*T,P*P] x [E,P*P]^T            (HBM-bound)  */
+    MIVIT_PROF_EMBED_WGRAD = 1, /* its weight gradient   d_emb^T x, re-reads the frames  (HBM-bound)  */
+    MIVIT_PROF_LINEAR_FWD = 2,  /* qkv / out-proj / fc1 / fc2 / head forward GEMMs                     */
+    MIVIT_PROF_LINEAR_DGRAD = 3,
+    MIVIT_PROF_LINEAR_WGRAD = 4,
+    MIVIT_PROF_ATTN_FWD = 5,
+    MIVIT_PROF_ATTN_BWD = 6,
+    MIVIT_PROF_LN_FWD = 7,
+    MIVIT_PROF_LN_BWD = 8,
+    MIVIT_PROF_OP = 9,
+    MIVIT_PROF_NUM_TAGS = 10
+};
+int mivit_profile_enable(uint64_t tag_mask);   /* 0 disables */
+int mivit_profile_collect(int tag, double *total_ms, int *count);
+const char *mivit_profile_tag_name(int tag);
+
 #ifdef __cplusplus
 }
 #endif

@@ -59,7 +59,12 @@ SYMBOLS = {
                               c_void_p, c_void_p]),
     "mivit_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p,
                                c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "mivit_profile_enable": (c_int, [ctypes.c_uint64]),
+    "mivit_profile_collect": (c_int, [c_int, POINTER(ctypes.c_double), POINTER(c_int)]),
+    "mivit_profile_tag_name": (c_char_p, [c_int]),
 }
+PROF_TAGS = ["embed_fwd", "embed_wgrad", "linear_fwd", "linear_dgrad", "linear_wgrad", "attn_fwd", "attn_bwd",
+             "ln_fwd", "ln_bwd", "op"]
 
 
 class MivitError(RuntimeError):

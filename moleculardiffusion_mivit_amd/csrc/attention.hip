@@ -317,6 +317,7 @@ int launch_fwd_nt(const T *qkv, T *ctx, const AttnDims &d, hipStream_t s) {
     if (bytes > 48 * 1024)
         MIVIT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     const int blocks = ceil_div(d.B * d.H, d.nw);
+    ProfScope prof(s);
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * d.nw), bytes, s, qkv, ctx, d);
     MIVIT_LAUNCH_CHECK();
     return 0;
@@ -328,6 +329,7 @@ int launch_bwd_nt(const T *qkv, const T *dctx, T *dqkv, const AttnDims &d, hipSt
     if (bytes > 48 * 1024)
         MIVIT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     const int blocks = ceil_div(d.B * d.H, d.nw);
+    ProfScope prof(s);
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * d.nw), bytes, s, qkv, dctx, dqkv, d);
     MIVIT_LAUNCH_CHECK();
     return 0;

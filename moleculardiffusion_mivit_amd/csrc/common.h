@@ -219,3 +219,13 @@ int launch_batch_colsum(int dtype, const void *x, int B, int S, int E, int s0, i
 int launch_convert(int src_is_f32, const void *src, int64_t lds_, int dst_dtype_is_f32, void *dst, int64_t ldd,
                    int rows, int cols, int accumulate, hipStream_t s);
 int launch_fill_zero(void *p, size_t bytes, hipStream_t s);
+
+// in-library kernel timing (misc.hip): the engine sets the category, launch sites bracket their main kernel
+void prof_set_tag(int tag);
+bool prof_begin(hipStream_t s);
+void prof_end(hipStream_t s);
+struct ProfScope {
+    hipStream_t s; bool on;
+    explicit ProfScope(hipStream_t st) : s(st), on(prof_begin(st)) {}
+    ~ProfScope() { if (on) prof_end(s); }
+};

@@ -122,6 +122,7 @@ int lin_fwd(int dtype, const void *x, int x_f32, int64_t ldx, const float *W, co
     a.dtype = dtype; a.x = x; a.x_is_f32 = x_f32 || dtype == MIVIT_F32; a.ldx = ldx; a.W = W; a.bias = b;
     a.M = M; a.N = N; a.K = K; a.act = act; a.resid = resid; a.ldr = ldr; a.y = y; a.ldy = ldy; a.y_preact = pre;
     a.y_is_f32 = y_f32;
+    prof_set_tag(x_f32 && K > 1024 ? MIVIT_PROF_EMBED_FWD : MIVIT_PROF_LINEAR_FWD);
     return launch_linear_fwd(a, s);
 }
 int lin_dgrad(int dtype, const void *dy, int64_t lddy, const float *W, int M, int N, int K, int act, const void *saved,
@@ -129,6 +130,7 @@ int lin_dgrad(int dtype, const void *dy, int64_t lddy, const float *W, int M, in
     LinearDgradArgs a = {};
     a.dtype = dtype; a.dy = dy; a.dy_is_f32 = dtype == MIVIT_F32; a.lddy = lddy; a.W = W; a.M = M; a.N = N; a.K = K;
     a.act = act; a.saved = saved; a.lds = lds; a.dres = dres; a.lddr = lddr; a.dx = dx; a.lddx = lddx; a.dx_is_f32 = dx_f32;
+    prof_set_tag(MIVIT_PROF_LINEAR_DGRAD);
     return launch_linear_dgrad(a, s);
 }
 int lin_wgrad(int dtype, const void *dy, int64_t lddy, const void *x, int x_f32, int64_t ldx, int M, int N, int K,
@@ -137,6 +139,7 @@ int lin_wgrad(int dtype, const void *dy, int64_t lddy, const void *x, int x_f32,
     a.dtype = dtype; a.dy = dy; a.dy_is_f32 = dtype == MIVIT_F32; a.lddy = lddy; a.x = x;
     a.x_is_f32 = x_f32 || dtype == MIVIT_F32; a.ldx = ldx; a.M = M; a.N = N; a.K = K; a.dW = dW; a.db = db;
     a.ws = ws; a.ws_bytes = wsb;
+    prof_set_tag(x_f32 && K > 1024 ? MIVIT_PROF_EMBED_WGRAD : MIVIT_PROF_LINEAR_WGRAD);
     return launch_linear_wgrad(a, s);
 }
 
@@ -304,7 +307,7 @@ extern "C" int mivit_forward(const mivit_plan *plan, const float *params, const 
         a.y = at(ws, w.x0); a.ldy = E; a.rows_per_seq = T; a.out_seq_stride = S; a.out_row_off = off;
         a.pos = c.use_pos_encoding ? P + plan->pos : nullptr;
         a.mean = static_cast<float *>(at(ws, w.mean0)); a.rstd = static_cast<float *>(at(ws, w.rstd0));
-        RC(launch_layernorm_fwd(a, s));
+        prof_set_tag(MIVIT_PROF_LN_FWD); RC(launch_layernorm_fwd(a, s));
     }
     // feature projector (models.py:316-320): Linear(Fg,E) -> ReLU -> Linear(E,E)
     if (c.fusion != MIVIT_FUSION_NONE) {
@@ -326,14 +329,14 @@ extern "C" int mivit_forward(const mivit_plan *plan, const float *params, const 
         const Ws::L &b = w.layer[l];
         RC(lin_fwd(dt, xin, 0, E, P + lp.qkv_w, P + lp.qkv_b, M, 3 * E, E, MIVIT_ACT_NONE, nullptr, 0, at(ws, b.qkv),
                    3 * E, nullptr, 0, s));
-        RC(launch_attention_fwd(dt, at(ws, b.qkv), B, S, H, Dh, at(ws, b.ctx), s));
+        prof_set_tag(MIVIT_PROF_ATTN_FWD); RC(launch_attention_fwd(dt, at(ws, b.qkv), B, S, H, Dh, at(ws, b.ctx), s));
         RC(lin_fwd(dt, at(ws, b.ctx), 0, E, P + lp.out_w, P + lp.out_b, M, E, E, MIVIT_ACT_NONE, xin, E, at(ws, b.z1), E,
                    nullptr, 0, s));
         LayerNormFwdArgs n1 = {};
         n1.dtype = dt; n1.z = at(ws, b.z1); n1.ldz = E; n1.gamma = P + lp.n1_w; n1.beta = P + lp.n1_b; n1.M = M; n1.E = E;
         n1.y = at(ws, b.x1); n1.ldy = E; n1.mean = static_cast<float *>(at(ws, b.mean1));
         n1.rstd = static_cast<float *>(at(ws, b.rstd1));
-        RC(launch_layernorm_fwd(n1, s));
+        prof_set_tag(MIVIT_PROF_LN_FWD); RC(launch_layernorm_fwd(n1, s));
         RC(lin_fwd(dt, at(ws, b.x1), 0, E, P + lp.fc1_w, P + lp.fc1_b, M, F, E, c.activation, nullptr, 0, at(ws, b.h), F,
                    c.activation == MIVIT_ACT_GELU ? at(ws, b.u) : nullptr, 0, s));
         RC(lin_fwd(dt, at(ws, b.h), 0, F, P + lp.fc2_w, P + lp.fc2_b, M, E, F, MIVIT_ACT_NONE, at(ws, b.x1), E,
@@ -341,7 +344,7 @@ extern "C" int mivit_forward(const mivit_plan *plan, const float *params, const 
         LayerNormFwdArgs n2 = n1;
         n2.z = at(ws, b.z2); n2.gamma = P + lp.n2_w; n2.beta = P + lp.n2_b; n2.y = at(ws, b.x2);
         n2.mean = static_cast<float *>(at(ws, b.mean2)); n2.rstd = static_cast<float *>(at(ws, b.rstd2));
-        RC(launch_layernorm_fwd(n2, s));
+        prof_set_tag(MIVIT_PROF_LN_FWD); RC(launch_layernorm_fwd(n2, s));
         xin = at(ws, b.x2);
     }
     // 5. final LayerNorm + readout (models.py:141, :351-354).  Only the regression-token row is normalised when it
@@ -352,10 +355,10 @@ extern "C" int mivit_forward(const mivit_plan *plan, const float *params, const 
         a.mean = static_cast<float *>(at(ws, w.meanF)); a.rstd = static_cast<float *>(at(ws, w.rstdF));
         if (c.use_regression_token) {
             a.M = B; a.y = at(ws, w.pooled); a.in_rows = 1; a.in_stride = S; a.in_off = 0;
-            RC(launch_layernorm_fwd(a, s));
+            prof_set_tag(MIVIT_PROF_LN_FWD); RC(launch_layernorm_fwd(a, s));
         } else {
             a.M = M; a.y = at(ws, w.xF);
-            RC(launch_layernorm_fwd(a, s));
+            prof_set_tag(MIVIT_PROF_LN_FWD); RC(launch_layernorm_fwd(a, s));
             RC(launch_mean_pool_fwd(dt, at(ws, w.xF), B, S, E, at(ws, w.pooled), s));
         }
     }
@@ -444,7 +447,7 @@ extern "C" int mivit_backward(const mivit_plan *plan, const float *params, const
             if (c.use_regression_token) {
                 RC(launch_fill_zero(at(ws, w.dxa), (size_t)M * E * dtype_size(dt), s));
                 a.dy = at(ws, w.d_head_in); a.lddy = Hin; a.M = B; a.z_rows = 1; a.z_stride = S; a.z_off = 0;
-                RC(launch_layernorm_bwd(a, s));
+                prof_set_tag(MIVIT_PROF_LN_BWD); RC(launch_layernorm_bwd(a, s));
             } else {
                 const void *dp = at(ws, w.d_head_in);
                 if (Hin != E) {
@@ -453,7 +456,7 @@ extern "C" int mivit_backward(const mivit_plan *plan, const float *params, const
                 }
                 RC(launch_mean_pool_bwd(dt, dp, B, S, E, at(ws, w.dxb), s));
                 a.dy = at(ws, w.dxb); a.lddy = E; a.M = M;
-                RC(launch_layernorm_bwd(a, s));
+                prof_set_tag(MIVIT_PROF_LN_BWD); RC(launch_layernorm_bwd(a, s));
             }
         } else if (st <= L) {
             // ---- encoder layer l = L - st; dxa holds d(x2) on entry and d(x_in) on exit ----
@@ -466,7 +469,7 @@ extern "C" int mivit_backward(const mivit_plan *plan, const float *params, const
             n2.mean = static_cast<const float *>(at(ws, b.mean2)); n2.rstd = static_cast<const float *>(at(ws, b.rstd2));
             n2.M = M; n2.E = E; n2.dz = at(ws, w.dxb); n2.lddz = E; n2.dgamma = G + lp.n2_w; n2.dbeta = G + lp.n2_b;
             n2.ws = at(ws, w.ln); n2.ws_bytes = w.ln_bytes;
-            RC(launch_layernorm_bwd(n2, s));                                                      // dxb = d(z2)
+            prof_set_tag(MIVIT_PROF_LN_BWD); RC(launch_layernorm_bwd(n2, s));                                                      // dxb = d(z2)
             RC(lin_wgrad(dt, at(ws, w.dxb), E, at(ws, b.h), 0, F, M, E, F, G + lp.fc2_w, G + lp.fc2_b, wg, wgb, s));
             RC(lin_dgrad(dt, at(ws, w.dxb), E, P + lp.fc2_w, M, E, F, c.activation,
                          c.activation == MIVIT_ACT_GELU ? at(ws, b.u) : at(ws, b.h), F, nullptr, 0, at(ws, w.dF), F, 0, s));
@@ -477,11 +480,11 @@ extern "C" int mivit_backward(const mivit_plan *plan, const float *params, const
             n1.dy = at(ws, w.dxa); n1.z = at(ws, b.z1); n1.gamma = P + lp.n1_w;
             n1.mean = static_cast<const float *>(at(ws, b.mean1)); n1.rstd = static_cast<const float *>(at(ws, b.rstd1));
             n1.dz = at(ws, w.dxb); n1.dgamma = G + lp.n1_w; n1.dbeta = G + lp.n1_b;
-            RC(launch_layernorm_bwd(n1, s));                                                      // dxb = d(z1)
+            prof_set_tag(MIVIT_PROF_LN_BWD); RC(launch_layernorm_bwd(n1, s));                                                      // dxb = d(z1)
             RC(lin_wgrad(dt, at(ws, w.dxb), E, at(ws, b.ctx), 0, E, M, E, E, G + lp.out_w, G + lp.out_b, wg, wgb, s));
             RC(lin_dgrad(dt, at(ws, w.dxb), E, P + lp.out_w, M, E, E, MIVIT_ACT_NONE, nullptr, 0, nullptr, 0,
                          at(ws, w.dctx), E, 0, s));
-            RC(launch_attention_bwd(dt, at(ws, b.qkv), at(ws, w.dctx), B, S, H, Dh, at(ws, w.dqkv), s));
+            prof_set_tag(MIVIT_PROF_ATTN_BWD); RC(launch_attention_bwd(dt, at(ws, b.qkv), at(ws, w.dctx), B, S, H, Dh, at(ws, w.dqkv), s));
             RC(lin_wgrad(dt, at(ws, w.dqkv), 3 * E, xin, 0, E, M, 3 * E, E, G + lp.qkv_w, G + lp.qkv_b, wg, wgb, s));
             RC(lin_dgrad(dt, at(ws, w.dqkv), 3 * E, P + lp.qkv_w, M, 3 * E, E, MIVIT_ACT_NONE, nullptr, 0, at(ws, w.dxb),
                          E, at(ws, w.dxa), E, 0, s));                                             // dxa = d(x_in)
@@ -501,7 +504,7 @@ extern "C" int mivit_backward(const mivit_plan *plan, const float *params, const
             a.M = Mt; a.E = E; a.rows_per_seq = T; a.in_seq_stride = S; a.in_row_off = off;
             a.dz = at(ws, w.dxb); a.lddz = E; a.dgamma = G + plan->n0_w; a.dbeta = G + plan->n0_b;
             a.ws = at(ws, w.ln); a.ws_bytes = w.ln_bytes;
-            RC(launch_layernorm_bwd(a, s));                                                       // dxb = d(embedding out)
+            prof_set_tag(MIVIT_PROF_LN_BWD); RC(launch_layernorm_bwd(a, s));                                                       // dxb = d(embedding out)
             if (c.embedding == MIVIT_EMBED_EXTERNAL) {
                 if (dx_tokens) RC(launch_convert(f32, at(ws, w.dxb), E, 1, dx_tokens, E, Mt, E, 0, s));
             } else {

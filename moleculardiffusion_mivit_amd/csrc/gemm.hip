@@ -225,6 +225,7 @@ template <typename T, typename TA, int LA, typename TB, int LB>
 int launch_gemm_t(const GemmArgs &g, int splits, hipStream_t s) {
     // 64x64 tiles when the 128x128 grid would leave most of the 256 CUs idle
     const long big = (long)ceil_div(g.M, 128) * ceil_div(g.N, 128) * splits;
+    ProfScope prof(s);
     if (big >= 192 || (g.M > 64 && g.N > 64 && big >= 64)) {
         dim3 grid(ceil_div(g.N, 128), ceil_div(g.M, 128), splits);
         hipLaunchKernelGGL((gemm_kernel<T, TA, LA, TB, LB, 128, 128>), grid, dim3(256), 0, s, g);

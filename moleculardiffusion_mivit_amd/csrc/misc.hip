@@ -19,6 +19,75 @@ extern "C" int mivit_device_count(void) {
     return n;
 }
 
+// ------------------------------------------------------------------------------------------------
+// kernel timing
+// ------------------------------------------------------------------------------------------------
+#include <mutex>
+#include <vector>
+namespace {
+struct ProfState {
+    std::mutex mu;
+    uint64_t mask = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[MIVIT_PROF_NUM_TAGS];
+    std::vector<hipEvent_t> pool;
+    hipEvent_t get() {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        return e;
+    }
+};
+ProfState g_prof;
+thread_local int t_tag = MIVIT_PROF_OP;
+thread_local hipEvent_t t_start = nullptr;
+const char *kTagNames[MIVIT_PROF_NUM_TAGS] = {"embed_fwd", "embed_wgrad", "linear_fwd", "linear_dgrad", "linear_wgrad",
+                                              "attn_fwd", "attn_bwd", "ln_fwd", "ln_bwd", "op"};
+}  // namespace
+
+void prof_set_tag(int tag) { t_tag = (tag >= 0 && tag < MIVIT_PROF_NUM_TAGS) ? tag : MIVIT_PROF_OP; }
+bool prof_begin(hipStream_t s) {
+    if (!((g_prof.mask >> t_tag) & 1ull)) return false;
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    t_start = g_prof.get();
+    if (!t_start) return false;
+    (void)hipEventRecord(t_start, s);
+    return true;
+}
+void prof_end(hipStream_t s) {
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    hipEvent_t stop = g_prof.get();
+    if (!stop) { g_prof.pool.push_back(t_start); return; }
+    (void)hipEventRecord(stop, s);
+    g_prof.ev[t_tag].push_back({t_start, stop});
+}
+extern "C" int mivit_profile_enable(uint64_t tag_mask) {
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    g_prof.mask = tag_mask;
+    return 0;
+}
+extern "C" int mivit_profile_collect(int tag, double *total_ms, int *count) {
+    MIVIT_CHECK(tag >= 0 && tag < MIVIT_PROF_NUM_TAGS, "profile_collect: bad tag %d", tag);
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    double tot = 0.0;
+    int n = 0;
+    for (auto &pr : g_prof.ev[tag]) {
+        float ms = 0.f;
+        if (hipEventSynchronize(pr.second) == hipSuccess && hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+            tot += ms;
+            ++n;
+        }
+        g_prof.pool.push_back(pr.first);
+        g_prof.pool.push_back(pr.second);
+    }
+    g_prof.ev[tag].clear();
+    if (total_ms) *total_ms = tot;
+    if (count) *count = n;
+    return 0;
+}
+extern "C" const char *mivit_profile_tag_name(int tag) {
+    return (tag >= 0 && tag < MIVIT_PROF_NUM_TAGS) ? kTagNames[tag] : "?";
+}
+
 namespace {
 
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float *part, int nparts, int64_t n, float *out,

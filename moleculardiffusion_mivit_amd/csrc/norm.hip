@@ -134,6 +134,7 @@ int ln_blocks(int M) {
 template <typename T>
 int ln_fwd_dispatch(const LnFwd &k, hipStream_t s) {
     const dim3 grid(ln_blocks(k.M)), block(256);
+    ProfScope prof(s);
     if (k.E <= 64) hipLaunchKernelGGL((ln_fwd_kernel<T, 1>), grid, block, 0, s, k);
     else if (k.E <= 128) hipLaunchKernelGGL((ln_fwd_kernel<T, 2>), grid, block, 0, s, k);
     else if (k.E <= 256) hipLaunchKernelGGL((ln_fwd_kernel<T, 4>), grid, block, 0, s, k);
@@ -146,6 +147,7 @@ int ln_fwd_dispatch(const LnFwd &k, hipStream_t s) {
 template <typename T>
 int ln_bwd_dispatch(const LnBwd &k, int blocks, hipStream_t s) {
     const dim3 grid(blocks), block(256);
+    ProfScope prof(s);
     if (k.E <= 64) hipLaunchKernelGGL((ln_bwd_kernel<T, 1>), grid, block, 0, s, k);
     else if (k.E <= 128) hipLaunchKernelGGL((ln_bwd_kernel<T, 2>), grid, block, 0, s, k);
     else if (k.E <= 256) hipLaunchKernelGGL((ln_bwd_kernel<T, 4>), grid, block, 0, s, k);

@@ -86,16 +86,15 @@ class MivitFunction(torch.autograd.Function):
         x = x.contiguous().float()
         feats = features.contiguous().float() if features is not None else None
         B, T = x.shape[0], x.shape[1]
-        need_bwd = torch.is_grad_enabled() and (any(p.requires_grad for p in params) or x.requires_grad or
-                                                (feats is not None and feats.requires_grad))
+        need_bwd = any(ctx.needs_input_grad)      # (grad mode is off inside Function.forward; this is the signal)
         ws = torch.empty(plan.workspace_bytes(B, T, need_bwd), dtype=torch.uint8, device=x.device)
         out = torch.empty(B, plan.output_dim, dtype=torch.float32, device=x.device)
         plan.forward(arena, x, feats, B, T, ws, need_bwd, out)
         ctx.owner, ctx.ws, ctx.x, ctx.feats, ctx.BT = owner, ws, x, feats, (B, T)
         ctx.arena_version = owner._arena_version
         ctx.n_params = len(params)
-        ctx.need_x = x.requires_grad
-        ctx.need_f = feats is not None and feats.requires_grad
+        ctx.need_x = ctx.needs_input_grad[1]
+        ctx.need_f = feats is not None and ctx.needs_input_grad[2]
         return out
 
     @staticmethod

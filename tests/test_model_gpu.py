@@ -1,0 +1,195 @@
+"""Whole-path parity: the product GeneralTransformer (HIP engine) against the reference-made golden vectors
+(fp32 mode, 1e-4 relative -- BASELINE.json north_star) and against the oracle in bf16 mode (bf16 tolerance)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import mivit_oracle as orc
+from util import build_product_model, golden_cases, golden_inputs, load_golden, rel_err, sample_idx
+
+pytestmark = pytest.mark.gpu
+
+FP32_TOL = 1e-4          # north_star: predicted D and training loss within 1e-4 relative
+CONV_TOL = 2e-4          # DeepResNet cases: the conv stack runs on MIOpen (different summation order than CPU mkldnn)
+
+
+def _run(model, x, labels, feats):
+    model.zero_grad(set_to_none=True)
+    out = model(x, feats) if feats is not None else model(x)
+    loss = F.mse_loss(out, labels)
+    loss.backward()
+    torch.cuda.synchronize()
+    return out.detach(), loss.detach(), {k: p.grad.detach() for k, p in model.named_parameters()}
+
+
+def _grad_err(got, fx, full):
+    """Per-tensor max error, scaled by max(|ref tensor|, 1e-3 * global gradient scale) (k_proj.bias has an
+    analytically zero gradient: both sides hold rounding noise there)."""
+    names = [k[6:] for k in fx.files if k.startswith("gnorm/")]
+    gscale = max(float(np.abs(fx["gsamp/" + k]).max()) for k in names)
+    worst, worst_name = 0.0, None
+    for k in names:
+        g = got[k].float().cpu().reshape(-1).numpy()
+        if full:
+            ref = fx["grad/" + k].reshape(-1)
+            diff = np.abs(g - ref).max()
+        else:
+            idx = sample_idx(g.size)
+            ref = fx["gsamp/" + k]
+            diff = np.abs(g[idx] - ref).max()
+            nrm = float(np.linalg.norm(g.astype(np.float64)))
+            nerr = abs(nrm - float(fx["gnorm/" + k])) / (float(fx["gnorm/" + k]) + 1e-3 * gscale)
+            if nerr > worst:
+                worst, worst_name = nerr, k + " (norm)"
+        e = float(diff) / (float(np.abs(ref).max()) + 1e-3 * gscale)
+        if e > worst:
+            worst, worst_name = e, k
+    return worst, worst_name
+
+
+@pytest.mark.parametrize("name", golden_cases())
+def test_fp32_matches_reference_golden(name):
+    fx, meta, cfg = load_golden(name)
+    params, x, labels, feats = golden_inputs(meta, cfg)
+    m = build_product_model(cfg, "fp32", params)
+    m.train(meta["training"])
+    out, loss, grads = _run(m, x.cuda(), labels.cuda(), None if feats is None else feats.cuda())
+    tol = CONV_TOL if cfg.embedding == "deepresnet" else FP32_TOL
+    assert rel_err(out, fx["out"]) < tol
+    assert abs(float(loss) - float(fx["loss"])) / float(fx["loss"]) < tol
+    e, who = _grad_err(grads, fx, meta["full_grads"])
+    assert e < tol, (who, e)
+    if cfg.embedding == "deepresnet" and meta["training"]:
+        sd = m.state_dict()
+        for k in fx.files:
+            if k.startswith("bnstat/"):
+                assert rel_err(sd[k[7:]], fx[k]) < tol, k
+
+
+@pytest.mark.parametrize("name", ["ref_linear", "c1"])
+def test_fp32_adamw_trajectory(name):
+    """3 optimizer steps with stock torch.optim.AdamW + StepLR(5, 0.9) (trainSettingsPSFNoise.py:119-120)."""
+    fx, meta, cfg = load_golden(name)
+    params, x, labels, _ = golden_inputs(meta, cfg)
+    m = build_product_model(cfg, "fp32", params)
+    m.train()
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-4)
+    sch = torch.optim.lr_scheduler.StepLR(opt, step_size=5, gamma=0.9)
+    xs, ls = x.cuda(), labels.cuda()
+    losses = []
+    for _ in range(meta["adamw_steps"]):
+        opt.zero_grad()
+        loss = F.mse_loss(m(xs), ls)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    sch.step()
+    ref = fx["adamw_losses"]
+    assert np.abs(np.array(losses) - ref).max() / np.abs(ref).max() < FP32_TOL
+    for k, p in m.named_parameters():
+        if k.endswith("k_proj.bias"):
+            continue   # analytically zero gradient: Adam turns pure rounding noise into +-lr steps on both sides
+        flat = p.detach().float().cpu().reshape(-1).numpy()
+        # 3 steps at lr 1e-4 move a weight by <= 3e-4; agreement to 1e-5 means the same moments on every element
+        assert np.abs(flat[sample_idx(flat.size)] - fx["adamw_psamp/" + k]).max() < 1e-5 + 2e-5 * np.abs(flat).max(), k
+
+
+@pytest.mark.parametrize("name", ["ref_linear", "c1", "c4_small", "c5_early", "c5_late", "meanpool_posenc_leaky",
+                                  "gelu_large_heads", "framerate_T60"])
+def test_bf16_as_accurate_as_torch_autocast(name):
+    """bf16 mode cannot meet 1e-4 (SURVEY trap 4).  Its gate: be as accurate, against the fp32 truth, as PyTorch's
+    own bf16 autocast of the same arithmetic on the same inputs (within 3x + a 2% floor), per output and per
+    gradient tensor (norm-wise).  The yardstick is computed here, on the host, with the oracle."""
+    fx, meta, cfg = load_golden(name)
+    params, x, labels, feats = golden_inputs(meta, cfg)
+    t_out, t_loss, t_g = orc.loss_and_grads(params, cfg, x, labels, feats)
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        a_out, a_loss, a_g = orc.loss_and_grads(params, cfg, x, labels, feats)
+    m = build_product_model(cfg, "bf16", params)
+    m.train()
+    out, loss, grads = _run(m, x.cuda(), labels.cuda(), None if feats is None else feats.cuda())
+    oscale = max(float(t_out.abs().max()), 0.25)       # outputs are D/10 in (0,1]: 0.25 = natural scale floor
+    e_hip = float((out.cpu() - t_out).abs().max()) / oscale
+    e_ac = float((a_out.float() - t_out).abs().max()) / oscale
+    assert e_hip <= 3 * e_ac + 2e-2, ("out", e_hip, e_ac)
+    assert abs(float(loss) - float(t_loss)) / float(t_loss) <= 3 * abs(float(a_loss) - float(t_loss)) / float(t_loss) + 3e-2
+    gscale = max(float(g.norm()) for g in t_g.values())
+    for k, g in t_g.items():
+        den = float(g.norm()) + 1e-2 * gscale
+        eh = float((grads[k].cpu() - g).norm()) / den
+        ea = float((a_g[k].float() - g).norm()) / den
+        assert eh <= 3 * ea + 3e-2, (k, eh, ea)
+
+
+def test_eval_no_grad_matches_train_forward_and_state_dict_roundtrip():
+    fx, meta, cfg = load_golden("ref_linear")
+    params, x, labels, _ = golden_inputs(meta, cfg)
+    m = build_product_model(cfg, "fp32", params)
+    xs = x.cuda()
+    out_train = m(xs).detach()
+    m.eval()
+    with torch.no_grad():
+        out_eval = m(xs)
+    assert torch.equal(out_train, out_eval)          # inference path shares one layer buffer set
+    # checkpoint round trip through the reference's state-dict schema
+    sd = {k: v.cpu().clone() for k, v in m.state_dict().items()}
+    assert list(sd) == list(orc.param_shapes(cfg))
+    m2 = build_product_model(cfg, "fp32", None)
+    m2.load_state_dict(sd)
+    with torch.no_grad():
+        assert torch.equal(m2.eval()(xs), out_eval)
+    # device moves re-pack the arena
+    m2 = m2.cpu().cuda()
+    with torch.no_grad():
+        assert torch.equal(m2(xs), out_eval)
+    # 3-D input = one sequence (models.py:154-158)
+    with torch.no_grad():
+        assert torch.allclose(m2(xs[0]), out_eval[:1], rtol=1e-5, atol=1e-6)
+
+
+def test_error_conventions():
+    fx, meta, cfg = load_golden("c5_early")
+    params, x, labels, feats = golden_inputs(meta, cfg)
+    m = build_product_model(cfg, "fp32", params)
+    with pytest.raises(AssertionError, match="Global features required for early fusion"):
+        m(x.cuda())
+    with pytest.raises(AssertionError, match="Patch size mismatch"):
+        m(torch.zeros(2, 4, cfg.patch_size + 1, cfg.patch_size + 1, device="cuda"), feats[:2].cuda())
+    with pytest.raises(RuntimeError, match="GPU"):
+        m(x, feats)                                   # CPU tensors: no silent fallback
+    with pytest.raises(ValueError):
+        m(torch.zeros(2, 3, 4, 16, 16, device="cuda"), feats[:2].cuda())
+
+
+def test_determinism_bitwise():
+    """Two runs give bit-identical outputs and gradients (no atomics anywhere: slab reductions)."""
+    fx, meta, cfg = load_golden("c1")
+    params, x, labels, _ = golden_inputs(meta, cfg)
+    for prec in ("fp32", "bf16"):
+        m = build_product_model(cfg, prec, params)
+        a = _run(m, x.cuda(), labels.cuda(), None)
+        b = _run(m, x.cuda(), labels.cuda(), None)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+        for k in a[2]:
+            assert torch.equal(a[2][k], b[2][k]), (prec, k)
+
+
+def test_c1_large_batch_properties():
+    """BASELINE cfg-1 shape at a throughput-sized batch: properties that need no oracle run.
+    (i) batch independence: rows of a big batch equal the same sequences run in small batches;
+    (ii) gradient linearity: grads of the mean loss over 2 half-batches average to the full-batch grads."""
+    cfg = orc.MiViTConfig(embedding="linear", patch_size=64, embed_dim=128, num_heads=4, hidden_dim=256, num_layers=4)
+    params = orc.closed_form_params(cfg)
+    x, labels, _ = orc.synthetic_batch(512, 32, 64, seed=7)
+    m = build_product_model(cfg, "fp32", params)
+    xs, ls = x.cuda(), labels.cuda()
+    out, loss, g = _run(m, xs, ls, None)
+    with torch.no_grad():
+        small = torch.cat([m(xs[i:i + 8]) for i in range(0, 64, 8)])
+    assert rel_err(out[:64], small) < 1e-5
+    _, _, g1 = _run(m, xs[:256], ls[:256], None)
+    _, _, g2 = _run(m, xs[256:], ls[256:], None)
+    for k in g:
+        avg = 0.5 * (g1[k] + g2[k])
+        assert float((avg - g[k]).abs().max()) <= 2e-5 * float(g[k].abs().max()) + 1e-9, k

