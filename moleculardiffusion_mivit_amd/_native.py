@@ -77,6 +77,10 @@ def _load():
             f"{LIB_PATH} is missing: the MiViT HIP extension has not been built. Run "
             "`python -m moleculardiffusion_mivit_amd.csrc.build` (needs hipcc, targets gfx950). "
             "There is no CPU / PyTorch fallback for this path.")
+    # PyTorch-ROCm bundles its own libamdhip64 / libhsa-runtime64.  One process must hold ONE HIP runtime, and device
+    # pointers + streams are shared with torch, so torch's copy has to be the one already resident when
+    # libmivit_hip.so (NEEDED: libamdhip64.so.7) is resolved: import torch first.
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)          # AttributeError if the library does not export a declared symbol

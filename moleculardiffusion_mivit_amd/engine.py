@@ -23,6 +23,8 @@ def _ptr(t: Optional[torch.Tensor]):
 
 
 def _stream_ptr(device):
+    if device.type != "cuda":
+        return None
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
@@ -64,11 +66,19 @@ class MivitPlan:
     def workspace_bytes(self, B: int, T: int, need_backward: bool) -> int:
         return N.lib.mivit_plan_workspace_bytes(self._h, B, T, int(need_backward))
 
+    @staticmethod
+    def _require_gpu(*tensors):
+        for t in tensors:
+            if t is not None and t.device.type != "cuda":
+                raise RuntimeError("the MiViT HIP path needs GPU tensors (no CPU fallback exists in this package)")
+
     def forward(self, arena, x, features, B, T, ws, need_backward, out):
+        self._require_gpu(arena, x, features)
         N.check(N.lib.mivit_forward(self._h, _ptr(arena), _ptr(x), _ptr(features), B, T, _ptr(ws), ws.numel(),
                                     int(need_backward), _ptr(out), _stream_ptr(x.device)), "mivit_forward")
 
     def backward(self, arena, x, features, B, T, ws, dout, grads, dfeatures, dx_tokens, s0, s1):
+        self._require_gpu(arena, x, dout, grads)
         N.check(N.lib.mivit_backward(self._h, _ptr(arena), _ptr(x), _ptr(features), B, T, _ptr(ws), ws.numel(),
                                      _ptr(dout), _ptr(grads), _ptr(dfeatures), _ptr(dx_tokens), s0, s1,
                                      _stream_ptr(x.device)), "mivit_backward")
@@ -81,8 +91,6 @@ class MivitFunction(torch.autograd.Function):
     def forward(ctx, owner, x, features, *params):
         plan: MivitPlan = owner._plan
         arena: torch.Tensor = owner._arena
-        if x.device.type != "cuda":
-            raise RuntimeError("the MiViT HIP path needs GPU tensors (no CPU fallback exists in this package)")
         x = x.contiguous().float()
         feats = features.contiguous().float() if features is not None else None
         B, T = x.shape[0], x.shape[1]
