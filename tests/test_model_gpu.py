@@ -51,13 +51,7 @@ def _grad_err(got, fx, full):
 @pytest.mark.parametrize("name", golden_cases())
 def test_fp32_matches_reference_golden(name):
     fx, meta, cfg = load_golden(name)
-    # a larger batch than the golden fixture: with B = 2..8 a single ReLU mask flip in the head (bf16 noise on a
-    # pre-activation near zero) moves every upstream gradient by ~15 %, on either side of the comparison
-    B = 24
-    params = orc.closed_form_params(cfg)
-    x, labels, feats = orc.closed_form_batch(B, meta["T"], cfg.patch_size, cfg.global_feature_dim, salt=3)
-    if cfg.output_dim > 1:
-        labels = labels.repeat(1, cfg.output_dim)
+    params, x, labels, feats = golden_inputs(meta, cfg)
     m = build_product_model(cfg, "fp32", params)
     m.train(meta["training"])
     out, loss, grads = _run(m, x.cuda(), labels.cuda(), None if feats is None else feats.cuda())
@@ -162,7 +156,13 @@ def test_eval_no_grad_matches_train_forward_and_state_dict_roundtrip():
 
 def test_error_conventions():
     fx, meta, cfg = load_golden("c5_early")
-    params, x, labels, feats = golden_inputs(meta, cfg)
+    # a larger batch than the golden fixture: with B = 2..8 a single ReLU mask flip in the head (bf16 noise on a
+    # pre-activation near zero) moves every upstream gradient by ~15 %, on either side of the comparison
+    B = 24
+    params = orc.closed_form_params(cfg)
+    x, labels, feats = orc.closed_form_batch(B, meta["T"], cfg.patch_size, cfg.global_feature_dim, salt=3)
+    if cfg.output_dim > 1:
+        labels = labels.repeat(1, cfg.output_dim)
     m = build_product_model(cfg, "fp32", params)
     with pytest.raises(AssertionError, match="Global features required for early fusion"):
         m(x.cuda())
