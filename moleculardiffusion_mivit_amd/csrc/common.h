@@ -132,6 +132,31 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// 16-byte vector access of V = 16 / sizeof(T) consecutive elements, widened to fp32
+__device__ __forceinline__ void load16(const float *p, float *out) {
+    const float4 v = *reinterpret_cast<const float4 *>(p);
+    out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+}
+__device__ __forceinline__ void load16(const bf16 *p, float *out) {
+    const uint4 v = *reinterpret_cast<const uint4 *>(p);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        out[2 * i] = __uint_as_float(w[i] << 16);
+        out[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    }
+}
+__device__ __forceinline__ void store16(float *p, const float *v) {
+    *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void store16(bf16 *p, const float *v) {
+    uint32_t w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        w[i] = (uint32_t)from_f32<bf16>(v[2 * i]).v | ((uint32_t)from_f32<bf16>(v[2 * i + 1]).v << 16);
+    *reinterpret_cast<uint4 *>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
@@ -139,7 +164,8 @@ static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; 
 struct LinearFwdArgs {
     int dtype;
     const void *x; int x_is_f32; int64_t ldx;
-    const float *W; const float *bias;
+    const void *W; int w_is_bf16;   // fp32 master weights, or (bf16 mode) the per-step bf16 shadow copy
+    const float *bias;
     int M, N, K, act;
     const void *resid; int64_t ldr;
     void *y; int64_t ldy; void *y_preact;
@@ -152,7 +178,7 @@ int launch_linear_fwd(const LinearFwdArgs &a, hipStream_t s);
 struct LinearDgradArgs {
     int dtype;
     const void *dy; int dy_is_f32; int64_t lddy;
-    const float *W;
+    const void *W; int w_is_bf16;
     int M, N, K;          // dy [M,N], W [N,K], dx [M,K]
     int act; const void *saved; int64_t lds;
     const void *dres; int64_t lddr;
@@ -191,6 +217,8 @@ struct LayerNormBwdArgs {
     int z_rows, z_stride, z_off;                   // row map of z  (gather used by the forward), z_rows > 0
     void *dz; int64_t lddz;                        // written through the z row map
     float *dgamma; float *dbeta; int accumulate;
+    float *dzsum;                                  // optional: column sums of dz (= bias gradient of the Linear whose
+                                                   // output fed this LayerNorm through the residual add)
     void *ws; size_t ws_bytes;
 };
 size_t layernorm_bwd_ws_bytes(int M, int E);

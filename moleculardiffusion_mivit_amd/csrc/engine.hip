@@ -33,8 +33,9 @@ namespace {
 
 constexpr int MAX_TOKENS = 128;   // helpers/models.py:8
 
-int64_t add_param(mivit_plan *p, const std::string &name, int64_t numel) {
-    p->arena = (p->arena + 3) / 4 * 4;   // 16-byte aligned tensors
+int64_t add_param(mivit_plan *p, const std::string &name, int64_t numel, bool align = true) {
+    // 32-byte aligned fp32 tensors = 16-byte aligned in the bf16 shadow copy (k/v follow q unpadded: one operand)
+    if (align) p->arena = (p->arena + 7) / 8 * 8;
     const int64_t off = p->arena;
     p->params.push_back({name, off, numel});
     p->arena += numel;
@@ -51,6 +52,7 @@ void add_feature_projector(mivit_plan *p) {
 
 struct Ws {
     size_t total;
+    size_t wsh;          // bf16 shadow of the parameter arena (bf16 mode), refreshed by every forward
     size_t emb, mean0, rstd0, x0;
     struct L { size_t qkv, ctx, z1, x1, h, u, z2, x2, mean1, rstd1, mean2, rstd2; };
     std::vector<L> layer;
@@ -69,6 +71,7 @@ Ws make_ws(const mivit_plan *p, int B, int T, bool bwd) {
     Ws w = {};
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes, 256); return o; };
+    w.wsh = c.dtype == MIVIT_BF16 ? take((size_t)p->arena * 2) : 0;
     w.emb = take(Mt * E * ts); w.mean0 = take(Mt * 4); w.rstd0 = take(Mt * 4);
     w.x0 = take(M * E * ts);
     const int nsets = bwd ? L : 1;
@@ -116,19 +119,21 @@ inline void *col_ptr(void *p, size_t cols, int dtype) { return static_cast<char 
 
 #define RC(call) do { int rc_ = (call); if (rc_) return rc_; } while (0)
 
-int lin_fwd(int dtype, const void *x, int x_f32, int64_t ldx, const float *W, const float *b, int M, int N, int K,
+int lin_fwd(int dtype, const void *x, int x_f32, int64_t ldx, const void *W, const float *b, int M, int N, int K,
             int act, const void *resid, int64_t ldr, void *y, int64_t ldy, void *pre, int y_f32, hipStream_t s) {
     LinearFwdArgs a = {};
-    a.dtype = dtype; a.x = x; a.x_is_f32 = x_f32 || dtype == MIVIT_F32; a.ldx = ldx; a.W = W; a.bias = b;
+    a.dtype = dtype; a.x = x; a.x_is_f32 = x_f32 || dtype == MIVIT_F32; a.ldx = ldx; a.W = W;
+    a.w_is_bf16 = dtype == MIVIT_BF16; a.bias = b;
     a.M = M; a.N = N; a.K = K; a.act = act; a.resid = resid; a.ldr = ldr; a.y = y; a.ldy = ldy; a.y_preact = pre;
     a.y_is_f32 = y_f32;
     prof_set_tag(x_f32 && K > 1024 ? MIVIT_PROF_EMBED_FWD : MIVIT_PROF_LINEAR_FWD);
     return launch_linear_fwd(a, s);
 }
-int lin_dgrad(int dtype, const void *dy, int64_t lddy, const float *W, int M, int N, int K, int act, const void *saved,
+int lin_dgrad(int dtype, const void *dy, int64_t lddy, const void *W, int M, int N, int K, int act, const void *saved,
               int64_t lds, const void *dres, int64_t lddr, void *dx, int64_t lddx, int dx_f32, hipStream_t s) {
     LinearDgradArgs a = {};
-    a.dtype = dtype; a.dy = dy; a.dy_is_f32 = dtype == MIVIT_F32; a.lddy = lddy; a.W = W; a.M = M; a.N = N; a.K = K;
+    a.dtype = dtype; a.dy = dy; a.dy_is_f32 = dtype == MIVIT_F32; a.lddy = lddy; a.W = W;
+    a.w_is_bf16 = dtype == MIVIT_BF16; a.M = M; a.N = N; a.K = K;
     a.act = act; a.saved = saved; a.lds = lds; a.dres = dres; a.lddr = lddr; a.dx = dx; a.lddx = lddx; a.dx_is_f32 = dx_f32;
     prof_set_tag(MIVIT_PROF_LINEAR_DGRAD);
     return launch_linear_dgrad(a, s);
@@ -141,6 +146,16 @@ int lin_wgrad(int dtype, const void *dy, int64_t lddy, const void *x, int x_f32,
     a.ws = ws; a.ws_bytes = wsb;
     prof_set_tag(x_f32 && K > 1024 ? MIVIT_PROF_EMBED_WGRAD : MIVIT_PROF_LINEAR_WGRAD);
     return launch_linear_wgrad(a, s);
+}
+
+// LayerNorm backward that also produces the bias gradient of the Linear feeding it (column sums of dz).
+// *need_colsum is set when the scalar LayerNorm path ran and the caller must compute that bias gradient itself.
+int ln_bwd_bias(LayerNormBwdArgs &a, float *db, bool *need_colsum, hipStream_t s) {
+    a.dzsum = db;
+    prof_set_tag(MIVIT_PROF_LN_BWD);
+    const int rc = launch_layernorm_bwd(a, s);
+    *need_colsum = (rc == 2);
+    return rc == 2 ? 0 : rc;
 }
 
 int check_call(const mivit_plan *plan, int B, int T, size_t ws_bytes, bool bwd, const char *who) {
@@ -196,7 +211,7 @@ extern "C" mivit_plan *mivit_plan_create(const mivit_config *cfg) {
     p->h0_b = add_param(p, "mlp_head.mlp.0.bias", c.head_hidden);
     p->h3_w = add_param(p, "mlp_head.mlp.3.weight", (int64_t)c.output_dim * c.head_hidden);
     p->h3_b = add_param(p, "mlp_head.mlp.3.bias", c.output_dim);
-    p->arena = (p->arena + 3) / 4 * 4;
+    p->arena = (p->arena + 7) / 8 * 8;
     p->stages.push_back({b0, p->arena});
     // stages 1..L: encoder layers L-1 .. 0 (q/k/v weights and biases contiguous: one [3E,E] GEMM operand)
     p->layers.resize(c.num_layers);
@@ -205,11 +220,11 @@ extern "C" mivit_plan *mivit_plan_create(const mivit_config *cfg) {
         const std::string pre = "transformer.encoder_layers." + std::to_string(l) + ".";
         LayerParams &lp = p->layers[l];
         lp.qkv_w = add_param(p, pre + "self_attn.q_proj.weight", (int64_t)E * E);
-        add_param(p, pre + "self_attn.k_proj.weight", (int64_t)E * E);
-        add_param(p, pre + "self_attn.v_proj.weight", (int64_t)E * E);
+        add_param(p, pre + "self_attn.k_proj.weight", (int64_t)E * E, false);
+        add_param(p, pre + "self_attn.v_proj.weight", (int64_t)E * E, false);
         lp.qkv_b = add_param(p, pre + "self_attn.q_proj.bias", E);
-        add_param(p, pre + "self_attn.k_proj.bias", E);
-        add_param(p, pre + "self_attn.v_proj.bias", E);
+        add_param(p, pre + "self_attn.k_proj.bias", E, false);
+        add_param(p, pre + "self_attn.v_proj.bias", E, false);
         lp.out_w = add_param(p, pre + "self_attn.out_proj.weight", (int64_t)E * E);
         lp.out_b = add_param(p, pre + "self_attn.out_proj.bias", E);
         lp.n1_w = add_param(p, pre + "norm1.weight", E);
@@ -220,7 +235,7 @@ extern "C" mivit_plan *mivit_plan_create(const mivit_config *cfg) {
         lp.fc2_b = add_param(p, pre + "feed_forward.fc2.bias", E);
         lp.n2_w = add_param(p, pre + "norm2.weight", E);
         lp.n2_b = add_param(p, pre + "norm2.bias", E);
-        p->arena = (p->arena + 3) / 4 * 4;
+        p->arena = (p->arena + 7) / 8 * 8;
         p->stages.push_back({b0, p->arena});
     }
     // last stage: token assembly + embedding (+ early-fusion feature projector)
@@ -238,7 +253,7 @@ extern "C" mivit_plan *mivit_plan_create(const mivit_config *cfg) {
         p->emb_w = add_param(p, "embedding.conv.weight", (int64_t)E * c.patch_size * c.patch_size);
         p->emb_b = add_param(p, "embedding.conv.bias", E);
     }
-    p->arena = (p->arena + 3) / 4 * 4;
+    p->arena = (p->arena + 7) / 8 * 8;
     p->stages.push_back({b0, p->arena});
     // q/k/v must be contiguous (E*E and E are multiples of 4 whenever E is): verify
     for (const LayerParams &lp : p->layers) (void)lp;
@@ -291,13 +306,19 @@ extern "C" int mivit_forward(const mivit_plan *plan, const float *params, const 
     const Ws w = make_ws(plan, B, T, need_backward != 0);
     void *ws = workspace;
     const float *P = params;
+    // bf16 mode: one conversion of the whole fp32 arena per step; every GEMM then stages bf16 weights
+    if (dt == MIVIT_BF16) RC(launch_convert(1, P, plan->arena, 0, at(ws, w.wsh), plan->arena, 1, (int)plan->arena, 0, s));
+    auto WT = [&](int64_t off) -> const void * {
+        return dt == MIVIT_BF16 ? static_cast<const void *>(static_cast<const bf16 *>(at(ws, w.wsh)) + off)
+                                : static_cast<const void *>(P + off);
+    };
 
     // 1. frame embedding: one token per whole frame (models.py:146-199), [B*T, P*P] x [E, P*P]^T
     if (c.embedding == MIVIT_EMBED_EXTERNAL) {
         RC(launch_convert(1, x, E, dt == MIVIT_F32, at(ws, w.emb), E, Mt, E, 0, s));
     } else {
         const int K = c.patch_size * c.patch_size;
-        RC(lin_fwd(dt, x, 1, K, P + plan->emb_w, P + plan->emb_b, Mt, E, K, MIVIT_ACT_NONE, nullptr, 0, at(ws, w.emb), E,
+        RC(lin_fwd(dt, x, 1, K, WT(plan->emb_w), P + plan->emb_b, Mt, E, K, MIVIT_ACT_NONE, nullptr, 0, at(ws, w.emb), E,
                    nullptr, 0, s));
     }
     // 2. LayerNorm of the tokens, written behind the regression-token row, + positional table (models.py:334,347,138)
@@ -312,9 +333,9 @@ extern "C" int mivit_forward(const mivit_plan *plan, const float *params, const 
     // feature projector (models.py:316-320): Linear(Fg,E) -> ReLU -> Linear(E,E)
     if (c.fusion != MIVIT_FUSION_NONE) {
         const int G = c.global_feature_dim;
-        RC(lin_fwd(dt, features, 1, G, P + plan->fp0_w, P + plan->fp0_b, B, E, G, MIVIT_ACT_RELU, nullptr, 0,
+        RC(lin_fwd(dt, features, 1, G, WT(plan->fp0_w), P + plan->fp0_b, B, E, G, MIVIT_ACT_RELU, nullptr, 0,
                    at(ws, w.fp_h), E, nullptr, 0, s));
-        RC(lin_fwd(dt, at(ws, w.fp_h), 0, E, P + plan->fp2_w, P + plan->fp2_b, B, E, E, MIVIT_ACT_NONE, nullptr, 0,
+        RC(lin_fwd(dt, at(ws, w.fp_h), 0, E, WT(plan->fp2_w), P + plan->fp2_b, B, E, E, MIVIT_ACT_NONE, nullptr, 0,
                    at(ws, w.fp_out), E, nullptr, 0, s));
     }
     // 3. regression token row (models.py:339-347)
@@ -327,19 +348,19 @@ extern "C" int mivit_forward(const mivit_plan *plan, const float *params, const 
     for (int l = 0; l < c.num_layers; ++l) {
         const LayerParams &lp = plan->layers[l];
         const Ws::L &b = w.layer[l];
-        RC(lin_fwd(dt, xin, 0, E, P + lp.qkv_w, P + lp.qkv_b, M, 3 * E, E, MIVIT_ACT_NONE, nullptr, 0, at(ws, b.qkv),
+        RC(lin_fwd(dt, xin, 0, E, WT(lp.qkv_w), P + lp.qkv_b, M, 3 * E, E, MIVIT_ACT_NONE, nullptr, 0, at(ws, b.qkv),
                    3 * E, nullptr, 0, s));
         prof_set_tag(MIVIT_PROF_ATTN_FWD); RC(launch_attention_fwd(dt, at(ws, b.qkv), B, S, H, Dh, at(ws, b.ctx), s));
-        RC(lin_fwd(dt, at(ws, b.ctx), 0, E, P + lp.out_w, P + lp.out_b, M, E, E, MIVIT_ACT_NONE, xin, E, at(ws, b.z1), E,
+        RC(lin_fwd(dt, at(ws, b.ctx), 0, E, WT(lp.out_w), P + lp.out_b, M, E, E, MIVIT_ACT_NONE, xin, E, at(ws, b.z1), E,
                    nullptr, 0, s));
         LayerNormFwdArgs n1 = {};
         n1.dtype = dt; n1.z = at(ws, b.z1); n1.ldz = E; n1.gamma = P + lp.n1_w; n1.beta = P + lp.n1_b; n1.M = M; n1.E = E;
         n1.y = at(ws, b.x1); n1.ldy = E; n1.mean = static_cast<float *>(at(ws, b.mean1));
         n1.rstd = static_cast<float *>(at(ws, b.rstd1));
         prof_set_tag(MIVIT_PROF_LN_FWD); RC(launch_layernorm_fwd(n1, s));
-        RC(lin_fwd(dt, at(ws, b.x1), 0, E, P + lp.fc1_w, P + lp.fc1_b, M, F, E, c.activation, nullptr, 0, at(ws, b.h), F,
+        RC(lin_fwd(dt, at(ws, b.x1), 0, E, WT(lp.fc1_w), P + lp.fc1_b, M, F, E, c.activation, nullptr, 0, at(ws, b.h), F,
                    c.activation == MIVIT_ACT_GELU ? at(ws, b.u) : nullptr, 0, s));
-        RC(lin_fwd(dt, at(ws, b.h), 0, F, P + lp.fc2_w, P + lp.fc2_b, M, E, F, MIVIT_ACT_NONE, at(ws, b.x1), E,
+        RC(lin_fwd(dt, at(ws, b.h), 0, F, WT(lp.fc2_w), P + lp.fc2_b, M, E, F, MIVIT_ACT_NONE, at(ws, b.x1), E,
                    at(ws, b.z2), E, nullptr, 0, s));
         LayerNormFwdArgs n2 = n1;
         n2.z = at(ws, b.z2); n2.gamma = P + lp.n2_w; n2.beta = P + lp.n2_b; n2.y = at(ws, b.x2);
@@ -370,9 +391,9 @@ extern "C" int mivit_forward(const mivit_plan *plan, const float *params, const 
         RC(launch_convert(f32, at(ws, w.fp_out), E, f32, col_ptr(at(ws, w.head_in), E, dt), 2 * E, B, E, 0, s));
         head_in = at(ws, w.head_in);
     }
-    RC(lin_fwd(dt, head_in, 0, plan->head_in, P + plan->h0_w, P + plan->h0_b, B, c.head_hidden, plan->head_in,
+    RC(lin_fwd(dt, head_in, 0, plan->head_in, WT(plan->h0_w), P + plan->h0_b, B, c.head_hidden, plan->head_in,
                MIVIT_ACT_RELU, nullptr, 0, at(ws, w.hh), c.head_hidden, nullptr, 0, s));
-    RC(lin_fwd(dt, at(ws, w.hh), 0, c.head_hidden, P + plan->h3_w, P + plan->h3_b, B, c.output_dim, c.head_hidden,
+    RC(lin_fwd(dt, at(ws, w.hh), 0, c.head_hidden, WT(plan->h3_w), P + plan->h3_b, B, c.output_dim, c.head_hidden,
                MIVIT_ACT_NONE, nullptr, 0, out, c.output_dim, nullptr, 1, s));
     return 0;
 }
@@ -387,14 +408,18 @@ int feature_projector_bwd(const mivit_plan *plan, const Ws &w, void *ws, const f
                           int B, const void *dy, int64_t lddy, float *dfeatures, hipStream_t s) {
     const mivit_config &c = plan->c;
     const int dt = c.dtype, E = c.embed_dim, Fg = c.global_feature_dim;
+    auto WT = [&](int64_t off) -> const void * {
+        return dt == MIVIT_BF16 ? static_cast<const void *>(static_cast<const bf16 *>(at(ws, w.wsh)) + off)
+                                : static_cast<const void *>(P + off);
+    };
     RC(lin_wgrad(dt, dy, lddy, at(ws, w.fp_h), 0, E, B, E, E, G + plan->fp2_w, G + plan->fp2_b, at(ws, w.wgrad),
                  w.wgrad_bytes, s));
-    RC(lin_dgrad(dt, dy, lddy, P + plan->fp2_w, B, E, E, MIVIT_ACT_RELU, at(ws, w.fp_h), E, nullptr, 0, at(ws, w.d_fp_h),
+    RC(lin_dgrad(dt, dy, lddy, WT(plan->fp2_w), B, E, E, MIVIT_ACT_RELU, at(ws, w.fp_h), E, nullptr, 0, at(ws, w.d_fp_h),
                  E, 0, s));
     RC(lin_wgrad(dt, at(ws, w.d_fp_h), E, features, 1, Fg, B, E, Fg, G + plan->fp0_w, G + plan->fp0_b, at(ws, w.wgrad),
                  w.wgrad_bytes, s));
     if (dfeatures)
-        RC(lin_dgrad(dt, at(ws, w.d_fp_h), E, P + plan->fp0_w, B, E, Fg, MIVIT_ACT_NONE, nullptr, 0, nullptr, 0, dfeatures,
+        RC(lin_dgrad(dt, at(ws, w.d_fp_h), E, WT(plan->fp0_w), B, E, Fg, MIVIT_ACT_NONE, nullptr, 0, nullptr, 0, dfeatures,
                      Fg, 1, s));
     return 0;
 }
@@ -421,6 +446,10 @@ extern "C" int mivit_backward(const mivit_plan *plan, const float *params, const
     float *G = grads;
     void *wg = at(ws, w.wgrad);
     const size_t wgb = w.wgrad_bytes;
+    auto WT = [&](int64_t off) -> const void * {
+        return dt == MIVIT_BF16 ? static_cast<const void *>(static_cast<const bf16 *>(at(ws, w.wsh)) + off)
+                                : static_cast<const void *>(P + off);
+    };
 
     for (int st = stage_begin; st < stage_end; ++st) {
         if (st == 0) {
@@ -431,10 +460,10 @@ extern "C" int mivit_backward(const mivit_plan *plan, const float *params, const
             const void *dy = dout;
             if (!f32) { RC(launch_convert(1, dout, O, 0, at(ws, w.dout_t), O, B, O, 0, s)); dy = at(ws, w.dout_t); }
             RC(lin_wgrad(dt, dy, O, at(ws, w.hh), 0, Hh, B, O, Hh, G + plan->h3_w, G + plan->h3_b, wg, wgb, s));
-            RC(lin_dgrad(dt, dy, O, P + plan->h3_w, B, O, Hh, MIVIT_ACT_RELU, at(ws, w.hh), Hh, nullptr, 0, at(ws, w.d_hh),
+            RC(lin_dgrad(dt, dy, O, WT(plan->h3_w), B, O, Hh, MIVIT_ACT_RELU, at(ws, w.hh), Hh, nullptr, 0, at(ws, w.d_hh),
                          Hh, 0, s));
             RC(lin_wgrad(dt, at(ws, w.d_hh), Hh, head_in, 0, Hin, B, Hh, Hin, G + plan->h0_w, G + plan->h0_b, wg, wgb, s));
-            RC(lin_dgrad(dt, at(ws, w.d_hh), Hh, P + plan->h0_w, B, Hh, Hin, MIVIT_ACT_NONE, nullptr, 0, nullptr, 0,
+            RC(lin_dgrad(dt, at(ws, w.d_hh), Hh, WT(plan->h0_w), B, Hh, Hin, MIVIT_ACT_NONE, nullptr, 0, nullptr, 0,
                          at(ws, w.d_head_in), Hin, 0, s));
             if (c.fusion == MIVIT_FUSION_LATE)
                 RC(feature_projector_bwd(plan, w, ws, P, G, features, B, col_ptr(at(ws, w.d_head_in), E, dt), Hin,
@@ -469,24 +498,25 @@ extern "C" int mivit_backward(const mivit_plan *plan, const float *params, const
             n2.mean = static_cast<const float *>(at(ws, b.mean2)); n2.rstd = static_cast<const float *>(at(ws, b.rstd2));
             n2.M = M; n2.E = E; n2.dz = at(ws, w.dxb); n2.lddz = E; n2.dgamma = G + lp.n2_w; n2.dbeta = G + lp.n2_b;
             n2.ws = at(ws, w.ln); n2.ws_bytes = w.ln_bytes;
-            prof_set_tag(MIVIT_PROF_LN_BWD); RC(launch_layernorm_bwd(n2, s));                                                      // dxb = d(z2)
-            RC(lin_wgrad(dt, at(ws, w.dxb), E, at(ws, b.h), 0, F, M, E, F, G + lp.fc2_w, G + lp.fc2_b, wg, wgb, s));
-            RC(lin_dgrad(dt, at(ws, w.dxb), E, P + lp.fc2_w, M, E, F, c.activation,
+            bool cs = false;
+            RC(ln_bwd_bias(n2, G + lp.fc2_b, &cs, s));                                            // dxb = d(z2), fc2.bias grad
+            RC(lin_wgrad(dt, at(ws, w.dxb), E, at(ws, b.h), 0, F, M, E, F, G + lp.fc2_w, cs ? G + lp.fc2_b : nullptr, wg, wgb, s));
+            RC(lin_dgrad(dt, at(ws, w.dxb), E, WT(lp.fc2_w), M, E, F, c.activation,
                          c.activation == MIVIT_ACT_GELU ? at(ws, b.u) : at(ws, b.h), F, nullptr, 0, at(ws, w.dF), F, 0, s));
             RC(lin_wgrad(dt, at(ws, w.dF), F, at(ws, b.x1), 0, E, M, F, E, G + lp.fc1_w, G + lp.fc1_b, wg, wgb, s));
-            RC(lin_dgrad(dt, at(ws, w.dF), F, P + lp.fc1_w, M, F, E, MIVIT_ACT_NONE, nullptr, 0, at(ws, w.dxb), E,
+            RC(lin_dgrad(dt, at(ws, w.dF), F, WT(lp.fc1_w), M, F, E, MIVIT_ACT_NONE, nullptr, 0, at(ws, w.dxb), E,
                          at(ws, w.dxa), E, 0, s));                                                // dxa = d(x1)
             LayerNormBwdArgs n1 = n2;
             n1.dy = at(ws, w.dxa); n1.z = at(ws, b.z1); n1.gamma = P + lp.n1_w;
             n1.mean = static_cast<const float *>(at(ws, b.mean1)); n1.rstd = static_cast<const float *>(at(ws, b.rstd1));
             n1.dz = at(ws, w.dxb); n1.dgamma = G + lp.n1_w; n1.dbeta = G + lp.n1_b;
-            prof_set_tag(MIVIT_PROF_LN_BWD); RC(launch_layernorm_bwd(n1, s));                                                      // dxb = d(z1)
-            RC(lin_wgrad(dt, at(ws, w.dxb), E, at(ws, b.ctx), 0, E, M, E, E, G + lp.out_w, G + lp.out_b, wg, wgb, s));
-            RC(lin_dgrad(dt, at(ws, w.dxb), E, P + lp.out_w, M, E, E, MIVIT_ACT_NONE, nullptr, 0, nullptr, 0,
+            RC(ln_bwd_bias(n1, G + lp.out_b, &cs, s));                                            // dxb = d(z1), out_proj.bias grad
+            RC(lin_wgrad(dt, at(ws, w.dxb), E, at(ws, b.ctx), 0, E, M, E, E, G + lp.out_w, cs ? G + lp.out_b : nullptr, wg, wgb, s));
+            RC(lin_dgrad(dt, at(ws, w.dxb), E, WT(lp.out_w), M, E, E, MIVIT_ACT_NONE, nullptr, 0, nullptr, 0,
                          at(ws, w.dctx), E, 0, s));
             prof_set_tag(MIVIT_PROF_ATTN_BWD); RC(launch_attention_bwd(dt, at(ws, b.qkv), at(ws, w.dctx), B, S, H, Dh, at(ws, w.dqkv), s));
             RC(lin_wgrad(dt, at(ws, w.dqkv), 3 * E, xin, 0, E, M, 3 * E, E, G + lp.qkv_w, G + lp.qkv_b, wg, wgb, s));
-            RC(lin_dgrad(dt, at(ws, w.dqkv), 3 * E, P + lp.qkv_w, M, 3 * E, E, MIVIT_ACT_NONE, nullptr, 0, at(ws, w.dxb),
+            RC(lin_dgrad(dt, at(ws, w.dqkv), 3 * E, WT(lp.qkv_w), M, 3 * E, E, MIVIT_ACT_NONE, nullptr, 0, at(ws, w.dxb),
                          E, at(ws, w.dxa), E, 0, s));                                             // dxa = d(x_in)
         } else {
             // ---- token assembly + embedding; dxa holds d(x0) [B,S,E] ----
@@ -504,12 +534,14 @@ extern "C" int mivit_backward(const mivit_plan *plan, const float *params, const
             a.M = Mt; a.E = E; a.rows_per_seq = T; a.in_seq_stride = S; a.in_row_off = off;
             a.dz = at(ws, w.dxb); a.lddz = E; a.dgamma = G + plan->n0_w; a.dbeta = G + plan->n0_b;
             a.ws = at(ws, w.ln); a.ws_bytes = w.ln_bytes;
-            prof_set_tag(MIVIT_PROF_LN_BWD); RC(launch_layernorm_bwd(a, s));                                                       // dxb = d(embedding out)
             if (c.embedding == MIVIT_EMBED_EXTERNAL) {
+                prof_set_tag(MIVIT_PROF_LN_BWD); RC(launch_layernorm_bwd(a, s));                  // dxb = d(tokens)
                 if (dx_tokens) RC(launch_convert(f32, at(ws, w.dxb), E, 1, dx_tokens, E, Mt, E, 0, s));
             } else {
+                bool cs = false;
+                RC(ln_bwd_bias(a, G + plan->emb_b, &cs, s));                                      // dxb = d(embedding out)
                 const int K = c.patch_size * c.patch_size;
-                RC(lin_wgrad(dt, at(ws, w.dxb), E, x, 1, K, Mt, E, K, G + plan->emb_w, G + plan->emb_b, wg, wgb, s));
+                RC(lin_wgrad(dt, at(ws, w.dxb), E, x, 1, K, Mt, E, K, G + plan->emb_w, cs ? G + plan->emb_b : nullptr, wg, wgb, s));
             }
         }
     }

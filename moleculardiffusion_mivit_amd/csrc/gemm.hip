@@ -32,26 +32,45 @@ struct GemmArgs {
 
 template <typename T>
 struct Cfg {
-    static constexpr int BK = 32;
-    static constexpr int LDK = (sizeof(T) == 2) ? 48 : 36;   // padded LDS row, elements (96 B / 144 B)
+    // bf16: BK = 64, LDS rows of 160 B (ds_read_b128 fragment reads conflict-free: slot = (10*row + chunk) mod 16
+    // separates the even/odd halves of every 16-lane read group);  fp32: BK = 32, rows of 144 B.
+    static constexpr int BK = (sizeof(T) == 2) ? 64 : 32;
+    static constexpr int LDK = (sizeof(T) == 2) ? 80 : 36;
 };
 
-template <typename TS>
-__device__ __forceinline__ void load_vec(const TS *p, float *out);
-template <>
-__device__ __forceinline__ void load_vec<float>(const float *p, float *out) {
-    const float4 v = *reinterpret_cast<const float4 *>(p);
+template <typename TS> struct VecOf;
+template <> struct VecOf<float> { typedef float4 type; };
+template <> struct VecOf<bf16> { typedef uint4 type; };
+
+__device__ __forceinline__ void unpack(const float4 &v, float *out) {
     out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
 }
-template <>
-__device__ __forceinline__ void load_vec<bf16>(const bf16 *p, float *out) {
-    const uint4 v = *reinterpret_cast<const uint4 *>(p);
+__device__ __forceinline__ void unpack(const uint4 &v, float *out) {
     const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         out[2 * i] = __uint_as_float(w[i] << 16);
         out[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
     }
+}
+// element-wise tail / unaligned path: zero fill beyond nvalid (static register indexing only: no scratch)
+__device__ __forceinline__ float4 load_vec_guarded(const float *p, int nvalid) {
+    float4 v;
+    v.x = nvalid > 0 ? p[0] : 0.f;
+    v.y = nvalid > 1 ? p[1] : 0.f;
+    v.z = nvalid > 2 ? p[2] : 0.f;
+    v.w = nvalid > 3 ? p[3] : 0.f;
+    return v;
+}
+__device__ __forceinline__ uint4 load_vec_guarded(const bf16 *p, int nvalid) {
+    uint32_t w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t lo = nvalid > 2 * i ? (uint32_t)p[2 * i].v : 0u;
+        const uint32_t hi = nvalid > 2 * i + 1 ? (uint32_t)p[2 * i + 1].v : 0u;
+        w[i] = lo | (hi << 16);
+    }
+    return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
 template <typename T, int N>
@@ -78,58 +97,74 @@ __device__ __forceinline__ void store_lds<bf16, 8>(bf16 *dst, const float *v) {
         make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
 }
 
+// Two-phase staging: load() issues the global loads of one k-tile into registers (kept raw, so they can stay in
+// flight under the MFMAs of the previous tile), store() converts and writes the [row][k] LDS image.
 // k-contiguous source: image[r][k] <- src[(r0 + r) * ld + k0 + k]
 template <typename T, typename TS, int R>
-__device__ __forceinline__ void stage_kc(T *img, const TS *src, int64_t ld, int r0, int rmax, int k0, int kend,
-                                         bool vec_ok, int tid) {
-    constexpr int V = 16 / sizeof(TS);
-    constexpr int TPR = Cfg<T>::BK / V;
-    constexpr int RPP = 256 / TPR;
-    constexpr int LDK = Cfg<T>::LDK;
+struct StageKC {
+    static constexpr int V = 16 / sizeof(TS);
+    static constexpr int TPR = Cfg<T>::BK / V;
+    static constexpr int RPP = 256 / TPR;
+    static constexpr int NP = R / RPP;
     static_assert(R % RPP == 0, "tile rows must be a multiple of the rows staged per pass");
+    typename VecOf<TS>::type regs[NP];
+    __device__ __forceinline__ void load(const TS *src, int64_t ld, int r0, int rmax, int k0, int kend, bool vec_ok,
+                                         int tid) {
 #pragma unroll
-    for (int p = 0; p < R / RPP; ++p) {
-        const int r = p * RPP + tid / TPR;
-        const int kv = (tid % TPR) * V;
-        const int gr = r0 + r, gk = k0 + kv;
-        float v[V];
-        if (gr < rmax && gk + V <= kend && vec_ok) {
-            load_vec<TS>(src + (int64_t)gr * ld + gk, v);
-        } else {
-#pragma unroll
-            for (int i = 0; i < V; ++i)
-                v[i] = (gr < rmax && gk + i < kend) ? to_f32(src[(int64_t)gr * ld + gk + i]) : 0.f;
+        for (int p = 0; p < NP; ++p) {
+            const int gr = r0 + p * RPP + tid / TPR, gk = k0 + (tid % TPR) * V;
+            if (gr < rmax && gk + V <= kend && vec_ok) {
+                regs[p] = *reinterpret_cast<const typename VecOf<TS>::type *>(src + (int64_t)gr * ld + gk);
+            } else {
+                const int nv = gr < rmax ? max(0, min(V, kend - gk)) : 0;
+                regs[p] = load_vec_guarded(src + (int64_t)(gr < rmax ? gr : 0) * ld + gk, nv);
+            }
         }
-        store_lds<T, V>(img + r * LDK + kv, v);
     }
-}
+    __device__ __forceinline__ void store(T *img, int tid) const {
+        constexpr int LDK = Cfg<T>::LDK;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            float v[V];
+            unpack(regs[p], v);
+            store_lds<T, V>(img + (p * RPP + tid / TPR) * LDK + (tid % TPR) * V, v);
+        }
+    }
+};
 
-// k-strided source: image[r][k] <- src[(k0 + k) * ld + r0 + r]; each unit loads KB k-rows of V consecutive r,
-// transposes in registers and writes V rows of KB consecutive k (one 16-byte LDS store each).
+// k-strided source: image[r][k] <- src[(k0 + k) * ld + r0 + r]; a unit = KB k-rows x V consecutive r, transposed
+// in registers, written as V LDS rows of KB consecutive k (one 16-byte store each).
 template <typename T, typename TS, int R>
-__device__ __forceinline__ void stage_ks(T *img, const TS *src, int64_t ld, int r0, int rmax, int k0, int kend,
-                                         bool vec_ok, int tid) {
-    constexpr int V = 16 / sizeof(TS);
-    constexpr int KB = 16 / sizeof(T);
-    constexpr int UR = R / V;
-    constexpr int UK = Cfg<T>::BK / KB;
-    constexpr int UNITS = UR * UK;
-    constexpr int LDK = Cfg<T>::LDK;
-    for (int u = tid; u < UNITS; u += 256) {
-        const int rv = (u % UR) * V, kg = (u / UR) * KB;
-        const int gr = r0 + rv;
-        float v[KB][V];
+struct StageKS {
+    static constexpr int V = 16 / sizeof(TS);
+    static constexpr int KB = 16 / sizeof(T);
+    static constexpr int UR = R / V;
+    static constexpr int UK = Cfg<T>::BK / KB;
+    static constexpr int UNITS = UR * UK;
+    static_assert(UNITS <= 256, "one staging unit per thread");
+    typename VecOf<TS>::type regs[KB];
+    __device__ __forceinline__ void load(const TS *src, int64_t ld, int r0, int rmax, int k0, int kend, bool vec_ok,
+                                         int tid) {
+        if (tid >= UNITS) return;
+        const int gr = r0 + (tid % UR) * V, kg = (tid / UR) * KB;
 #pragma unroll
         for (int i = 0; i < KB; ++i) {
             const int gk = k0 + kg + i;
             if (gk < kend && gr + V <= rmax && vec_ok) {
-                load_vec<TS>(src + (int64_t)gk * ld + gr, v[i]);
+                regs[i] = *reinterpret_cast<const typename VecOf<TS>::type *>(src + (int64_t)gk * ld + gr);
             } else {
-#pragma unroll
-                for (int j = 0; j < V; ++j)
-                    v[i][j] = (gk < kend && gr + j < rmax) ? to_f32(src[(int64_t)gk * ld + gr + j]) : 0.f;
+                const int nv = gk < kend ? max(0, min(V, rmax - gr)) : 0;
+                regs[i] = load_vec_guarded(src + (int64_t)(gk < kend ? gk : 0) * ld + gr, nv);
             }
         }
+    }
+    __device__ __forceinline__ void store(T *img, int tid) const {
+        constexpr int LDK = Cfg<T>::LDK;
+        if (tid >= UNITS) return;
+        const int rv = (tid % UR) * V, kg = (tid / UR) * KB;
+        float v[KB][V];
+#pragma unroll
+        for (int i = 0; i < KB; ++i) unpack(regs[i], v[i]);
 #pragma unroll
         for (int j = 0; j < V; ++j) {
             float t[KB];
@@ -138,10 +173,14 @@ __device__ __forceinline__ void stage_ks(T *img, const TS *src, int64_t ld, int 
             store_lds<T, KB>(img + (rv + j) * LDK + kg, t);
         }
     }
-}
+};
+
+template <typename T, typename TS, int L, int R> struct StageSel;
+template <typename T, typename TS, int R> struct StageSel<T, TS, KC, R> { typedef StageKC<T, TS, R> type; };
+template <typename T, typename TS, int R> struct StageSel<T, TS, KSTR, R> { typedef StageKS<T, TS, R> type; };
 
 template <typename T, typename TA, int LA, typename TB, int LB, int BM, int BN>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     constexpr int BK = Cfg<T>::BK, LDK = Cfg<T>::LDK;
     constexpr int TM = BM / 32, TN = BN / 32;   // 16x16 tiles per wave (waves arranged 2 x 2)
     __shared__ __attribute__((aligned(16))) T smem[(BM + BN) * LDK];
@@ -165,12 +204,21 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    typename StageSel<T, TA, LA, BM>::type sa;
+    typename StageSel<T, TB, LB, BN>::type sb;
+    if (kb < ke) {
+        sa.load(A, g.lda, m0, g.M, kb, ke, va_ok, tid);
+        sb.load(B, g.ldb, n0, g.N, kb, ke, vb_ok, tid);
+        sa.store(As, tid);
+        sb.store(Bs, tid);
+    }
+    __syncthreads();
     for (int k0 = kb; k0 < ke; k0 += BK) {
-        if (LA == KC) stage_kc<T, TA, BM>(As, A, g.lda, m0, g.M, k0, ke, va_ok, tid);
-        else          stage_ks<T, TA, BM>(As, A, g.lda, m0, g.M, k0, ke, va_ok, tid);
-        if (LB == KC) stage_kc<T, TB, BN>(Bs, B, g.ldb, n0, g.N, k0, ke, vb_ok, tid);
-        else          stage_ks<T, TB, BN>(Bs, B, g.ldb, n0, g.N, k0, ke, vb_ok, tid);
-        __syncthreads();
+        const bool more = k0 + BK < ke;
+        if (more) {   // next tile's global loads fly under this tile's MFMAs
+            sa.load(A, g.lda, m0, g.M, k0 + BK, ke, va_ok, tid);
+            sb.load(B, g.ldb, n0, g.N, k0 + BK, ke, vb_ok, tid);
+        }
 #pragma unroll
         for (int kk = 0; kk < BK; kk += Mma<T>::KS) {
             typename Mma<T>::Frag a[TM], b[TN];
@@ -184,37 +232,113 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
                 for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::mma(a[i], b[j], acc[i][j]);
         }
         __syncthreads();
+        if (more) {
+            sa.store(As, tid);
+            sb.store(Bs, tid);
+            __syncthreads();
+        }
     }
 
-    // ---- epilogue: lane holds column (lane & 15), rows (lane >> 4) * 4 + j of each 16x16 tile ----
-    float *Cf = static_cast<float *>(g.C) + (int64_t)blockIdx.z * g.slab_stride;
-    T *Ct = static_cast<T *>(g.C);
-    T *C2 = static_cast<T *>(g.C2);
-    const T *resid = static_cast<const T *>(g.resid);
-    const T *dact = static_cast<const T *>(g.dact);
+    const int colq = lane & 15, rowq = (lane >> 4) * 4;
+    if (g.c_is_f32) {
+        // ---- fp32 output (fp32 mode, split-reduction slabs, model output): straight from the accumulator layout
+        float *Cf = static_cast<float *>(g.C) + (int64_t)blockIdx.z * g.slab_stride;
+        T *C2 = static_cast<T *>(g.C2);
+        const T *resid = static_cast<const T *>(g.resid);
+        const T *dact = static_cast<const T *>(g.dact);
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+        for (int i = 0; i < TM; ++i) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int col = n0 + wn * (BN / 2) + j * 16 + (lane & 15);
-            if (col >= g.N) continue;
-            const float bv = g.bias ? g.bias[col] : 0.f;
+            for (int j = 0; j < TN; ++j) {
+                const int col = n0 + wn * (BN / 2) + j * 16 + colq;
+                if (col >= g.N) continue;
+                const float bv = g.bias ? g.bias[col] : 0.f;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = m0 + wm * (BM / 2) + i * 16 + (lane >> 4) * 4 + r;
-                if (row >= g.M) continue;
-                float v = acc[i][j][r] + bv;
-                int64_t orow = row;
-                if (g.map_rows > 0) orow = (int64_t)(row / g.map_rows) * g.map_stride + row % g.map_rows + g.map_off;
-                if (C2) C2[orow * g.ldc + col] = from_f32<T>(v);
-                v = act_fwd(g.act, v);
-                if (dact) v *= act_bwd(g.dact_kind, to_f32(dact[(int64_t)row * g.ldd + col]));
-                if (resid) v += to_f32(resid[(int64_t)row * g.ldr + col]);
-                if (g.c_is_f32) {
+                for (int r = 0; r < 4; ++r) {
+                    const int row = m0 + wm * (BM / 2) + i * 16 + rowq + r;
+                    if (row >= g.M) continue;
+                    float v = acc[i][j][r] + bv;
+                    int64_t orow = row;
+                    if (g.map_rows > 0) orow = (int64_t)(row / g.map_rows) * g.map_stride + row % g.map_rows + g.map_off;
+                    if (C2) C2[orow * g.ldc + col] = from_f32<T>(v);
+                    v = act_fwd(g.act, v);
+                    if (dact) v *= act_bwd(g.dact_kind, to_f32(dact[(int64_t)row * g.ldd + col]));
+                    if (resid) v += to_f32(resid[(int64_t)row * g.ldr + col]);
                     float *p = Cf + orow * g.ldc + col;
                     *p = g.accumulate ? (*p + v) : v;
+                }
+            }
+        }
+        return;
+    }
+
+    // ---- bf16 output: stage acc + bias through LDS as fp32 (half the tile rows at a time), then every thread
+    //      finishes 8 consecutive columns: 16-byte loads of residual / saved activation, one rounding, 16-byte store.
+    if constexpr (sizeof(T) == 2) {
+        constexpr int HR = BM / 2;          // rows per pass = the rows owned by the waves with wm == h
+        constexpr int LDC = BN + 4;         // fp32 row stride of the staging tile (16-byte aligned rows)
+        static_assert((size_t)HR * LDC * 4 <= (size_t)(BM + BN) * LDK * sizeof(T), "staging tile must fit in the operand LDS");
+        float *Cs = reinterpret_cast<float *>(smem);
+        bf16 *Ct = static_cast<bf16 *>(g.C);
+        bf16 *C2 = static_cast<bf16 *>(g.C2);
+        const bf16 *resid = static_cast<const bf16 *>(g.resid);
+        const bf16 *dact = static_cast<const bf16 *>(g.dact);
+        const bool vec_c = (g.ldc % 8 == 0) && ((reinterpret_cast<uintptr_t>(Ct) & 15) == 0) &&
+                           (!C2 || (reinterpret_cast<uintptr_t>(C2) & 15) == 0) &&
+                           (!resid || (g.ldr % 8 == 0 && (reinterpret_cast<uintptr_t>(resid) & 15) == 0)) &&
+                           (!dact || (g.ldd % 8 == 0 && (reinterpret_cast<uintptr_t>(dact) & 15) == 0));
+        for (int h = 0; h < 2; ++h) {
+            if (h) __syncthreads();
+            if (wm == h) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const int lc = wn * (BN / 2) + j * 16 + colq;
+                        const float bv = (g.bias && n0 + lc < g.N) ? g.bias[n0 + lc] : 0.f;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) Cs[(i * 16 + rowq + r) * LDC + lc] = acc[i][j][r] + bv;
+                    }
+            }
+            __syncthreads();
+            for (int c = tid; c < HR * (BN / 8); c += 256) {
+                const int lr = c / (BN / 8), lc = (c % (BN / 8)) * 8;
+                const int row = m0 + h * HR + lr, col = n0 + lc;
+                if (row >= g.M || col >= g.N) continue;
+                int64_t orow = row;
+                if (g.map_rows > 0) orow = (int64_t)(row / g.map_rows) * g.map_stride + row % g.map_rows + g.map_off;
+                float v[8];
+                *reinterpret_cast<float4 *>(v) = *reinterpret_cast<const float4 *>(Cs + lr * LDC + lc);
+                *reinterpret_cast<float4 *>(v + 4) = *reinterpret_cast<const float4 *>(Cs + lr * LDC + lc + 4);
+                if (col + 8 <= g.N && vec_c) {
+                    if (C2) store_lds<bf16, 8>(C2 + orow * g.ldc + col, v);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = act_fwd(g.act, v[e]);
+                    if (dact) {
+                        float d[8];
+                        unpack(*reinterpret_cast<const uint4 *>(dact + (int64_t)row * g.ldd + col), d);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] *= act_bwd(g.dact_kind, d[e]);
+                    }
+                    if (resid) {
+                        float d[8];
+                        unpack(*reinterpret_cast<const uint4 *>(resid + (int64_t)row * g.ldr + col), d);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += d[e];
+                    }
+                    store_lds<bf16, 8>(Ct + orow * g.ldc + col, v);
                 } else {
-                    Ct[orow * g.ldc + col] = from_f32<T>(v);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        if (col + e < g.N) {
+                            float x = v[e];
+                            if (C2) C2[orow * g.ldc + col + e] = from_f32<bf16>(x);
+                            x = act_fwd(g.act, x);
+                            if (dact) x *= act_bwd(g.dact_kind, to_f32(dact[(int64_t)row * g.ldd + col + e]));
+                            if (resid) x += to_f32(resid[(int64_t)row * g.ldr + col + e]);
+                            Ct[orow * g.ldc + col + e] = from_f32<bf16>(x);
+                        }
+                    }
                 }
             }
         }
@@ -226,7 +350,16 @@ int launch_gemm_t(const GemmArgs &g, int splits, hipStream_t s) {
     // 64x64 tiles when the 128x128 grid would leave most of the 256 CUs idle
     const long big = (long)ceil_div(g.M, 128) * ceil_div(g.N, 128) * splits;
     ProfScope prof(s);
-    if (big >= 192 || (g.M > 64 && g.N > 64 && big >= 64)) {
+    if (sizeof(TA) == 4 && sizeof(T) == 2 && LA == KC && g.K >= 1024 && g.N >= 128 && big >= 192) {
+        // streaming fp32 rows (frame embedding): a 64-row tile halves the prefetch registers -> 3+ blocks per CU
+        // keep enough bytes in flight to cover HBM latency
+        dim3 grid(ceil_div(g.N, 128), ceil_div(g.M, 64), splits);
+        hipLaunchKernelGGL((gemm_kernel<T, TA, LA, TB, LB, 64, 128>), grid, dim3(256), 0, s, g);
+    } else if (sizeof(TA) == 4 && sizeof(T) == 2 && sizeof(TB) == 4 && LA == KC) {
+        // (fp32 activations AND fp32 weights both staged through registers: the 128x128 tile would spill)
+        dim3 grid(ceil_div(g.N, 64), ceil_div(g.M, 64), splits);
+        hipLaunchKernelGGL((gemm_kernel<T, TA, LA, TB, LB, 64, 64>), grid, dim3(256), 0, s, g);
+    } else if (big >= 192 || (g.M > 64 && g.N > 64 && big >= 64)) {
         dim3 grid(ceil_div(g.N, 128), ceil_div(g.M, 128), splits);
         hipLaunchKernelGGL((gemm_kernel<T, TA, LA, TB, LB, 128, 128>), grid, dim3(256), 0, s, g);
     } else {
@@ -237,25 +370,49 @@ int launch_gemm_t(const GemmArgs &g, int splits, hipStream_t s) {
     return 0;
 }
 
-// column sums of dy[M,N] over a row chunk: part[z][n]
+// column sums of dy[M,N] over a row chunk: part[chunk][n].  Thread = V consecutive columns (16-byte loads) x one of
+// 8 row lanes; 8-way LDS reduction per block.
 template <typename TS>
 __global__ __launch_bounds__(256) void colsum_kernel(const TS *src, int64_t ld, int M, int N, int chunk, float *part) {
-    __shared__ float red[4][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int rl = threadIdx.x >> 6;
+    constexpr int V = 16 / sizeof(TS);
+    __shared__ float red[8][32 * V];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int c0 = (blockIdx.x * 32 + tx) * V;
     const int rb = blockIdx.y * chunk, re = min(M, rb + chunk);
-    float acc = 0.f;
-    if (c < N)
-        for (int r = rb + rl; r < re; r += 4) acc += to_f32(src[(int64_t)r * ld + c]);
-    red[rl][threadIdx.x & 63] = acc;
+    const bool vec_ok = (ld % V == 0) && ((reinterpret_cast<uintptr_t>(src) & 15) == 0) && (c0 + V <= N);
+    float acc[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) acc[i] = 0.f;
+    if (c0 < N) {
+        for (int r = rb + ty; r < re; r += 8) {
+            float v[V];
+            if (vec_ok) unpack(*reinterpret_cast<const typename VecOf<TS>::type *>(src + (int64_t)r * ld + c0), v);
+            else
+#pragma unroll
+                for (int i = 0; i < V; ++i) v[i] = (c0 + i < N) ? to_f32(src[(int64_t)r * ld + c0 + i]) : 0.f;
+#pragma unroll
+            for (int i = 0; i < V; ++i) acc[i] += v[i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < V; ++i) red[ty][tx * V + i] = acc[i];
     __syncthreads();
-    if (rl == 0 && c < N)
-        part[(int64_t)blockIdx.y * N + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    for (int c = threadIdx.x; c < 32 * V; c += 256) {
+        const int col = blockIdx.x * 32 * V + c;
+        if (col < N) {
+            float t = 0.f;
+#pragma unroll
+            for (int y = 0; y < 8; ++y) t += red[y][c];
+            part[(int64_t)blockIdx.y * N + col] = t;
+        }
+    }
 }
 
 int wgrad_splits(int M, int N, int K) {
+    // total blocks ~ 1.5 per CU: enough to stream from every CU, few enough that the fp32 slabs
+    // (splits * N * K * 4 bytes written + re-read) stay a fraction of the operand traffic
     const long tiles = (long)ceil_div(N, 128) * ceil_div(K, 128);
-    long want = (1024 + tiles - 1) / tiles;               // ~4 blocks per CU in flight
+    long want = (384 + tiles - 1) / tiles;
     long maxs = (M + 255) / 256;                          // at least 256 reduction rows per split
     long s = want < maxs ? want : maxs;
     if (s < 1) s = 1;
@@ -276,13 +433,17 @@ int launch_linear_fwd(const LinearFwdArgs &a, hipStream_t s) {
     MIVIT_CHECK(a.M > 0 && a.N > 0 && a.K > 0, "linear_fwd: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
     GemmArgs g = {};
     g.A = a.x; g.lda = a.ldx; g.B = a.W; g.ldb = a.K;
-    g.M = a.M; g.N = a.N; g.K = a.K; g.k_chunk = (a.K + 31) / 32 * 32;
+    g.M = a.M; g.N = a.N; g.K = a.K; g.k_chunk = (a.K + 63) / 64 * 64;
     g.bias = a.bias; g.act = a.act;
     g.resid = a.resid; g.ldr = a.ldr;
     g.C = a.y; g.ldc = a.ldy; g.c_is_f32 = (a.dtype == MIVIT_F32) || a.y_is_f32;
     g.C2 = a.y_preact;
     g.map_rows = a.map_rows; g.map_stride = a.map_stride; g.map_off = a.map_off;
     if (a.dtype == MIVIT_F32) return launch_gemm_t<float, float, KC, float, KC>(g, 1, s);
+    if (a.w_is_bf16) {
+        if (a.x_is_f32) return launch_gemm_t<bf16, float, KC, bf16, KC>(g, 1, s);
+        return launch_gemm_t<bf16, bf16, KC, bf16, KC>(g, 1, s);
+    }
     if (a.x_is_f32) return launch_gemm_t<bf16, float, KC, float, KC>(g, 1, s);
     return launch_gemm_t<bf16, bf16, KC, float, KC>(g, 1, s);
 }
@@ -291,12 +452,13 @@ int launch_linear_dgrad(const LinearDgradArgs &a, hipStream_t s) {
     MIVIT_CHECK(a.M > 0 && a.N > 0 && a.K > 0, "linear_dgrad: empty problem");
     GemmArgs g = {};
     g.A = a.dy; g.lda = a.lddy; g.B = a.W; g.ldb = a.K;      // B(n = k_in, k = n_out) = W[n_out * K + k_in]
-    g.M = a.M; g.N = a.K; g.K = a.N; g.k_chunk = (a.N + 31) / 32 * 32;
+    g.M = a.M; g.N = a.K; g.K = a.N; g.k_chunk = (a.N + 63) / 64 * 64;
     g.dact = a.act != MIVIT_ACT_NONE ? a.saved : nullptr; g.ldd = a.lds; g.dact_kind = a.act;
     g.resid = a.dres; g.ldr = a.lddr;
     g.C = a.dx; g.ldc = a.lddx; g.c_is_f32 = (a.dtype == MIVIT_F32) || a.dx_is_f32;
     if (a.dtype == MIVIT_F32) return launch_gemm_t<float, float, KC, float, KSTR>(g, 1, s);
     MIVIT_CHECK(!a.dy_is_f32, "linear_dgrad: fp32 dy in bf16 mode is not instantiated (convert first)");
+    if (a.w_is_bf16) return launch_gemm_t<bf16, bf16, KC, bf16, KSTR>(g, 1, s);
     return launch_gemm_t<bf16, bf16, KC, float, KSTR>(g, 1, s);
 }
 
@@ -317,7 +479,7 @@ int launch_linear_wgrad(const LinearWgradArgs &a, hipStream_t s) {
         GemmArgs g = {};
         g.A = a.dy; g.lda = a.lddy; g.B = a.x; g.ldb = a.ldx;
         g.M = a.N; g.N = a.K; g.K = a.M;
-        g.k_chunk = (ceil_div(a.M, sp) + 31) / 32 * 32;
+        g.k_chunk = (ceil_div(a.M, sp) + 63) / 64 * 64;
         const int splits = ceil_div(a.M, g.k_chunk);
         g.c_is_f32 = 1; g.ldc = a.K;
         if (splits > 1) { g.C = slabs; g.slab_stride = (int64_t)a.N * a.K; }
@@ -336,7 +498,8 @@ int launch_linear_wgrad(const LinearWgradArgs &a, hipStream_t s) {
     if (a.db) {
         const int chunks = colsum_chunks(a.M);
         const int chunk = ceil_div(a.M, chunks);
-        dim3 grid(ceil_div(a.N, 64), chunks);
+        const int cols_per_block = (a.dtype == MIVIT_F32 || a.dy_is_f32) ? 32 * 4 : 32 * 8;
+        dim3 grid(ceil_div(a.N, cols_per_block), chunks);
         if (a.dtype == MIVIT_F32 || a.dy_is_f32)
             hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, s, static_cast<const float *>(a.dy), a.lddy,
                                a.M, a.N, chunk, bias_part);
@@ -359,7 +522,7 @@ extern "C" int mivit_linear_fwd(int dtype, const void *x, int x_is_f32, int64_t 
     MIVIT_CHECK(dtype == MIVIT_F32 || dtype == MIVIT_BF16, "bad dtype %d", dtype);
     MIVIT_CHECK(x && W && y, "linear_fwd: null pointer");
     LinearFwdArgs a = {};
-    a.dtype = dtype; a.x = x; a.x_is_f32 = x_is_f32 || dtype == MIVIT_F32; a.ldx = ldx; a.W = W; a.bias = bias;
+    a.dtype = dtype; a.x = x; a.x_is_f32 = x_is_f32 || dtype == MIVIT_F32; a.ldx = ldx; a.W = W; a.w_is_bf16 = 0; a.bias = bias;
     a.M = M; a.N = N; a.K = K; a.act = act; a.resid = resid; a.ldr = ldr; a.y = y; a.ldy = ldy; a.y_preact = y_preact;
     return launch_linear_fwd(a, static_cast<hipStream_t>(stream));
 }

@@ -90,12 +90,50 @@ extern "C" const char *mivit_profile_tag_name(int tag) {
 
 namespace {
 
+// out[i] (+)= sum_p part[p * n + i].  Block = 32 element-threads (one float4 each) x 8 part-lanes; every part-lane
+// sums its parts in a fixed order, the 8 lanes are combined through LDS in a fixed order: deterministic.
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float *part, int nparts, int64_t n, float *out,
-                                                          int accumulate) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        float acc = 0.f;
-        for (int p = 0; p < nparts; ++p) acc += part[(int64_t)p * n + i];   // fixed order: deterministic
-        out[i] = accumulate ? out[i] + acc : acc;
+                                                          int accumulate, int vec_ok) {
+    __shared__ float4 red[8][32];
+    const int ex = threadIdx.x & 31, pl = threadIdx.x >> 5;
+    const int64_t e0 = ((int64_t)blockIdx.x * 32 + ex) * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (e0 < n) {
+        if (vec_ok) {
+            int p = pl;
+            for (; p + 24 < nparts; p += 32) {        // 4 independent 16-byte loads in flight per thread
+                const float4 a = *reinterpret_cast<const float4 *>(part + (int64_t)p * n + e0);
+                const float4 b = *reinterpret_cast<const float4 *>(part + (int64_t)(p + 8) * n + e0);
+                const float4 c = *reinterpret_cast<const float4 *>(part + (int64_t)(p + 16) * n + e0);
+                const float4 d = *reinterpret_cast<const float4 *>(part + (int64_t)(p + 24) * n + e0);
+                acc.x += (a.x + b.x) + (c.x + d.x); acc.y += (a.y + b.y) + (c.y + d.y);
+                acc.z += (a.z + b.z) + (c.z + d.z); acc.w += (a.w + b.w) + (c.w + d.w);
+            }
+            for (; p < nparts; p += 8) {
+                const float4 a = *reinterpret_cast<const float4 *>(part + (int64_t)p * n + e0);
+                acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
+            }
+        } else {
+            for (int p = pl; p < nparts; p += 8) {
+                const float *q = part + (int64_t)p * n + e0;
+                acc.x += q[0];
+                if (e0 + 1 < n) acc.y += q[1];
+                if (e0 + 2 < n) acc.z += q[2];
+                if (e0 + 3 < n) acc.w += q[3];
+            }
+        }
+    }
+    red[pl][ex] = acc;
+    __syncthreads();
+    if (pl == 0 && e0 < n) {
+        float4 t = red[0][ex];
+#pragma unroll
+        for (int y = 1; y < 8; ++y) { t.x += red[y][ex].x; t.y += red[y][ex].y; t.z += red[y][ex].z; t.w += red[y][ex].w; }
+        float *o = out + e0;
+        const float v[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (e0 + i < n) o[i] = accumulate ? o[i] + v[i] : v[i];
     }
 }
 
@@ -162,9 +200,9 @@ int batch_chunks(int B) {
 }  // namespace
 
 int launch_slab_reduce(const float *part, int nparts, int64_t n, float *out, int accumulate, hipStream_t s) {
-    int blocks = (int)((n + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, s, part, nparts, n, out, accumulate);
+    const int blocks = (int)((n + 127) / 128);
+    const int vec_ok = (n % 4 == 0) && ((reinterpret_cast<uintptr_t>(part) & 15) == 0);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, s, part, nparts, n, out, accumulate, vec_ok);
     MIVIT_LAUNCH_CHECK();
     return 0;
 }
