@@ -1,0 +1,419 @@
+// bf16 fast path of the attention core for short sequences (S <= 64, head dim 16/32: every shipped MiViT config).
+//
+// One 64-lane wavefront per (batch, head).  What makes it cheap:
+//  * Q/K/V/dO MFMA fragments whose contraction index is the head dimension are loaded STRAIGHT from HBM/L2 into
+//    registers (16 contiguous bytes per lane): no LDS staging, no zero fill, and the same registers serve as A or
+//    B operand (both want [row or col = lane&15][k = 8*(lane>>4)..+7]).
+//  * Products that contract over tokens take one operand from the accumulator registers of the score tile
+//    (C layout: lane = column, registers = rows) with a consistent permutation of the k index, and the other
+//    through ds_read_b64_tr_b16 from a NATURAL [token][d] LDS image: no transposed copies, no P / dS round trip.
+//      forward : S^T = K Q^T (lane = query row) -> softmax in-lane + 2 shuffles -> O = P V   (V image in LDS)
+//      backward: S = Q K^T, dP = dO V^T (lane = key)  -> dV += P^T dO, dK += dS^T Q           (dO, Q images)
+//                S^T, dP^T            (lane = query)  -> dQ  = dS K                            (K image)
+//    (scores are computed in both orientations in backward: 4 extra MFMAs per tile pair buy zero LDS traffic
+//    for the probabilities).
+// Everything else (fp32 mode, long sequences, wide heads) uses the general kernels in attention.hip.
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+struct U128 {
+    uint32_t w[4];
+};
+
+__device__ __forceinline__ bf16x8 as_frag(const U128 &u) { return __builtin_bit_cast(bf16x8, u); }
+
+// fragment straight from global memory: element (row0 + lane&15, d0 + 8*(lane>>4) .. +7); zero outside [S) x [Dh)
+__device__ __forceinline__ bf16x8 gfrag(const bf16 *base, int64_t ld, int row0, int S, int d0, int Dh, int lane) {
+    const int r = row0 + (lane & 15), d = d0 + 8 * (lane >> 4);
+    U128 u = {{0u, 0u, 0u, 0u}};
+    if (r < S && d + 8 <= Dh) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(base + (int64_t)r * ld + d);
+        u.w[0] = v.x; u.w[1] = v.y; u.w[2] = v.z; u.w[3] = v.w;
+    }
+    return as_frag(u);
+}
+
+// B (or A) fragment whose k index runs over tokens, read transposed from a natural [token][d] LDS image:
+// k slots 0..3 = tokens ta + 0..3, k slots 4..7 = tokens tb + 0..3 (ta, tb already include the lane group's 4*g),
+// column = col0 + (lane & 15).
+__device__ __forceinline__ bf16x8 tr_frag(const bf16 *img, int ld, int ta, int tb, int col0, int lane) {
+    const int i = lane & 15, q = i >> 2, p = i & 3;
+    typedef __attribute__((address_space(3))) s16x4 lds_v4;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4 *)(img + (ta + q) * ld + col0 + 4 * p));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4 *)(img + (tb + q) * ld + col0 + 4 * p));
+    struct { s16x4 a, b; } pr = {lo, hi};
+    return __builtin_bit_cast(bf16x8, pr);
+}
+
+// 8 fp32 accumulator values (two tiles' 4 rows each) -> one bf16 operand fragment
+__device__ __forceinline__ bf16x8 pack_frag(const f32x4 a, const f32x4 b) {
+    bf16x8 f;
+    f[0] = (__bf16)a[0]; f[1] = (__bf16)a[1]; f[2] = (__bf16)a[2]; f[3] = (__bf16)a[3];
+    f[4] = (__bf16)b[0]; f[5] = (__bf16)b[1]; f[6] = (__bf16)b[2]; f[7] = (__bf16)b[3];
+    return f;
+}
+
+__device__ __forceinline__ f32x4 mma(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float g16_max(float v) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float g16_sum(float v) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float x4_max(float v) {   // across the 4 lane groups (same lane & 15)
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float x4_sum(float v) {
+    v += __shfl_xor(v, 16, 64);
+    return v + __shfl_xor(v, 32, 64);
+}
+
+__device__ __forceinline__ void lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// stage a natural [S][Dh] head slice into an LDS image of NTP*16 rows (rows >= S zero), 16-byte chunks
+__device__ __forceinline__ void stage_nat(bf16 *img, int ld, const bf16 *src, int64_t src_ld, int S, int rows, int Dh,
+                                          int lane) {
+    const int cpr = Dh >> 3;
+    for (int u = lane; u < rows * cpr; u += 64) {
+        const int r = u / cpr, d = (u % cpr) * 8;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (r < S) v = *reinterpret_cast<const uint4 *>(src + (int64_t)r * src_ld + d);
+        *reinterpret_cast<uint4 *>(img + r * ld + d) = v;
+    }
+}
+
+struct FastDims {
+    int B, S, H, Dh, E;
+    int ld;          // LDS image row length (elements)
+    int img;         // elements per image (NTP * 16 * ld)
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------------------------
+template <int NT, int ND>
+__global__ __launch_bounds__(256) void attn_fwd_fast(const bf16 *qkv, bf16 *ctx, const FastDims d) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int KD = (ND + 1) / 2;          // 32-wide k steps over the head dimension
+    constexpr int NP = (NT + 1) / 2;          // token tile pairs (32-wide k steps over tokens)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pair = blockIdx.x * 4 + wave;
+    if (pair >= d.B * d.H) return;
+    const int b = pair / d.H, h = pair % d.H;
+    const int g = lane >> 4, cq = lane & 15;
+    bf16 *Vimg = reinterpret_cast<bf16 *>(smem_raw) + (size_t)wave * d.img;
+    const int64_t ld3 = 3 * (int64_t)d.E;
+    const bf16 *q = qkv + (int64_t)b * d.S * ld3 + h * d.Dh, *k = q + d.E, *v = q + 2 * d.E;
+    stage_nat(Vimg, d.ld, v, ld3, d.S, NP * 32, d.Dh, lane);
+    bf16x8 kf[NT][KD];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int kd = 0; kd < KD; ++kd) kf[j][kd] = gfrag(k, ld3, j * 16, d.S, kd * 32, d.Dh, lane);
+    lds_sync();
+    const float scale = 1.0f / sqrtf((float)d.Dh);
+
+    for (int it = 0; it < NT; ++it) {
+        bf16x8 qf[KD];
+#pragma unroll
+        for (int kd = 0; kd < KD; ++kd) qf[kd] = gfrag(q, ld3, it * 16, d.S, kd * 32, d.Dh, lane);
+        // S^T tiles: rows = keys (registers), column = query row it*16 + cq (lane)
+        f32x4 st[NT];
+        float m = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            st[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kd = 0; kd < KD; ++kd) st[j] = mma(kf[j][kd], qf[kd], st[j]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool ok = j * 16 + 4 * g + r < d.S;
+                st[j][r] = ok ? st[j][r] * scale : -INFINITY;
+                m = fmaxf(m, st[j][r]);
+            }
+        }
+        m = x4_max(m);
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = (j * 16 + 4 * g + r < d.S) ? __expf(st[j][r] - m) : 0.f;
+                st[j][r] = e;
+                sum += e;
+            }
+        const float inv = 1.f / x4_sum(sum);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) st[j] *= inv;
+        // O[row][d] = sum_key P[row][key] V[key][d]: A = P from registers (lane = row), B = V image transposed-read
+#pragma unroll
+        for (int jd = 0; jd < ND; ++jd) {
+            f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < NP; ++ks) {
+                const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                const bf16x8 a = pack_frag(st[2 * ks], (2 * ks + 1 < NT) ? st[2 * ks + 1] : zero);
+                const bf16x8 bb = tr_frag(Vimg, d.ld, 32 * ks + 4 * g, 32 * ks + 16 + 4 * g, jd * 16, lane);
+                o = mma(a, bb, o);
+            }
+            // C layout: column = d (jd*16 + cq), rows = query it*16 + 4g + r
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = it * 16 + 4 * g + r;
+                if (row < d.S) ctx[((int64_t)b * d.S + row) * d.E + h * d.Dh + jd * 16 + cq] = from_f32<bf16>(o[r]);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// backward
+// ---------------------------------------------------------------------------------------------------------------
+template <int NT, int ND>
+__global__ __launch_bounds__(256) void attn_bwd_fast(const bf16 *qkv, const bf16 *dctx, bf16 *dqkv, const FastDims d) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int KD = (ND + 1) / 2;
+    constexpr int NP = (NT + 1) / 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pair = blockIdx.x * 4 + wave;
+    if (pair >= d.B * d.H) return;
+    const int b = pair / d.H, h = pair % d.H;
+    const int g = lane >> 4, cq = lane & 15;
+    bf16 *Qimg = reinterpret_cast<bf16 *>(smem_raw) + (size_t)wave * 3 * d.img;
+    bf16 *Kimg = Qimg + d.img, *Oimg = Kimg + d.img;
+    const int64_t ld3 = 3 * (int64_t)d.E;
+    const bf16 *q = qkv + (int64_t)b * d.S * ld3 + h * d.Dh, *k = q + d.E, *v = q + 2 * d.E;
+    const bf16 *dO = dctx + (int64_t)b * d.S * d.E + h * d.Dh;
+    stage_nat(Qimg, d.ld, q, ld3, d.S, NP * 32, d.Dh, lane);
+    stage_nat(Kimg, d.ld, k, ld3, d.S, NP * 32, d.Dh, lane);
+    stage_nat(Oimg, d.ld, dO, d.E, d.S, NP * 32, d.Dh, lane);
+    bf16x8 kf[NT][KD], vf[NT][KD], qf[NT][KD], of[NT][KD];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int kd = 0; kd < KD; ++kd) {
+            kf[j][kd] = gfrag(k, ld3, j * 16, d.S, kd * 32, d.Dh, lane);
+            vf[j][kd] = gfrag(v, ld3, j * 16, d.S, kd * 32, d.Dh, lane);
+            qf[j][kd] = gfrag(q, ld3, j * 16, d.S, kd * 32, d.Dh, lane);
+            of[j][kd] = gfrag(dO, d.E, j * 16, d.S, kd * 32, d.Dh, lane);
+        }
+    lds_sync();
+    const float scale = 1.0f / sqrtf((float)d.Dh);
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    bf16 *dst = dqkv + (int64_t)b * d.S * ld3 + h * d.Dh;
+
+    f32x4 dv[NT][ND], dk[NT][ND];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int jd = 0; jd < ND; ++jd) { dv[j][jd] = zero; dk[j][jd] = zero; }
+
+#pragma unroll
+    for (int ip = 0; ip < NP; ++ip) {
+        f32x4 pU[2][NT], sU[2][NT];     // P and dS of the two row tiles of this pair, lane = key, registers = rows
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int it = 2 * ip + t;
+            if (it >= NT) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j) { pU[t][j] = zero; sU[t][j] = zero; }
+                continue;
+            }
+            // ---- lane = key orientation: S = Q K^T, dP = dO V^T ----
+            f32x4 sc[NT], dp[NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                sc[j] = zero; dp[j] = zero;
+#pragma unroll
+                for (int kd = 0; kd < KD; ++kd) {
+                    sc[j] = mma(qf[it][kd], kf[j][kd], sc[j]);
+                    dp[j] = mma(of[it][kd], vf[j][kd], dp[j]);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float m = -INFINITY;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const bool ok = j * 16 + cq < d.S;
+                    sc[j][r] = ok ? sc[j][r] * scale : -INFINITY;
+                    m = fmaxf(m, sc[j][r]);
+                }
+                m = g16_max(m);
+                float sum = 0.f;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const float e = (j * 16 + cq < d.S) ? __expf(sc[j][r] - m) : 0.f;
+                    sc[j][r] = e;
+                    sum += e;
+                }
+                const float inv = 1.f / g16_sum(sum);
+                float delta = 0.f;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    sc[j][r] *= inv;
+                    delta += sc[j][r] * dp[j][r];
+                }
+                delta = g16_sum(delta);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    pU[t][j][r] = sc[j][r];
+                    sU[t][j][r] = scale * sc[j][r] * (dp[j][r] - delta);
+                }
+            }
+            // ---- lane = query orientation: S^T = K Q^T, dP^T = V dO^T -> dQ for this row tile ----
+            f32x4 st[NT], dt[NT];
+            float m = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                st[j] = zero; dt[j] = zero;
+#pragma unroll
+                for (int kd = 0; kd < KD; ++kd) {
+                    st[j] = mma(kf[j][kd], qf[it][kd], st[j]);
+                    dt[j] = mma(vf[j][kd], of[it][kd], dt[j]);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool ok = j * 16 + 4 * g + r < d.S;
+                    st[j][r] = ok ? st[j][r] * scale : -INFINITY;
+                    m = fmaxf(m, st[j][r]);
+                }
+            }
+            m = x4_max(m);
+            float sum = 0.f;
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = (j * 16 + 4 * g + r < d.S) ? __expf(st[j][r] - m) : 0.f;
+                    st[j][r] = e;
+                    sum += e;
+                }
+            const float inv = 1.f / x4_sum(sum);
+            float delta = 0.f;
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    st[j][r] *= inv;
+                    delta += st[j][r] * dt[j][r];
+                }
+            delta = x4_sum(delta);
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) st[j][r] = scale * st[j][r] * (dt[j][r] - delta);    // dS^T
+#pragma unroll
+            for (int jd = 0; jd < ND; ++jd) {
+                f32x4 dq = zero;
+#pragma unroll
+                for (int ks = 0; ks < NP; ++ks) {
+                    const bf16x8 a = pack_frag(st[2 * ks], (2 * ks + 1 < NT) ? st[2 * ks + 1] : zero);
+                    const bf16x8 bb = tr_frag(Kimg, d.ld, 32 * ks + 4 * g, 32 * ks + 16 + 4 * g, jd * 16, lane);
+                    dq = mma(a, bb, dq);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = it * 16 + 4 * g + r;
+                    if (row < d.S) dst[(int64_t)row * ld3 + jd * 16 + cq] = from_f32<bf16>(dq[r]);
+                }
+            }
+        }
+        // ---- dV += P^T dO, dK += dS^T Q over the 32 query rows of this pair ----
+#pragma unroll
+        for (int jd = 0; jd < ND; ++jd) {
+            const bf16x8 bo = tr_frag(Oimg, d.ld, 32 * ip + 4 * g, 32 * ip + 16 + 4 * g, jd * 16, lane);
+            const bf16x8 bq = tr_frag(Qimg, d.ld, 32 * ip + 4 * g, 32 * ip + 16 + 4 * g, jd * 16, lane);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                dv[j][jd] = mma(pack_frag(pU[0][j], pU[1][j]), bo, dv[j][jd]);
+                dk[j][jd] = mma(pack_frag(sU[0][j], sU[1][j]), bq, dk[j][jd]);
+            }
+        }
+    }
+    // C layout of dV / dK tiles: column = d (jd*16 + cq), rows = key j*16 + 4g + r
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int jd = 0; jd < ND; ++jd)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = j * 16 + 4 * g + r;
+                if (key < d.S) {
+                    bf16 *o = dst + (int64_t)key * ld3 + jd * 16 + cq;
+                    o[d.E] = from_f32<bf16>(dk[j][jd][r]);
+                    o[2 * d.E] = from_f32<bf16>(dv[j][jd][r]);
+                }
+            }
+}
+
+FastDims make_fast(int B, int S, int H, int Dh) {
+    FastDims d;
+    d.B = B; d.S = S; d.H = H; d.Dh = Dh; d.E = H * Dh;
+    const int NT = (S + 15) / 16, NP = (NT + 1) / 2;
+    d.ld = Dh + 8;
+    d.img = NP * 32 * d.ld;
+    return d;
+}
+
+template <int NT, int ND>
+int fwd_launch(const bf16 *qkv, bf16 *ctx, const FastDims &d, hipStream_t s) {
+    const size_t bytes = (size_t)4 * d.img * sizeof(bf16);
+    ProfScope prof(s);
+    hipLaunchKernelGGL((attn_fwd_fast<NT, ND>), dim3(ceil_div(d.B * d.H, 4)), dim3(256), bytes, s, qkv, ctx, d);
+    MIVIT_LAUNCH_CHECK();
+    return 0;
+}
+template <int NT, int ND>
+int bwd_launch(const bf16 *qkv, const bf16 *dctx, bf16 *dqkv, const FastDims &d, hipStream_t s) {
+    const size_t bytes = (size_t)4 * 3 * d.img * sizeof(bf16);
+    ProfScope prof(s);
+    hipLaunchKernelGGL((attn_bwd_fast<NT, ND>), dim3(ceil_div(d.B * d.H, 4)), dim3(256), bytes, s, qkv, dctx, dqkv, d);
+    MIVIT_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+
+bool attention_fast_supported(int dtype, int S, int Dh) {
+    return dtype == MIVIT_BF16 && S >= 1 && S <= 64 && (Dh == 16 || Dh == 32);
+}
+
+#define FAST_DISPATCH(FN, ...)                                                 \
+    switch (NT * 10 + ND) {                                                    \
+        case 11: return FN<1, 1>(__VA_ARGS__);                                 \
+        case 21: return FN<2, 1>(__VA_ARGS__);                                 \
+        case 31: return FN<3, 1>(__VA_ARGS__);                                 \
+        case 41: return FN<4, 1>(__VA_ARGS__);                                 \
+        case 12: return FN<1, 2>(__VA_ARGS__);                                 \
+        case 22: return FN<2, 2>(__VA_ARGS__);                                 \
+        case 32: return FN<3, 2>(__VA_ARGS__);                                 \
+        case 42: return FN<4, 2>(__VA_ARGS__);                                 \
+        default: MIVIT_FAIL("attention fast path: unsupported tile shape");    \
+    }
+
+int launch_attention_fwd_fast(const void *qkv, int B, int S, int H, int Dh, void *ctx, hipStream_t s) {
+    const FastDims d = make_fast(B, S, H, Dh);
+    const int NT = (S + 15) / 16, ND = Dh / 16;
+    FAST_DISPATCH(fwd_launch, static_cast<const bf16 *>(qkv), static_cast<bf16 *>(ctx), d, s)
+}
+
+int launch_attention_bwd_fast(const void *qkv, const void *dctx, int B, int S, int H, int Dh, void *dqkv, hipStream_t s) {
+    const FastDims d = make_fast(B, S, H, Dh);
+    const int NT = (S + 15) / 16, ND = Dh / 16;
+    FAST_DISPATCH(bwd_launch, static_cast<const bf16 *>(qkv), static_cast<const bf16 *>(dctx), static_cast<bf16 *>(dqkv), d, s)
+}

@@ -228,6 +228,10 @@ int launch_attention_fwd(int dtype, const void *qkv, int B, int S, int H, int Dh
 int launch_attention_bwd(int dtype, const void *qkv, const void *dctx, int B, int S, int H, int Dh, void *dqkv,
                          hipStream_t s);
 int attention_max_seq(int dtype, int Dh);
+// bf16 short-sequence fast path (attention_fast.hip)
+bool attention_fast_supported(int dtype, int S, int Dh);
+int launch_attention_fwd_fast(const void *qkv, int B, int S, int H, int Dh, void *ctx, hipStream_t s);
+int launch_attention_bwd_fast(const void *qkv, const void *dctx, int B, int S, int H, int Dh, void *dqkv, hipStream_t s);
 
 // small elementwise / reduction helpers (misc.hip)
 // out[n] (+)= sum_p part[p*n_stride + n]   (deterministic slab reduce)
