@@ -401,3 +401,106 @@ class ImageFeatureDataset(Dataset):
 
     def __getitem__(self, idx):
         return self.images[idx], self.features[idx], self.labels[idx]
+
+
+# ------------------------------------------------------------------------------------------------------------
+# Pix2D-style ResNet comparison baselines (reference models.py:600-772).  NOT on the MiViT path: plain
+# PyTorch-ROCm modules kept only so getTrainingModels() returns the same model zoo with the same state-dict keys.
+# ------------------------------------------------------------------------------------------------------------
+class BasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, in_channels, out_channels, stride=1, activation=nn.ReLU):
+        super().__init__()
+        self.activation = activation(inplace=True)
+        self.conv1 = nn.Conv2d(in_channels, out_channels, kernel_size=3, stride=stride, padding=1, bias=False)
+        self.bn1 = nn.BatchNorm2d(out_channels)
+        self.act1 = activation(inplace=True)
+        self.conv2 = nn.Conv2d(out_channels, out_channels, kernel_size=3, stride=1, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(out_channels)
+        self.act2 = activation(inplace=True)
+        self.shortcut = nn.Sequential()
+        if stride != 1 or in_channels != out_channels:
+            self.shortcut = nn.Sequential(nn.Conv2d(in_channels, out_channels, kernel_size=1, stride=stride, bias=False),
+                                          nn.BatchNorm2d(out_channels))
+
+    def forward(self, x):
+        out = self.act1(self.bn1(self.conv1(x)))
+        out = self.bn2(self.conv2(out))
+        return self.act2(out + self.shortcut(x))
+
+
+class _LightTrunk(nn.Module):
+    """conv5x5/2 -> maxpool -> three residual stages (32, 64, 128) -> global average pool -> fc1."""
+
+    def __init__(self, block, num_blocks, feature_size, activation):
+        super().__init__()
+        self.in_channels = 32
+        self.activation = activation
+        self.conv1 = nn.Conv2d(1, 32, kernel_size=5, stride=2, padding=2, bias=False)
+        self.bn1 = nn.BatchNorm2d(32)
+        self.act = activation(inplace=True)
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        self.layer1 = self._make_layer(block, 32, num_blocks[0], stride=1)
+        self.layer2 = self._make_layer(block, 64, num_blocks[1], stride=2)
+        self.layer3 = self._make_layer(block, 128, num_blocks[2], stride=2)
+        self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
+        self.feature_size = feature_size
+        self.fc1 = nn.Linear(128 * block.expansion, feature_size)
+        self.fc_act = activation(inplace=True)
+
+    def _make_layer(self, block, out_channels, num_blocks, stride):
+        layers = []
+        for st in [stride] + [1] * (num_blocks - 1):
+            layers.append(block(self.in_channels, out_channels, st, activation=self.activation))
+            self.in_channels = out_channels * block.expansion
+        return nn.Sequential(*layers)
+
+    def trunk(self, x):
+        out = self.maxpool(self.act(self.bn1(self.conv1(x))))
+        out = self.layer3(self.layer2(self.layer1(out)))
+        return self.fc_act(self.fc1(torch.flatten(self.avgpool(out), 1)))
+
+
+class LightResNet(_LightTrunk):
+    def __init__(self, block, num_blocks, num_classes=1, feature_size=64, activation=nn.ReLU):
+        super().__init__(block, num_blocks, feature_size, activation)
+        self.fc2 = nn.Linear(feature_size, num_classes)
+
+    def forward(self, x):
+        return self.fc2(self.trunk(x))
+
+
+class LightImagesFeaturesResNet(_LightTrunk):
+    def __init__(self, block, num_blocks, feature_size=64, activation=nn.ReLU):
+        super().__init__(block, num_blocks, feature_size, activation)
+
+    def forward(self, x):
+        return self.trunk(x)
+
+
+class MultiImageResNet(nn.Module):
+    def __init__(self, image_size, num_classes=1, single_prediction=True, activation=nn.ReLU):
+        super().__init__()
+        self.single_prediction = single_prediction
+        self.resnet = LightResNet(BasicBlock, [1, 1, 1], num_classes, activation=activation)
+
+    def forward(self, x):
+        b, n, h, w = x.shape
+        y = self.resnet(x.reshape(b * n, 1, h, w)).view(b, n, 1)
+        return torch.mean(y, dim=1, keepdim=False) if self.single_prediction else y
+
+
+class MultiImageFeatureResNet(nn.Module):
+    def __init__(self, image_size, external_dim, feature_size=64, hidden_size=128, activation=nn.ReLU):
+        super().__init__()
+        self.resnet = LightImagesFeaturesResNet(BasicBlock, [1, 1, 1], feature_size, activation=activation)
+        self.feature_size = feature_size
+        self.external_dim = external_dim
+        self.mlp = nn.Sequential(nn.Linear(feature_size + external_dim, hidden_size), activation(inplace=True),
+                                 nn.Linear(hidden_size, 1))
+
+    def forward(self, x, external_features):
+        b, n, h, w = x.shape
+        feats = self.resnet(x.reshape(b * n, 1, h, w)).view(b, n, -1).mean(dim=1)
+        return self.mlp(torch.cat([feats, external_features], dim=1))
