@@ -106,11 +106,18 @@ def main():
                   file=sys.stderr)
             sys.exit(2)
     import torch.distributed as dist
+    # rehearsal knobs (not used by the driver): several ranks on ONE GPU over gloo, to exercise the launcher path
+    if os.environ.get("MIVIT_BENCH_SHARE_GPU") == "1":
+        local = 0
+    backend = os.environ.get("MIVIT_DIST_BACKEND", "nccl")       # "nccl" IS RCCL on ROCm
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
 
     from moleculardiffusion_mivit_amd import _native as N
     from moleculardiffusion_mivit_amd import dp
