@@ -61,6 +61,18 @@ int mivit_linear_wgrad(int dtype, const void *dy, int64_t lddy, const void *x, i
                        int M, int N, int K, float *dW, float *db, int accumulate,
                        void *workspace, size_t workspace_bytes, void *stream);
 
+/* bf16-mode streaming kernels of the frame embedding (LinearProjectionEmbedding / CNNEmbedding, models.py:164,191):
+ * the two launches that read the fp32 frames x[M = B*T, K = P*P].  LDS-DMA ring, see csrc/embed.hip.
+ *   fwd  : y[M,E] (bf16) = x @ W^T + bias, W given as its bf16 copy [E,K]
+ *   wgrad: dW[E,K] (fp32, overwritten) = dy[M,E]^T (bf16) @ x
+ * Return 3 when the shape is outside the kernels' constraints (E % 128, K % 128, K >= 256, M >= 128): the caller
+ * then uses mivit_linear_fwd / mivit_linear_wgrad, which accept any shape. */
+int mivit_embed_fwd_bf16(const float *x, const void *W_bf16, const float *bias, int M, int K, int E, void *y_bf16,
+                         void *stream);
+size_t mivit_embed_wgrad_bf16_workspace_bytes(int M, int K, int E);
+int mivit_embed_wgrad_bf16(const void *dy_bf16, const float *x, int M, int K, int E, float *dW, void *workspace,
+                           size_t workspace_bytes, void *stream);
+
 /* Row LayerNorm over E, eps 1e-5, biased variance, affine (nn.LayerNorm: models.py:88-89,134,301).
  * Row r of the output goes to row  (r / rows_per_seq) * out_seq_stride + r % rows_per_seq + out_row_off  when
  * rows_per_seq > 0 (token assembly behind the regression token, models.py:347), else to row r.

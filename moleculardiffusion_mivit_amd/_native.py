@@ -36,6 +36,9 @@ SYMBOLS = {
     "mivit_linear_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "mivit_linear_wgrad": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_void_p,
                                    c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    "mivit_embed_fwd_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "mivit_embed_wgrad_bf16_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "mivit_embed_wgrad_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "mivit_layernorm_fwd": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int64,
                                     c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mivit_layernorm_bwd_workspace_bytes": (c_size_t, [c_int, c_int]),

@@ -233,6 +233,13 @@ bool attention_fast_supported(int dtype, int S, int Dh);
 int launch_attention_fwd_fast(const void *qkv, int B, int S, int H, int Dh, void *ctx, hipStream_t s);
 int launch_attention_bwd_fast(const void *qkv, const void *dctx, int B, int S, int H, int Dh, void *dqkv, hipStream_t s);
 
+// LDS-DMA streaming kernels of the frame embedding, bf16 mode (embed.hip)
+bool embed_dma_supported(int dtype, int M, int K, int E);
+int launch_embed_fwd_dma(const float *X, const void *W_bf16, const float *bias, void *Y, int M, int K, int E, hipStream_t s);
+size_t embed_wgrad_dma_ws_bytes(int M, int K, int E);
+int launch_embed_wgrad_dma(const void *dY_bf16, const float *X, float *dW, int M, int K, int E, void *ws, size_t ws_bytes,
+                           hipStream_t s);
+
 // small elementwise / reduction helpers (misc.hip)
 // out[n] (+)= sum_p part[p*n_stride + n]   (deterministic slab reduce)
 int launch_slab_reduce(const float *part, int nparts, int64_t n, float *out, int accumulate, hipStream_t s);

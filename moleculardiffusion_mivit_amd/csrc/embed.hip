@@ -1,0 +1,366 @@
+// HBM-streaming kernels of the frame embedding (bf16 mode): the two launches that read the fp32 frames.
+//
+//   forward : emb[M, E]  = X[M, K] . W[E, K]^T + b          X = fp32 frames [B*T, P*P], W = bf16 shadow weights
+//   wgrad   : dW[E, K]   = sum_m d_emb[m, :]^T X[m, :]      (split over rows into fp32 slabs, reduced deterministically)
+//
+// Both are bound by the one pass over X (AI = E/2 FLOP/B), so the design goal is bytes in flight, not FLOPs:
+//  * operands go global -> LDS by LDS-DMA (global_load_lds, 16 B per lane, 1 KiB per wave-instruction): no staging
+//    registers, a 3-slot ring with two stages in flight behind counted s_waitcnt vmcnt + raw s_barrier;
+//  * fp32 -> bf16 conversion happens AFTER the LDS read, on the MFMA operand fragments;
+//  * LDS images are the natural row-major tiles; bank conflicts are removed by XOR-permuting the 16-byte chunks of
+//    a row on the SOURCE address (the DMA destination is lane-linear) and applying the same XOR when reading;
+//  * in wgrad the contraction runs over rows: the bf16 operand is read with ds_read_b64_tr_b16, the fp32 operand
+//    with 8 scalar reads per fragment (no 32-bit transposing read exists).
+// Shapes outside the constraints below fall back to the general register-staged GEMM (gemm.hip).
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((address_space(1))) const void gptr_t;
+typedef __attribute__((address_space(3))) void lptr_t;
+
+__device__ __forceinline__ void dma16(const void *g, void *l) {
+    __builtin_amdgcn_global_load_lds((gptr_t *)g, (lptr_t *)l, 16, 0, 0);
+}
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+
+__device__ __forceinline__ bf16x8 cvt8(const float4 a, const float4 b) {
+    bf16x8 f;
+    f[0] = (__bf16)a.x; f[1] = (__bf16)a.y; f[2] = (__bf16)a.z; f[3] = (__bf16)a.w;
+    f[4] = (__bf16)b.x; f[5] = (__bf16)b.y; f[6] = (__bf16)b.z; f[7] = (__bf16)b.w;
+    return f;
+}
+__device__ __forceinline__ f32x4 mma(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+constexpr int NSLOT = 3;
+
+// =================================================================================================================
+// forward: tile 128 rows x BN columns, stage = 64 fp32 k of X (256 B rows) + 64 bf16 k of W (128 B rows)
+// =================================================================================================================
+template <int BN>
+struct FwdCfg {
+    static constexpr int BM = 128, BK = 64;
+    static constexpr int A_BYTES = BM * BK * 4;          // 32 KiB
+    static constexpr int B_BYTES = BN * BK * 2;          // 16 KiB (BN = 128)
+    static constexpr int STAGE = A_BYTES + B_BYTES;
+    static constexpr int A_DMA = A_BYTES / 1024 / 4;     // wave-instructions per wave per stage
+    static constexpr int B_DMA = B_BYTES / 1024 / 4;
+    static constexpr int PER_STAGE = A_DMA + B_DMA;
+};
+
+struct EmbFwdArgs {
+    const float *X; const bf16 *W; const float *bias; bf16 *Y;
+    int M, K, E;
+};
+
+template <int BN>
+__device__ __forceinline__ void fwd_issue(const EmbFwdArgs &a, unsigned char *slot, int m0, int n0, int k0, int wave,
+                                          int lane) {
+    using C = FwdCfg<BN>;
+    // A: 4 rows (256 B each) per wave-instruction; chunk c of row r lands in slot c ^ (2 * (r & 7))
+#pragma unroll
+    for (int i = 0; i < C::A_DMA; ++i) {
+        const int inst = wave * C::A_DMA + i;
+        const int r = inst * 4 + (lane >> 4), s = lane & 15;
+        const int c = s ^ (2 * (r & 7));
+        const int gr = min(m0 + r, a.M - 1);
+        dma16(a.X + (int64_t)gr * a.K + k0 + c * 4, slot + inst * 1024);
+    }
+    // B: 8 rows (128 B each) per wave-instruction; chunk c of row n lands in slot c ^ ((n >> 1) & 7)
+    unsigned char *bs = slot + C::A_BYTES;
+#pragma unroll
+    for (int i = 0; i < C::B_DMA; ++i) {
+        const int inst = wave * C::B_DMA + i;
+        const int n = inst * 8 + (lane >> 3), s = lane & 7;
+        const int c = s ^ ((n >> 1) & 7);
+        dma16(a.W + (int64_t)(n0 + n) * a.K + k0 + c * 8, bs + inst * 1024);
+    }
+}
+
+template <int BN>
+__global__ __launch_bounds__(256) void embed_fwd_dma(const EmbFwdArgs a) {
+    using C = FwdCfg<BN>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int TM = 4, TN = BN / 32;           // wave tile 64 x BN/2 (waves 2 x 2)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * C::BM, n0 = blockIdx.x * BN;
+    const int nst = a.K / C::BK;
+    const int g = lane >> 4, cq = lane & 15;
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    fwd_issue<BN>(a, smem, m0, n0, 0, wave, lane);
+    if (nst > 1) fwd_issue<BN>(a, smem + C::STAGE, m0, n0, C::BK, wave, lane);
+    for (int s = 0; s < nst; ++s) {
+        // stage s has landed once at most one younger stage of this wave's DMAs is still in flight
+        if (s + 1 < nst) wait_vm<C::PER_STAGE>();
+        else wait_vm<0>();
+        barrier();      // everyone's share of stage s landed; everyone finished reading slot (s+2)%3 (= stage s-1)
+        if (s + 2 < nst) fwd_issue<BN>(a, smem + ((s + 2) % NSLOT) * C::STAGE, m0, n0, (s + 2) * C::BK, wave, lane);
+        const unsigned char *As = smem + (s % NSLOT) * C::STAGE, *Bs = As + C::A_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int r = wm * 64 + i * 16 + cq;
+                const int c = (kk * 8 + 2 * g) ^ (2 * (r & 7));
+                const float4 *p = reinterpret_cast<const float4 *>(As + r * 256 + c * 16);
+                af[i] = cvt8(p[0], p[1]);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = wn * (BN / 2) + j * 16 + cq;
+                const int c = (kk * 4 + g) ^ ((n >> 1) & 7);
+                bf[j] = *reinterpret_cast<const bf16x8 *>(Bs + n * 128 + c * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = mma(af[i], bf[j], acc[i][j]);
+        }
+    }
+    // epilogue: + bias, through LDS as fp32 (64 rows per pass), 16-byte bf16 stores
+    constexpr int LDC = BN + 4;
+    float *Cs = reinterpret_cast<float *>(smem);
+    for (int h = 0; h < 2; ++h) {
+        barrier();
+        if (wm == h) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int lc = wn * (BN / 2) + j * 16 + cq;
+                    const float bv = a.bias ? a.bias[n0 + lc] : 0.f;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Cs[(i * 16 + 4 * g + r) * LDC + lc] = acc[i][j][r] + bv;
+                }
+        }
+        barrier();
+        for (int c = tid; c < 64 * (BN / 8); c += 256) {
+            const int lr = c / (BN / 8), lc = (c % (BN / 8)) * 8;
+            const int row = m0 + h * 64 + lr;
+            if (row < a.M) {
+                float v[8];
+                *reinterpret_cast<float4 *>(v) = *reinterpret_cast<const float4 *>(Cs + lr * LDC + lc);
+                *reinterpret_cast<float4 *>(v + 4) = *reinterpret_cast<const float4 *>(Cs + lr * LDC + lc + 4);
+                store16(a.Y + (int64_t)row * a.E + n0 + lc, v);
+            }
+        }
+    }
+}
+
+// =================================================================================================================
+// wgrad: tile BE rows (e) x 128 columns (k), stage = 64 rows m of dY (E bf16 = 2E B rows) + 64 rows of X (512 B)
+// =================================================================================================================
+template <int BE>
+struct WgCfg {
+    static constexpr int BK = 128, BMR = 64;             // 128 output columns, 64 reduction rows per stage
+    static constexpr int A_BYTES = BMR * BE * 2;         // 16 KiB (BE = 128)
+    static constexpr int B_BYTES = BMR * BK * 4;         // 32 KiB
+    static constexpr int STAGE = A_BYTES + B_BYTES;
+    static constexpr int A_DMA = A_BYTES / 1024 / 4;
+    static constexpr int B_DMA = B_BYTES / 1024 / 4;
+    static constexpr int PER_STAGE = A_DMA + B_DMA;
+    static constexpr int A_CH = BE / 8;                  // 16-byte chunks per dY row
+};
+
+struct EmbWgArgs {
+    const bf16 *dY; const float *X; float *slabs;
+    int M, K, E, rows_per_split;
+};
+
+template <int BE>
+__device__ __forceinline__ void wg_issue(const EmbWgArgs &a, unsigned char *slot, int e0, int k0, int mrow, int mend,
+                                         int wave, int lane) {
+    using C = WgCfg<BE>;
+    constexpr int RPI = 1024 / (BE * 2);               // dY rows per wave-instruction (4 at BE = 128)
+#pragma unroll
+    for (int i = 0; i < C::A_DMA; ++i) {
+        const int inst = wave * C::A_DMA + i;
+        const int r = inst * RPI + lane / C::A_CH, s = lane % C::A_CH;
+        const int c = s ^ ((2 * (r & 7)) & (C::A_CH - 1));
+        const int gm = min(mrow + r, mend - 1);
+        dma16(a.dY + (int64_t)gm * a.E + e0 + c * 8, slot + inst * 1024);
+    }
+    unsigned char *bs = slot + C::A_BYTES;
+#pragma unroll
+    for (int i = 0; i < C::B_DMA; ++i) {
+        const int inst = wave * C::B_DMA + i;
+        const int r = inst * 2 + (lane >> 5), s = lane & 31;
+        const int c = s ^ (((r >> 3) & 1) << 2);          // rows 8 apart land 16 floats (= 16 banks) apart
+        const int gm = min(mrow + r, mend - 1);
+        dma16(a.X + (int64_t)gm * a.K + k0 + c * 4, bs + inst * 1024);
+    }
+}
+
+template <int BE>
+__global__ __launch_bounds__(256) void embed_wgrad_dma(const EmbWgArgs a) {
+    using C = WgCfg<BE>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int TM = BE / 32, TN = 4;            // wave tile BE/2 (e) x 64 (k)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int k0 = blockIdx.x * C::BK, e0 = blockIdx.y * BE;
+    const int mb = blockIdx.z * a.rows_per_split, me = min(a.M, mb + a.rows_per_split);
+    const int nst = (me - mb + C::BMR - 1) / C::BMR;
+    const int g = lane >> 4, cq = lane & 15, q = cq >> 2, p = cq & 3;
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (nst > 0) wg_issue<BE>(a, smem, e0, k0, mb, me, wave, lane);
+    if (nst > 1) wg_issue<BE>(a, smem + C::STAGE, e0, k0, mb + C::BMR, me, wave, lane);
+    for (int s = 0; s < nst; ++s) {
+        if (s + 1 < nst) wait_vm<C::PER_STAGE>();
+        else wait_vm<0>();
+        barrier();
+        if (s + 2 < nst) wg_issue<BE>(a, smem + ((s + 2) % NSLOT) * C::STAGE, e0, k0, mb + (s + 2) * C::BMR, me, wave, lane);
+        const unsigned char *As = smem + (s % NSLOT) * C::STAGE, *Bs = As + C::A_BYTES;
+        const int valid = min(C::BMR, me - (mb + s * C::BMR));     // rows of this stage inside the split
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            // k slots 0..3 = rows kk*32 + 8g + 0..3, slots 4..7 = rows kk*32 + 8g + 4..7 (both operands)
+            const int mr = kk * 32 + 8 * g;
+            bf16x8 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                // A[e][m] from the natural [m][e] image: transposed read of 4 rows x 16 e (two per fragment)
+                const int ecol = wm * (BE / 2) + i * 16 + 4 * p;           // this lane supplies e columns ecol..ecol+3
+                s16x4 lo, hi;
+                {
+                    const int r = mr + q;
+                    const int c = (ecol >> 3) ^ ((2 * (r & 7)) & (C::A_CH - 1));
+                    lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4 *)(As + r * (BE * 2) + c * 16 + (ecol & 7) * 2));
+                }
+                {
+                    const int r = mr + 4 + q;
+                    const int c = (ecol >> 3) ^ ((2 * (r & 7)) & (C::A_CH - 1));
+                    hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4 *)(As + r * (BE * 2) + c * 16 + (ecol & 7) * 2));
+                }
+                struct { s16x4 a, b; } pr = {lo, hi};
+                af[i] = __builtin_bit_cast(bf16x8, pr);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = wn * 64 + j * 16 + cq;                       // output column (k of X) of this lane
+                float v[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const int r = mr + t;
+                    const int c = (n >> 2) ^ (((r >> 3) & 1) << 2);
+                    const float x = *reinterpret_cast<const float *>(Bs + r * 512 + c * 16 + (n & 3) * 4);
+                    v[t] = r < valid ? x : 0.f;                            // rows past the split end repeat the last row
+                }
+                bf[j] = cvt8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]));
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = mma(af[i], bf[j], acc[i][j]);
+        }
+    }
+    // slab[z][e][k] fp32 straight from the accumulator layout (column = k, rows = e)
+    float *out = a.slabs + (int64_t)blockIdx.z * a.E * a.K;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int e = e0 + wm * (BE / 2) + i * 16 + 4 * g + r;
+                out[(int64_t)e * a.K + k0 + wn * 64 + j * 16 + cq] = acc[i][j][r];
+            }
+}
+
+int wg_splits(int M, int K, int E) {
+    const long tiles = (long)(K / 128) * (E / 128 > 0 ? E / 128 : 1);
+    long s = (256 + tiles - 1) / tiles;            // ~1 block per CU (one block owns a CU's LDS)
+    const long maxs = (M + 511) / 512;
+    if (s > maxs) s = maxs;
+    if (s < 1) s = 1;
+    return (int)s;
+}
+
+}  // namespace
+
+bool embed_dma_supported(int dtype, int M, int K, int E) {
+    return dtype == MIVIT_BF16 && E % 128 == 0 && K % 128 == 0 && K >= 256 && M >= 128;
+}
+
+int launch_embed_fwd_dma(const float *X, const void *W_bf16, const float *bias, void *Y, int M, int K, int E,
+                         hipStream_t s) {
+    MIVIT_CHECK(((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(W_bf16) | reinterpret_cast<uintptr_t>(Y)) & 15) == 0,
+                "embed_fwd_dma: operands must be 16-byte aligned");
+    using C = FwdCfg<128>;
+    EmbFwdArgs a = {X, static_cast<const bf16 *>(W_bf16), bias, static_cast<bf16 *>(Y), M, K, E};
+    const size_t bytes = (size_t)NSLOT * C::STAGE;
+    auto kern = embed_fwd_dma<128>;
+    MIVIT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    ProfScope prof(s);
+    hipLaunchKernelGGL(kern, dim3(E / 128, ceil_div(M, C::BM)), dim3(256), bytes, s, a);
+    MIVIT_LAUNCH_CHECK();
+    return 0;
+}
+
+size_t embed_wgrad_dma_ws_bytes(int M, int K, int E) { return (size_t)wg_splits(M, K, E) * E * K * sizeof(float); }
+
+int launch_embed_wgrad_dma(const void *dY_bf16, const float *X, float *dW, int M, int K, int E, void *ws, size_t ws_bytes,
+                           hipStream_t s) {
+    MIVIT_CHECK(((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(dY_bf16) | reinterpret_cast<uintptr_t>(ws)) & 15) == 0,
+                "embed_wgrad_dma: operands must be 16-byte aligned");
+    using C = WgCfg<128>;
+    const int splits = wg_splits(M, K, E);
+    MIVIT_CHECK(ws_bytes >= embed_wgrad_dma_ws_bytes(M, K, E), "embed_wgrad_dma: workspace too small");
+    int rps = ceil_div(M, splits);
+    rps = (rps + C::BMR - 1) / C::BMR * C::BMR;
+    const int nz = ceil_div(M, rps);
+    EmbWgArgs a = {static_cast<const bf16 *>(dY_bf16), X, static_cast<float *>(ws), M, K, E, rps};
+    const size_t bytes = (size_t)NSLOT * C::STAGE;
+    auto kern = embed_wgrad_dma<128>;
+    MIVIT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    {
+        ProfScope prof(s);
+        hipLaunchKernelGGL(kern, dim3(K / C::BK, E / 128, nz), dim3(256), bytes, s, a);
+        MIVIT_LAUNCH_CHECK();
+    }
+    return launch_slab_reduce(static_cast<const float *>(ws), nz, (int64_t)E * K, dW, 0, s);
+}
+
+extern "C" int mivit_embed_fwd_bf16(const float *x, const void *W_bf16, const float *bias, int M, int K, int E,
+                                    void *y_bf16, void *stream) {
+    MIVIT_CHECK(x && W_bf16 && y_bf16, "embed_fwd_bf16: null pointer");
+    if (!embed_dma_supported(MIVIT_BF16, M, K, E)) { mivit_set_error("embed_fwd_bf16: unsupported shape"); return 3; }
+    prof_set_tag(MIVIT_PROF_OP);
+    return launch_embed_fwd_dma(x, W_bf16, bias, y_bf16, M, K, E, static_cast<hipStream_t>(stream));
+}
+extern "C" size_t mivit_embed_wgrad_bf16_workspace_bytes(int M, int K, int E) {
+    return embed_dma_supported(MIVIT_BF16, M, K, E) ? embed_wgrad_dma_ws_bytes(M, K, E) : 0;
+}
+extern "C" int mivit_embed_wgrad_bf16(const void *dy_bf16, const float *x, int M, int K, int E, float *dW,
+                                      void *workspace, size_t workspace_bytes, void *stream) {
+    MIVIT_CHECK(dy_bf16 && x && dW && workspace, "embed_wgrad_bf16: null pointer");
+    if (!embed_dma_supported(MIVIT_BF16, M, K, E)) { mivit_set_error("embed_wgrad_bf16: unsupported shape"); return 3; }
+    prof_set_tag(MIVIT_PROF_OP);
+    return launch_embed_wgrad_dma(dy_bf16, x, dW, M, K, E, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+}

@@ -101,7 +101,13 @@ Ws make_ws(const mivit_plan *p, int B, int T, bool bwd) {
         size_t wg = 0;
         auto mx = [&](int m, int n, int k) { size_t b = linear_wgrad_ws_bytes(m, n, k); if (b > wg) wg = b; };
         mx((int)M, 3 * E, E); mx((int)M, E, E); mx((int)M, F, E); mx((int)M, E, F);
-        if (c.embedding != MIVIT_EMBED_EXTERNAL) mx((int)Mt, E, c.patch_size * c.patch_size);
+        if (c.embedding != MIVIT_EMBED_EXTERNAL) {
+            mx((int)Mt, E, c.patch_size * c.patch_size);
+            if (embed_dma_supported(c.dtype, (int)Mt, c.patch_size * c.patch_size, E)) {
+                const size_t b = embed_wgrad_dma_ws_bytes((int)Mt, c.patch_size * c.patch_size, E);
+                if (b > wg) wg = b;
+            }
+        }
         mx(B, c.head_hidden, p->head_in); mx(B, c.output_dim, c.head_hidden);
         if (c.fusion != MIVIT_FUSION_NONE) { mx(B, E, E); mx(B, E, c.global_feature_dim); }
         w.wgrad_bytes = wg; w.wgrad = take(wg);
@@ -318,8 +324,13 @@ extern "C" int mivit_forward(const mivit_plan *plan, const float *params, const 
         RC(launch_convert(1, x, E, dt == MIVIT_F32, at(ws, w.emb), E, Mt, E, 0, s));
     } else {
         const int K = c.patch_size * c.patch_size;
-        RC(lin_fwd(dt, x, 1, K, WT(plan->emb_w), P + plan->emb_b, Mt, E, K, MIVIT_ACT_NONE, nullptr, 0, at(ws, w.emb), E,
-                   nullptr, 0, s));
+        if (embed_dma_supported(dt, Mt, K, E)) {
+            prof_set_tag(MIVIT_PROF_EMBED_FWD);
+            RC(launch_embed_fwd_dma(x, WT(plan->emb_w), P + plan->emb_b, at(ws, w.emb), Mt, K, E, s));
+        } else {
+            RC(lin_fwd(dt, x, 1, K, WT(plan->emb_w), P + plan->emb_b, Mt, E, K, MIVIT_ACT_NONE, nullptr, 0, at(ws, w.emb), E,
+                       nullptr, 0, s));
+        }
     }
     // 2. LayerNorm of the tokens, written behind the regression-token row, + positional table (models.py:334,347,138)
     {
@@ -541,7 +552,13 @@ extern "C" int mivit_backward(const mivit_plan *plan, const float *params, const
                 bool cs = false;
                 RC(ln_bwd_bias(a, G + plan->emb_b, &cs, s));                                      // dxb = d(embedding out)
                 const int K = c.patch_size * c.patch_size;
-                RC(lin_wgrad(dt, at(ws, w.dxb), E, x, 1, K, Mt, E, K, G + plan->emb_w, cs ? G + plan->emb_b : nullptr, wg, wgb, s));
+                if (embed_dma_supported(dt, Mt, K, E)) {
+                    prof_set_tag(MIVIT_PROF_EMBED_WGRAD);
+                    RC(launch_embed_wgrad_dma(at(ws, w.dxb), x, G + plan->emb_w, Mt, K, E, wg, wgb, s));
+                    if (cs) RC(lin_wgrad(dt, at(ws, w.dxb), E, x, 1, K, Mt, E, K, nullptr, G + plan->emb_b, wg, wgb, s));
+                } else {
+                    RC(lin_wgrad(dt, at(ws, w.dxb), E, x, 1, K, Mt, E, K, G + plan->emb_w, cs ? G + plan->emb_b : nullptr, wg, wgb, s));
+                }
             }
         }
     }

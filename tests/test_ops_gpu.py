@@ -135,3 +135,37 @@ def test_attention_exact_uniform():
     out = ops.attention(qkv.cuda(), H).cpu()
     ref = qkv[..., 2 * E:].mean(dim=1, keepdim=True).expand(B, S, E)
     assert _rel(out, ref) < 1e-5
+
+
+@pytest.mark.parametrize("M,K,E", [(256, 4096, 128), (1000, 256, 128), (130, 1024, 256), (4096, 4096, 128), (333, 16384, 512)])
+def test_embed_streaming_kernels_exact(M, K, E):
+    """LDS-DMA embedding kernels (csrc/embed.hip) on small-integer data: bf16 represents every operand and fp32
+    every partial sum exactly, so any swizzle / fragment / ring-slot mix-up is an exact mismatch."""
+    import ctypes
+    from moleculardiffusion_mivit_amd import _native as N
+    g = torch.Generator().manual_seed(M + K)
+    x = torch.randint(-3, 4, (M, K), generator=g).float()
+    W = torch.randint(-2, 3, (E, K), generator=g).float()
+    b = torch.randint(-4, 5, (E,), generator=g).float()
+    dy = torch.randint(-2, 3, (M, E), generator=g).float()
+    xg, Wg, bg, dyg = x.cuda(), W.bfloat16().cuda(), b.cuda(), dy.bfloat16().cuda()
+    y = torch.empty(M, E, dtype=torch.bfloat16, device="cuda")
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())   # noqa: E731
+    N.check(N.lib.mivit_embed_fwd_bf16(p(xg), p(Wg), p(bg), M, K, E, p(y), st), "embed_fwd")
+    ref = x.double() @ W.double().t() + b.double()
+    assert float(ref.abs().max()) < 2 ** 24           # exactly representable sums
+    assert torch.equal(y.float().cpu(), ref.float().bfloat16().float())
+    ws = torch.empty(max(N.lib.mivit_embed_wgrad_bf16_workspace_bytes(M, K, E), 16), dtype=torch.uint8, device="cuda")
+    dW = torch.empty(E, K, device="cuda")
+    N.check(N.lib.mivit_embed_wgrad_bf16(p(dyg), p(xg), M, K, E, p(dW), p(ws), ws.numel(), st), "embed_wgrad")
+    assert torch.equal(dW.cpu(), (dy.double().t() @ x.double()).float())
+
+
+def test_embed_streaming_kernels_reject_odd_shapes():
+    import ctypes
+    from moleculardiffusion_mivit_amd import _native as N
+    z = torch.zeros(16, device="cuda")
+    p = ctypes.c_void_p(z.data_ptr())
+    assert N.lib.mivit_embed_fwd_bf16(p, p, p, 240, 81, 64, p, None) == 3      # reference shape: general GEMM instead
+    assert N.lib.mivit_embed_wgrad_bf16_workspace_bytes(240, 81, 64) == 0
