@@ -13,6 +13,7 @@
 //    with 8 scalar reads per fragment (no 32-bit transposing read exists).
 // Shapes outside the constraints below fall back to the general register-staged GEMM (gemm.hip).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -45,17 +46,20 @@ __device__ __forceinline__ f32x4 mma(bf16x8 a, bf16x8 b, f32x4 c) {
 constexpr int NSLOT = 3;
 
 // =================================================================================================================
-// forward: tile 128 rows x BN columns, stage = 64 fp32 k of X (256 B rows) + 64 bf16 k of W (128 B rows)
+// forward: tile BM rows x 128 columns, stage = 64 fp32 k of X (256 B rows) + 64 bf16 k of W (128 B rows).
+// BM / 64 x 2 waves, each owning a 64 x 64 sub-tile.  NS ring slots, NS - 1 stages in flight.
 // =================================================================================================================
-template <int BN>
+template <int BM, int NS>
 struct FwdCfg {
-    static constexpr int BM = 128, BK = 64;
-    static constexpr int A_BYTES = BM * BK * 4;          // 32 KiB
-    static constexpr int B_BYTES = BN * BK * 2;          // 16 KiB (BN = 128)
+    static constexpr int BN = 128, BK = 64;
+    static constexpr int NW = BM / 64 * 2;               // waves per block
+    static constexpr int A_BYTES = BM * BK * 4;
+    static constexpr int B_BYTES = BN * BK * 2;          // 16 KiB
     static constexpr int STAGE = A_BYTES + B_BYTES;
-    static constexpr int A_DMA = A_BYTES / 1024 / 4;     // wave-instructions per wave per stage
-    static constexpr int B_DMA = B_BYTES / 1024 / 4;
+    static constexpr int A_DMA = A_BYTES / 1024 / NW;    // wave-instructions per wave per stage
+    static constexpr int B_DMA = B_BYTES / 1024 / NW;
     static constexpr int PER_STAGE = A_DMA + B_DMA;
+    static_assert(A_DMA * NW * 1024 == A_BYTES && B_DMA * NW * 1024 == B_BYTES, "stage must split evenly over the waves");
 };
 
 struct EmbFwdArgs {
@@ -63,10 +67,10 @@ struct EmbFwdArgs {
     int M, K, E;
 };
 
-template <int BN>
+template <int BM, int NS>
 __device__ __forceinline__ void fwd_issue(const EmbFwdArgs &a, unsigned char *slot, int m0, int n0, int k0, int wave,
                                           int lane) {
-    using C = FwdCfg<BN>;
+    using C = FwdCfg<BM, NS>;
     // A: 4 rows (256 B each) per wave-instruction; chunk c of row r lands in slot c ^ (2 * (r & 7))
 #pragma unroll
     for (int i = 0; i < C::A_DMA; ++i) {
@@ -87,14 +91,15 @@ __device__ __forceinline__ void fwd_issue(const EmbFwdArgs &a, unsigned char *sl
     }
 }
 
-template <int BN>
-__global__ __launch_bounds__(256) void embed_fwd_dma(const EmbFwdArgs a) {
-    using C = FwdCfg<BN>;
+template <int BM, int NS>
+__global__ __launch_bounds__(BM / 64 * 2 * 64) void embed_fwd_dma(const EmbFwdArgs a) {
+    using C = FwdCfg<BM, NS>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int TM = 4, TN = BN / 32;           // wave tile 64 x BN/2 (waves 2 x 2)
+    constexpr int TM = 4, TN = 4, BN = C::BN, NT = C::NW * 64;
+    constexpr int D = NS - 1;                      // prefetch distance (stages in flight)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * C::BM, n0 = blockIdx.x * BN;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     const int nst = a.K / C::BK;
     const int g = lane >> 4, cq = lane & 15;
 
@@ -104,15 +109,16 @@ __global__ __launch_bounds__(256) void embed_fwd_dma(const EmbFwdArgs a) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    fwd_issue<BN>(a, smem, m0, n0, 0, wave, lane);
-    if (nst > 1) fwd_issue<BN>(a, smem + C::STAGE, m0, n0, C::BK, wave, lane);
+#pragma unroll
+    for (int s = 0; s < D; ++s)
+        if (s < nst) fwd_issue<BM, NS>(a, smem + s * C::STAGE, m0, n0, s * C::BK, wave, lane);
     for (int s = 0; s < nst; ++s) {
-        // stage s has landed once at most one younger stage of this wave's DMAs is still in flight
-        if (s + 1 < nst) wait_vm<C::PER_STAGE>();
+        // stage s has landed once only the younger in-flight stages of this wave's DMAs remain outstanding
+        if (s + D - 1 < nst) wait_vm<C::PER_STAGE * (D - 1)>();
         else wait_vm<0>();
-        barrier();      // everyone's share of stage s landed; everyone finished reading slot (s+2)%3 (= stage s-1)
-        if (s + 2 < nst) fwd_issue<BN>(a, smem + ((s + 2) % NSLOT) * C::STAGE, m0, n0, (s + 2) * C::BK, wave, lane);
-        const unsigned char *As = smem + (s % NSLOT) * C::STAGE, *Bs = As + C::A_BYTES;
+        barrier();      // everyone's share of stage s landed; everyone finished reading the slot of stage s-1
+        if (s + D < nst) fwd_issue<BM, NS>(a, smem + ((s + D) % NS) * C::STAGE, m0, n0, (s + D) * C::BK, wave, lane);
+        const unsigned char *As = smem + (s % NS) * C::STAGE, *Bs = As + C::A_BYTES;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             bf16x8 af[TM], bf[TN];
@@ -125,7 +131,7 @@ __global__ __launch_bounds__(256) void embed_fwd_dma(const EmbFwdArgs a) {
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                const int n = wn * (BN / 2) + j * 16 + cq;
+                const int n = wn * 64 + j * 16 + cq;
                 const int c = (kk * 4 + g) ^ ((n >> 1) & 7);
                 bf[j] = *reinterpret_cast<const bf16x8 *>(Bs + n * 128 + c * 16);
             }
@@ -135,24 +141,24 @@ __global__ __launch_bounds__(256) void embed_fwd_dma(const EmbFwdArgs a) {
                 for (int j = 0; j < TN; ++j) acc[i][j] = mma(af[i], bf[j], acc[i][j]);
         }
     }
-    // epilogue: + bias, through LDS as fp32 (64 rows per pass), 16-byte bf16 stores
+    // epilogue: + bias, through LDS as fp32 (64 rows per pass = the rows of one wave row), 16-byte bf16 stores
     constexpr int LDC = BN + 4;
     float *Cs = reinterpret_cast<float *>(smem);
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < BM / 64; ++h) {
         barrier();
         if (wm == h) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    const int lc = wn * (BN / 2) + j * 16 + cq;
+                    const int lc = wn * 64 + j * 16 + cq;
                     const float bv = a.bias ? a.bias[n0 + lc] : 0.f;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) Cs[(i * 16 + 4 * g + r) * LDC + lc] = acc[i][j][r] + bv;
                 }
         }
         barrier();
-        for (int c = tid; c < 64 * (BN / 8); c += 256) {
+        for (int c = tid; c < 64 * (BN / 8); c += NT) {
             const int lr = c / (BN / 8), lc = (c % (BN / 8)) * 8;
             const int row = m0 + h * 64 + lr;
             if (row < a.M) {
@@ -166,18 +172,23 @@ __global__ __launch_bounds__(256) void embed_fwd_dma(const EmbFwdArgs a) {
 }
 
 // =================================================================================================================
-// wgrad: tile BE rows (e) x 128 columns (k), stage = 64 rows m of dY (E bf16 = 2E B rows) + 64 rows of X (512 B)
+// wgrad: tile 128 rows (e) x BKC columns (k of X), stage = 64 reduction rows m of dY (256 B rows) + of X (4*BKC B rows).
+// 2 x BKC/64 waves, each a 64 x 64 sub-tile.  NS ring slots, NS - 1 stages in flight.
 // =================================================================================================================
-template <int BE>
+template <int BKC, int NS>
 struct WgCfg {
-    static constexpr int BK = 128, BMR = 64;             // 128 output columns, 64 reduction rows per stage
-    static constexpr int A_BYTES = BMR * BE * 2;         // 16 KiB (BE = 128)
-    static constexpr int B_BYTES = BMR * BK * 4;         // 32 KiB
+    static constexpr int BE = 128, BMR = 64;
+    static constexpr int NW = 2 * (BKC / 64);
+    static constexpr int A_BYTES = BMR * BE * 2;         // 16 KiB
+    static constexpr int B_ROW = BKC * 4;                // bytes per X row in the tile
+    static constexpr int B_BYTES = BMR * B_ROW;          // 32 / 64 KiB
     static constexpr int STAGE = A_BYTES + B_BYTES;
-    static constexpr int A_DMA = A_BYTES / 1024 / 4;
-    static constexpr int B_DMA = B_BYTES / 1024 / 4;
+    static constexpr int A_DMA = A_BYTES / 1024 / NW;
+    static constexpr int B_DMA = B_BYTES / 1024 / NW;
     static constexpr int PER_STAGE = A_DMA + B_DMA;
     static constexpr int A_CH = BE / 8;                  // 16-byte chunks per dY row
+    static constexpr int B_CH = B_ROW / 16;              // 16-byte chunks per X row (32 / 64)
+    static_assert(A_DMA * NW * 1024 == A_BYTES && B_DMA * NW * 1024 == B_BYTES, "stage must split evenly over the waves");
 };
 
 struct EmbWgArgs {
@@ -185,38 +196,39 @@ struct EmbWgArgs {
     int M, K, E, rows_per_split;
 };
 
-template <int BE>
+template <int BKC, int NS>
 __device__ __forceinline__ void wg_issue(const EmbWgArgs &a, unsigned char *slot, int e0, int k0, int mrow, int mend,
                                          int wave, int lane) {
-    using C = WgCfg<BE>;
-    constexpr int RPI = 1024 / (BE * 2);               // dY rows per wave-instruction (4 at BE = 128)
+    using C = WgCfg<BKC, NS>;
 #pragma unroll
-    for (int i = 0; i < C::A_DMA; ++i) {
+    for (int i = 0; i < C::A_DMA; ++i) {              // dY: 4 rows of 256 B per wave-instruction
         const int inst = wave * C::A_DMA + i;
-        const int r = inst * RPI + lane / C::A_CH, s = lane % C::A_CH;
-        const int c = s ^ ((2 * (r & 7)) & (C::A_CH - 1));
+        const int r = inst * 4 + (lane >> 4), s = lane & 15;
+        const int c = s ^ (2 * (r & 7));
         const int gm = min(mrow + r, mend - 1);
         dma16(a.dY + (int64_t)gm * a.E + e0 + c * 8, slot + inst * 1024);
     }
     unsigned char *bs = slot + C::A_BYTES;
+    constexpr int RPI = 64 / C::B_CH == 0 ? 1 : 1024 / C::B_ROW;    // X rows per wave-instruction (2 or 1)
 #pragma unroll
     for (int i = 0; i < C::B_DMA; ++i) {
         const int inst = wave * C::B_DMA + i;
-        const int r = inst * 2 + (lane >> 5), s = lane & 31;
+        const int r = inst * RPI + lane / C::B_CH, s = lane % C::B_CH;
         const int c = s ^ (((r >> 3) & 1) << 2);          // rows 8 apart land 16 floats (= 16 banks) apart
         const int gm = min(mrow + r, mend - 1);
         dma16(a.X + (int64_t)gm * a.K + k0 + c * 4, bs + inst * 1024);
     }
 }
 
-template <int BE>
-__global__ __launch_bounds__(256) void embed_wgrad_dma(const EmbWgArgs a) {
-    using C = WgCfg<BE>;
+template <int BKC, int NS>
+__global__ __launch_bounds__(2 * (BKC / 64) * 64) void embed_wgrad_dma(const EmbWgArgs a) {
+    using C = WgCfg<BKC, NS>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int TM = BE / 32, TN = 4;            // wave tile BE/2 (e) x 64 (k)
+    constexpr int TM = 4, TN = 4, D = NS - 1;
+    constexpr int WN = BKC / 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int k0 = blockIdx.x * C::BK, e0 = blockIdx.y * BE;
+    const int wm = wave / WN, wn = wave % WN;
+    const int k0 = blockIdx.x * BKC, e0 = blockIdx.y * C::BE;
     const int mb = blockIdx.z * a.rows_per_split, me = min(a.M, mb + a.rows_per_split);
     const int nst = (me - mb + C::BMR - 1) / C::BMR;
     const int g = lane >> 4, cq = lane & 15, q = cq >> 2, p = cq & 3;
@@ -227,14 +239,15 @@ __global__ __launch_bounds__(256) void embed_wgrad_dma(const EmbWgArgs a) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    if (nst > 0) wg_issue<BE>(a, smem, e0, k0, mb, me, wave, lane);
-    if (nst > 1) wg_issue<BE>(a, smem + C::STAGE, e0, k0, mb + C::BMR, me, wave, lane);
+#pragma unroll
+    for (int s = 0; s < D; ++s)
+        if (s < nst) wg_issue<BKC, NS>(a, smem + s * C::STAGE, e0, k0, mb + s * C::BMR, me, wave, lane);
     for (int s = 0; s < nst; ++s) {
-        if (s + 1 < nst) wait_vm<C::PER_STAGE>();
+        if (s + D - 1 < nst) wait_vm<C::PER_STAGE * (D - 1)>();
         else wait_vm<0>();
         barrier();
-        if (s + 2 < nst) wg_issue<BE>(a, smem + ((s + 2) % NSLOT) * C::STAGE, e0, k0, mb + (s + 2) * C::BMR, me, wave, lane);
-        const unsigned char *As = smem + (s % NSLOT) * C::STAGE, *Bs = As + C::A_BYTES;
+        if (s + D < nst) wg_issue<BKC, NS>(a, smem + ((s + D) % NS) * C::STAGE, e0, k0, mb + (s + D) * C::BMR, me, wave, lane);
+        const unsigned char *As = smem + (s % NS) * C::STAGE, *Bs = As + C::A_BYTES;
         const int valid = min(C::BMR, me - (mb + s * C::BMR));     // rows of this stage inside the split
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -244,19 +257,19 @@ __global__ __launch_bounds__(256) void embed_wgrad_dma(const EmbWgArgs a) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 // A[e][m] from the natural [m][e] image: transposed read of 4 rows x 16 e (two per fragment)
-                const int ecol = wm * (BE / 2) + i * 16 + 4 * p;           // this lane supplies e columns ecol..ecol+3
+                const int ecol = wm * 64 + i * 16 + 4 * p;                 // this lane supplies e columns ecol..ecol+3
                 s16x4 lo, hi;
                 {
                     const int r = mr + q;
-                    const int c = (ecol >> 3) ^ ((2 * (r & 7)) & (C::A_CH - 1));
+                    const int c = (ecol >> 3) ^ (2 * (r & 7));
                     lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) s16x4 *)(As + r * (BE * 2) + c * 16 + (ecol & 7) * 2));
+                        (__attribute__((address_space(3))) s16x4 *)(As + r * 256 + c * 16 + (ecol & 7) * 2));
                 }
                 {
                     const int r = mr + 4 + q;
-                    const int c = (ecol >> 3) ^ ((2 * (r & 7)) & (C::A_CH - 1));
+                    const int c = (ecol >> 3) ^ (2 * (r & 7));
                     hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) s16x4 *)(As + r * (BE * 2) + c * 16 + (ecol & 7) * 2));
+                        (__attribute__((address_space(3))) s16x4 *)(As + r * 256 + c * 16 + (ecol & 7) * 2));
                 }
                 struct { s16x4 a, b; } pr = {lo, hi};
                 af[i] = __builtin_bit_cast(bf16x8, pr);
@@ -269,7 +282,7 @@ __global__ __launch_bounds__(256) void embed_wgrad_dma(const EmbWgArgs a) {
                 for (int t = 0; t < 8; ++t) {
                     const int r = mr + t;
                     const int c = (n >> 2) ^ (((r >> 3) & 1) << 2);
-                    const float x = *reinterpret_cast<const float *>(Bs + r * 512 + c * 16 + (n & 3) * 4);
+                    const float x = *reinterpret_cast<const float *>(Bs + r * C::B_ROW + c * 16 + (n & 3) * 4);
                     v[t] = r < valid ? x : 0.f;                            // rows past the split end repeat the last row
                 }
                 bf[j] = cvt8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]));
@@ -288,18 +301,35 @@ __global__ __launch_bounds__(256) void embed_wgrad_dma(const EmbWgArgs a) {
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int e = e0 + wm * (BE / 2) + i * 16 + 4 * g + r;
+                const int e = e0 + wm * 64 + i * 16 + 4 * g + r;
                 out[(int64_t)e * a.K + k0 + wn * 64 + j * 16 + cq] = acc[i][j][r];
             }
 }
 
+bool wg_wide(int K) {
+    static const int variant = getenv("MIVIT_EMBED_WGRAD_VARIANT") ? atoi(getenv("MIVIT_EMBED_WGRAD_VARIANT")) : 1;
+    return variant == 1 && K % 256 == 0;
+}
+
 int wg_splits(int M, int K, int E) {
-    const long tiles = (long)(K / 128) * (E / 128 > 0 ? E / 128 : 1);
+    const long tiles = (long)(K / (wg_wide(K) ? 256 : 128)) * (E / 128 > 0 ? E / 128 : 1);
     long s = (256 + tiles - 1) / tiles;            // ~1 block per CU (one block owns a CU's LDS)
     const long maxs = (M + 511) / 512;
     if (s > maxs) s = maxs;
     if (s < 1) s = 1;
     return (int)s;
+}
+
+template <int BM, int NS>
+int fwd_dma_launch(const EmbFwdArgs &a, hipStream_t s) {
+    using C = FwdCfg<BM, NS>;
+    const size_t bytes = (size_t)NS * C::STAGE;
+    auto kern = embed_fwd_dma<BM, NS>;
+    MIVIT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    ProfScope prof(s);
+    hipLaunchKernelGGL(kern, dim3(a.E / 128, ceil_div(a.M, BM)), dim3(C::NW * 64), bytes, s, a);
+    MIVIT_LAUNCH_CHECK();
+    return 0;
 }
 
 }  // namespace
@@ -312,38 +342,38 @@ int launch_embed_fwd_dma(const float *X, const void *W_bf16, const float *bias, 
                          hipStream_t s) {
     MIVIT_CHECK(((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(W_bf16) | reinterpret_cast<uintptr_t>(Y)) & 15) == 0,
                 "embed_fwd_dma: operands must be 16-byte aligned");
-    using C = FwdCfg<128>;
     EmbFwdArgs a = {X, static_cast<const bf16 *>(W_bf16), bias, static_cast<bf16 *>(Y), M, K, E};
-    const size_t bytes = (size_t)NSLOT * C::STAGE;
-    auto kern = embed_fwd_dma<128>;
-    MIVIT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    ProfScope prof(s);
-    hipLaunchKernelGGL(kern, dim3(E / 128, ceil_div(M, C::BM)), dim3(256), bytes, s, a);
-    MIVIT_LAUNCH_CHECK();
-    return 0;
+    static const int variant = getenv("MIVIT_EMBED_FWD_VARIANT") ? atoi(getenv("MIVIT_EMBED_FWD_VARIANT")) : 0;
+    if (variant == 2) return fwd_dma_launch<128, 3>(a, s);
+    return fwd_dma_launch<256, 2>(a, s);     // 256-row tiles: the L2-resident W tile is re-streamed half as often
 }
 
 size_t embed_wgrad_dma_ws_bytes(int M, int K, int E) { return (size_t)wg_splits(M, K, E) * E * K * sizeof(float); }
+
+template <int BKC, int NS>
+static int wg_dma_launch(EmbWgArgs a, int nz, hipStream_t s) {
+    using C = WgCfg<BKC, NS>;
+    const size_t bytes = (size_t)NS * C::STAGE;
+    auto kern = embed_wgrad_dma<BKC, NS>;
+    MIVIT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    ProfScope prof(s);
+    hipLaunchKernelGGL(kern, dim3(a.K / BKC, a.E / 128, nz), dim3(C::NW * 64), bytes, s, a);
+    MIVIT_LAUNCH_CHECK();
+    return 0;
+}
 
 int launch_embed_wgrad_dma(const void *dY_bf16, const float *X, float *dW, int M, int K, int E, void *ws, size_t ws_bytes,
                            hipStream_t s) {
     MIVIT_CHECK(((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(dY_bf16) | reinterpret_cast<uintptr_t>(ws)) & 15) == 0,
                 "embed_wgrad_dma: operands must be 16-byte aligned");
-    using C = WgCfg<128>;
     const int splits = wg_splits(M, K, E);
     MIVIT_CHECK(ws_bytes >= embed_wgrad_dma_ws_bytes(M, K, E), "embed_wgrad_dma: workspace too small");
     int rps = ceil_div(M, splits);
-    rps = (rps + C::BMR - 1) / C::BMR * C::BMR;
+    rps = (rps + 63) / 64 * 64;
     const int nz = ceil_div(M, rps);
     EmbWgArgs a = {static_cast<const bf16 *>(dY_bf16), X, static_cast<float *>(ws), M, K, E, rps};
-    const size_t bytes = (size_t)NSLOT * C::STAGE;
-    auto kern = embed_wgrad_dma<128>;
-    MIVIT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    {
-        ProfScope prof(s);
-        hipLaunchKernelGGL(kern, dim3(K / C::BK, E / 128, nz), dim3(256), bytes, s, a);
-        MIVIT_LAUNCH_CHECK();
-    }
+    const int rc = wg_wide(K) ? wg_dma_launch<256, 2>(a, nz, s) : wg_dma_launch<128, 3>(a, nz, s);
+    if (rc) return rc;
     return launch_slab_reduce(static_cast<const float *>(ws), nz, (int64_t)E * K, dW, 0, s);
 }
 
