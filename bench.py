@@ -90,7 +90,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch-per-gpu", type=int, default=int(os.environ.get("MIVIT_BENCH_BATCH", 2048)))
+    ap.add_argument("--batch-per-gpu", type=int, default=int(os.environ.get("MIVIT_BENCH_BATCH", 4096)))
     ap.add_argument("--precision", default=os.environ.get("MIVIT_BENCH_PRECISION", "bf16"), choices=["bf16", "fp32"])
     ap.add_argument("--resident-batches", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -221,6 +221,17 @@ def main():
                 roof = {"kernel": dominant, "bound": "mfma", "achieved": round(ach, 2), "peak": pk, "unit": "TFLOP/s",
                         "frac": round(ach / pk, 4), "traffic": None, "launch_ms": round(k_ms, 4),
                         "launches_timed": cnt.value}
+        # HBM traffic of the dominant kernel from the PMC passes committed under profiles/ (rocprofv3 cannot run
+        # inside this process): used only when it was collected for this kernel at this per-GPU batch
+        if roof is not None:
+            try:
+                with open(os.path.join(ROOT, "profiles", "r01_pmc_embed.json")) as fh:
+                    pmc = json.load(fh)
+                if pmc.get("per_gpu_batch") == Bg and dominant in pmc["kernels"] and args.precision == "bf16":
+                    roof["traffic"] = pmc["kernels"][dominant]["hbm_bytes_per_launch"]
+                    roof["traffic_source"] = "profiles/r01_pmc_embed.json"
+            except (OSError, ValueError, KeyError):
+                pass
         line = {
             "metric": "training image-sequences/sec", "value": round(seqs / dt, 1), "unit": "sequences/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
