@@ -240,6 +240,19 @@ size_t embed_wgrad_dma_ws_bytes(int M, int K, int E);
 int launch_embed_wgrad_dma(const void *dY_bf16, const float *X, float *dW, int M, int K, int E, void *ws, size_t ws_bytes,
                            hipStream_t s);
 
+// bf16 row-stream GEMM with resident weights (rowstream.hip)
+bool rowstream_supported(int M, int N, int K, bool dgrad, int64_t lda, int64_t ldw, const void *A, const void *W);
+int launch_rowstream(bool dgrad, const void *A, int64_t lda, const void *W_bf16, int64_t ldw, int M, int N, int K,
+                     const float *bias, int act, const void *dact, int64_t ldd, int dact_kind, const void *resid,
+                     int64_t ldr, void *Cout, int64_t ldc, void *C2, const float *gamma, const float *beta, void *Y,
+                     int64_t ldy, float *mean, float *rstd, hipStream_t s);
+
+// bf16 LDS-DMA weight gradient of the layer projections (wgrad_dma.hip)
+bool wgrad_dma_supported(int M, int N, int K, int64_t lddy, int64_t ldx, const void *dy, const void *x);
+size_t wgrad_dma_ws_bytes(int M, int N, int K);
+int launch_wgrad_dma(const void *dy, int64_t lddy, const void *x, int64_t ldx, int M, int N, int K, float *dW, void *ws,
+                     size_t ws_bytes, hipStream_t s);
+
 // small elementwise / reduction helpers (misc.hip)
 // out[n] (+)= sum_p part[p*n_stride + n]   (deterministic slab reduce)
 int launch_slab_reduce(const float *part, int nparts, int64_t n, float *out, int accumulate, hipStream_t s);

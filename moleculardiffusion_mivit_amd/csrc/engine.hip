@@ -99,7 +99,11 @@ Ws make_ws(const mivit_plan *p, int B, int T, bool bwd) {
         w.dxa = take(M * E * ts); w.dxb = take(M * E * ts);
         w.dF = take(M * F * ts); w.dctx = take(M * E * ts); w.dqkv = take(M * 3 * E * ts);
         size_t wg = 0;
-        auto mx = [&](int m, int n, int k) { size_t b = linear_wgrad_ws_bytes(m, n, k); if (b > wg) wg = b; };
+        auto mx = [&](int m, int n, int k) {
+            size_t b = linear_wgrad_ws_bytes(m, n, k);
+            if (c.dtype == MIVIT_BF16 && n % 128 == 0 && k % 128 == 0 && m >= 256) b += wgrad_dma_ws_bytes(m, n, k);
+            if (b > wg) wg = b;
+        };
         mx((int)M, 3 * E, E); mx((int)M, E, E); mx((int)M, F, E); mx((int)M, E, F);
         if (c.embedding != MIVIT_EMBED_EXTERNAL) {
             mx((int)Mt, E, c.patch_size * c.patch_size);
@@ -127,6 +131,12 @@ inline void *col_ptr(void *p, size_t cols, int dtype) { return static_cast<char 
 
 int lin_fwd(int dtype, const void *x, int x_f32, int64_t ldx, const void *W, const float *b, int M, int N, int K,
             int act, const void *resid, int64_t ldr, void *y, int64_t ldy, void *pre, int y_f32, hipStream_t s) {
+    if (dtype == MIVIT_BF16 && !x_f32 && !y_f32 && rowstream_supported(M, N, K, false, ldx, K, x, W) &&
+        (!resid || ldr % 8 == 0) && ldy % 8 == 0) {
+        prof_set_tag(MIVIT_PROF_LINEAR_FWD);
+        return launch_rowstream(false, x, ldx, W, K, M, N, K, b, act, nullptr, 0, 0, resid, ldr, y, ldy, pre, nullptr,
+                                nullptr, nullptr, 0, nullptr, nullptr, s);
+    }
     LinearFwdArgs a = {};
     a.dtype = dtype; a.x = x; a.x_is_f32 = x_f32 || dtype == MIVIT_F32; a.ldx = ldx; a.W = W;
     a.w_is_bf16 = dtype == MIVIT_BF16; a.bias = b;
@@ -137,6 +147,12 @@ int lin_fwd(int dtype, const void *x, int x_f32, int64_t ldx, const void *W, con
 }
 int lin_dgrad(int dtype, const void *dy, int64_t lddy, const void *W, int M, int N, int K, int act, const void *saved,
               int64_t lds, const void *dres, int64_t lddr, void *dx, int64_t lddx, int dx_f32, hipStream_t s) {
+    if (dtype == MIVIT_BF16 && !dx_f32 && rowstream_supported(M, K, N, true, lddy, K, dy, W) && lddx % 8 == 0 &&
+        (!dres || lddr % 8 == 0) && (act == MIVIT_ACT_NONE || lds % 8 == 0)) {
+        prof_set_tag(MIVIT_PROF_LINEAR_DGRAD);
+        return launch_rowstream(true, dy, lddy, W, K, M, K, N, nullptr, MIVIT_ACT_NONE, act != MIVIT_ACT_NONE ? saved : nullptr,
+                                lds, act, dres, lddr, dx, lddx, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, s);
+    }
     LinearDgradArgs a = {};
     a.dtype = dtype; a.dy = dy; a.dy_is_f32 = dtype == MIVIT_F32; a.lddy = lddy; a.W = W;
     a.w_is_bf16 = dtype == MIVIT_BF16; a.M = M; a.N = N; a.K = K;
@@ -146,12 +162,36 @@ int lin_dgrad(int dtype, const void *dy, int64_t lddy, const void *W, int M, int
 }
 int lin_wgrad(int dtype, const void *dy, int64_t lddy, const void *x, int x_f32, int64_t ldx, int M, int N, int K,
               float *dW, float *db, void *ws, size_t wsb, hipStream_t s) {
+    if (dtype == MIVIT_BF16 && !x_f32 && dW && wgrad_dma_supported(M, N, K, lddy, ldx, dy, x) &&
+        wsb >= wgrad_dma_ws_bytes(M, N, K) + linear_wgrad_ws_bytes(M, N, K)) {
+        prof_set_tag(MIVIT_PROF_LINEAR_WGRAD);
+        RC(launch_wgrad_dma(dy, lddy, x, ldx, M, N, K, dW, ws, wsb, s));
+        if (!db) return 0;
+        dW = nullptr;     // bias gradient only, through the general path below
+    }
     LinearWgradArgs a = {};
     a.dtype = dtype; a.dy = dy; a.dy_is_f32 = dtype == MIVIT_F32; a.lddy = lddy; a.x = x;
     a.x_is_f32 = x_f32 || dtype == MIVIT_F32; a.ldx = ldx; a.M = M; a.N = N; a.K = K; a.dW = dW; a.db = db;
     a.ws = ws; a.ws_bytes = wsb;
     prof_set_tag(x_f32 && K > 1024 ? MIVIT_PROF_EMBED_WGRAD : MIVIT_PROF_LINEAR_WGRAD);
     return launch_linear_wgrad(a, s);
+}
+
+// z = x W^T + b + resid;  y = LayerNorm(z)  (post-norm sub-layer, models.py:100-106): one row-stream launch when the
+// block owns whole rows, otherwise GEMM + LayerNorm kernel.
+int lin_res_ln(int dtype, const void *x, int64_t ldx, const void *W, const float *b, int M, int N, int K, const void *resid,
+               void *z, const float *gamma, const float *beta, void *y, float *mean, float *rstd, hipStream_t s) {
+    if (dtype == MIVIT_BF16 && N == 128 && rowstream_supported(M, N, K, false, ldx, K, x, W)) {
+        prof_set_tag(MIVIT_PROF_LINEAR_FWD);
+        return launch_rowstream(false, x, ldx, W, K, M, N, K, b, MIVIT_ACT_NONE, nullptr, 0, 0, resid, N, z, N, nullptr, gamma,
+                                beta, y, N, mean, rstd, s);
+    }
+    RC(lin_fwd(dtype, x, 0, ldx, W, b, M, N, K, MIVIT_ACT_NONE, resid, N, z, N, nullptr, 0, s));
+    LayerNormFwdArgs n = {};
+    n.dtype = dtype; n.z = z; n.ldz = N; n.gamma = gamma; n.beta = beta; n.M = M; n.E = N; n.y = y; n.ldy = N;
+    n.mean = mean; n.rstd = rstd;
+    prof_set_tag(MIVIT_PROF_LN_FWD);
+    return launch_layernorm_fwd(n, s);
 }
 
 // LayerNorm backward that also produces the bias gradient of the Linear feeding it (column sums of dz).
@@ -362,21 +402,12 @@ extern "C" int mivit_forward(const mivit_plan *plan, const float *params, const 
         RC(lin_fwd(dt, xin, 0, E, WT(lp.qkv_w), P + lp.qkv_b, M, 3 * E, E, MIVIT_ACT_NONE, nullptr, 0, at(ws, b.qkv),
                    3 * E, nullptr, 0, s));
         prof_set_tag(MIVIT_PROF_ATTN_FWD); RC(launch_attention_fwd(dt, at(ws, b.qkv), B, S, H, Dh, at(ws, b.ctx), s));
-        RC(lin_fwd(dt, at(ws, b.ctx), 0, E, WT(lp.out_w), P + lp.out_b, M, E, E, MIVIT_ACT_NONE, xin, E, at(ws, b.z1), E,
-                   nullptr, 0, s));
-        LayerNormFwdArgs n1 = {};
-        n1.dtype = dt; n1.z = at(ws, b.z1); n1.ldz = E; n1.gamma = P + lp.n1_w; n1.beta = P + lp.n1_b; n1.M = M; n1.E = E;
-        n1.y = at(ws, b.x1); n1.ldy = E; n1.mean = static_cast<float *>(at(ws, b.mean1));
-        n1.rstd = static_cast<float *>(at(ws, b.rstd1));
-        prof_set_tag(MIVIT_PROF_LN_FWD); RC(launch_layernorm_fwd(n1, s));
+        RC(lin_res_ln(dt, at(ws, b.ctx), E, WT(lp.out_w), P + lp.out_b, M, E, E, xin, at(ws, b.z1), P + lp.n1_w, P + lp.n1_b,
+                      at(ws, b.x1), static_cast<float *>(at(ws, b.mean1)), static_cast<float *>(at(ws, b.rstd1)), s));
         RC(lin_fwd(dt, at(ws, b.x1), 0, E, WT(lp.fc1_w), P + lp.fc1_b, M, F, E, c.activation, nullptr, 0, at(ws, b.h), F,
                    c.activation == MIVIT_ACT_GELU ? at(ws, b.u) : nullptr, 0, s));
-        RC(lin_fwd(dt, at(ws, b.h), 0, F, WT(lp.fc2_w), P + lp.fc2_b, M, E, F, MIVIT_ACT_NONE, at(ws, b.x1), E,
-                   at(ws, b.z2), E, nullptr, 0, s));
-        LayerNormFwdArgs n2 = n1;
-        n2.z = at(ws, b.z2); n2.gamma = P + lp.n2_w; n2.beta = P + lp.n2_b; n2.y = at(ws, b.x2);
-        n2.mean = static_cast<float *>(at(ws, b.mean2)); n2.rstd = static_cast<float *>(at(ws, b.rstd2));
-        prof_set_tag(MIVIT_PROF_LN_FWD); RC(launch_layernorm_fwd(n2, s));
+        RC(lin_res_ln(dt, at(ws, b.h), F, WT(lp.fc2_w), P + lp.fc2_b, M, E, F, at(ws, b.x1), at(ws, b.z2), P + lp.n2_w, P + lp.n2_b,
+                      at(ws, b.x2), static_cast<float *>(at(ws, b.mean2)), static_cast<float *>(at(ws, b.rstd2)), s));
         xin = at(ws, b.x2);
     }
     // 5. final LayerNorm + readout (models.py:141, :351-354).  Only the regression-token row is normalised when it

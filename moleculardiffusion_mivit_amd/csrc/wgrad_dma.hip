@@ -1,0 +1,170 @@
+// Weight gradients of the encoder-layer projections in bf16 mode:  dW[N, K] = dY[M, N]^T . X[M, K]  (M = all tokens).
+// Same streaming structure as the embedding weight gradient (embed.hip): both operands are natural [m][.] bf16 tiles
+// brought in by LDS-DMA into a ring, the contraction over rows m uses ds_read_b64_tr_b16 for BOTH fragments, the
+// reduction is split over row ranges into fp32 slabs that slab_reduce sums in a fixed order (deterministic).
+#include "common.h"
+#include <stdlib.h>
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((address_space(1))) const void gptr_t;
+typedef __attribute__((address_space(3))) void lptr_t;
+
+__device__ __forceinline__ void dma16(const void *g, void *l) {
+    __builtin_amdgcn_global_load_lds((gptr_t *)g, (lptr_t *)l, 16, 0, 0);
+}
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+__device__ __forceinline__ f32x4 mma(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+struct WgArgs {
+    const bf16 *dY; int64_t lddy; const bf16 *X; int64_t ldx; float *slabs;
+    int M, N, K, rows_per_split;
+};
+
+constexpr int BMR = 64, TILE = 128, NS = 3, IMG = BMR * TILE * 2, STAGE = 2 * IMG;   // 16 KiB per image
+constexpr int DMA_PER_WAVE = IMG / 1024 / 4;                                           // per image per wave (4)
+
+// natural [64 rows m][128 cols] bf16 image, 256-byte rows; chunk c of row r lands in slot c ^ (2 * (r & 7))
+__device__ __forceinline__ void issue_img(const bf16 *src, int64_t ld, int col0, int mrow, int mend, unsigned char *img,
+                                          int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < DMA_PER_WAVE; ++i) {
+        const int inst = wave * DMA_PER_WAVE + i;
+        const int r = inst * 4 + (lane >> 4), s = lane & 15;
+        const int c = s ^ (2 * (r & 7));
+        const int gm = min(mrow + r, mend - 1);
+        dma16(src + (int64_t)gm * ld + col0 + c * 8, img + inst * 1024);
+    }
+}
+
+// fragment with k = rows (mr + 0..3 | mr + 4 + 0..3) and lane index = column col0 + (lane & 15)
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char *img, int mr, int colbase, int q, int p, int valid) {
+    const int col = colbase + 4 * p;
+    s16x4 lo, hi;
+    {
+        const int r = mr + q;
+        const int c = (col >> 3) ^ (2 * (r & 7));
+        lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4 *)(img + r * 256 + c * 16 + (col & 7) * 2));
+    }
+    {
+        const int r = mr + 4 + q;
+        const int c = (col >> 3) ^ (2 * (r & 7));
+        hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4 *)(img + r * 256 + c * 16 + (col & 7) * 2));
+    }
+    // rows past the end of the split repeat the last row (clamped DMA): zero those k slots (the lane RECEIVES rows
+    // mr + 0..3 in lo[0..3] and mr + 4..7 in hi[0..3], whatever address it supplied)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (mr + e >= valid) lo[e] = 0;
+        if (mr + 4 + e >= valid) hi[e] = 0;
+    }
+    struct { s16x4 a, b; } pr = {lo, hi};
+    return __builtin_bit_cast(bf16x8, pr);
+}
+
+__global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int TM = 4, TN = 4, D = NS - 1, PER_STAGE = 2 * DMA_PER_WAVE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int k0 = blockIdx.x * TILE, n0 = blockIdx.y * TILE;
+    const int mb = blockIdx.z * a.rows_per_split, me = min(a.M, mb + a.rows_per_split);
+    const int nst = (me - mb + BMR - 1) / BMR;
+    const int g = lane >> 4, cq = lane & 15, q = cq >> 2, p = cq & 3;
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int s = 0; s < D; ++s)
+        if (s < nst) {
+            issue_img(a.dY, a.lddy, n0, mb + s * BMR, me, smem + s * STAGE, wave, lane);
+            issue_img(a.X, a.ldx, k0, mb + s * BMR, me, smem + s * STAGE + IMG, wave, lane);
+        }
+    for (int s = 0; s < nst; ++s) {
+        if (s + D - 1 < nst) wait_vm<PER_STAGE *(D - 1)>();
+        else wait_vm<0>();
+        barrier();
+        if (s + D < nst) {
+            unsigned char *slot = smem + ((s + D) % NS) * STAGE;
+            issue_img(a.dY, a.lddy, n0, mb + (s + D) * BMR, me, slot, wave, lane);
+            issue_img(a.X, a.ldx, k0, mb + (s + D) * BMR, me, slot + IMG, wave, lane);
+        }
+        const unsigned char *As = smem + (s % NS) * STAGE, *Bs = As + IMG;
+        const int valid = min(BMR, me - (mb + s * BMR));
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int mr = kk * 32 + 8 * g;
+            bf16x8 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = tr_frag(As, mr, wm * 64 + i * 16, q, p, valid);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = tr_frag(Bs, mr, wn * 64 + j * 16, q, p, BMR);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = mma(af[i], bf[j], acc[i][j]);
+        }
+    }
+    float *out = a.slabs + (int64_t)blockIdx.z * a.N * a.K;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + wm * 64 + i * 16 + 4 * g + r;
+                out[(int64_t)n * a.K + k0 + wn * 64 + j * 16 + cq] = acc[i][j][r];
+            }
+}
+
+int dma_splits(int M, int N, int K) {
+    const long tiles = (long)(N / TILE) * (K / TILE);
+    long s = (512 + tiles - 1) / tiles;          // 96 KiB of LDS per block: one resident block per CU, two rounds
+    const long maxs = (M + 511) / 512;
+    if (s > maxs) s = maxs;
+    return s < 1 ? 1 : (int)s;
+}
+
+}  // namespace
+
+bool wgrad_dma_supported(int M, int N, int K, int64_t lddy, int64_t ldx, const void *dy, const void *x) {
+    static const bool off = getenv("MIVIT_NO_WGRAD_DMA") != nullptr;
+    return !off && N % TILE == 0 && K % TILE == 0 && M >= 256 && lddy % 8 == 0 && ldx % 8 == 0 &&
+           ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(x)) & 15) == 0;
+}
+
+size_t wgrad_dma_ws_bytes(int M, int N, int K) { return (size_t)dma_splits(M, N, K) * N * K * sizeof(float); }
+
+int launch_wgrad_dma(const void *dy, int64_t lddy, const void *x, int64_t ldx, int M, int N, int K, float *dW,
+                     void *ws, size_t ws_bytes, hipStream_t s) {
+    MIVIT_CHECK(ws_bytes >= wgrad_dma_ws_bytes(M, N, K), "wgrad_dma: workspace too small");
+    const int splits = dma_splits(M, N, K);
+    int rps = ceil_div(M, splits);
+    rps = (rps + BMR - 1) / BMR * BMR;
+    const int nz = ceil_div(M, rps);
+    WgArgs a = {static_cast<const bf16 *>(dy), lddy, static_cast<const bf16 *>(x), ldx, static_cast<float *>(ws), M, N, K, rps};
+    const size_t bytes = (size_t)NS * STAGE;
+    MIVIT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wgrad_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    {
+        ProfScope prof(s);
+        hipLaunchKernelGGL(wgrad_dma_kernel, dim3(K / TILE, N / TILE, nz), dim3(256), bytes, s, a);
+        MIVIT_LAUNCH_CHECK();
+    }
+    return launch_slab_reduce(static_cast<const float *>(ws), nz, (int64_t)N * K, dW, 0, s);
+}
