@@ -24,7 +24,10 @@ typedef __attribute__((address_space(3))) void lptr_t;
 __device__ __forceinline__ void dma16(const void *g, void *l) {
     __builtin_amdgcn_global_load_lds((gptr_t *)g, (lptr_t *)l, 16, 0, 0);
 }
-__device__ __forceinline__ void wait_all_vm() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
 __device__ __forceinline__ void barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -46,24 +49,30 @@ struct RsArgs {
     bf16 *Y; int64_t ldy; float *mean, *rstd;
 };
 
-constexpr int BM = 64, BN = 128, NT = 256;
+constexpr int BM = 64, BN = 128, NW = 8, NT = NW * 64;
+constexpr int E_BYTES = BM * BN * 2;                         // optional epilogue-operand tile (residual or saved act.)
 
-template <int K, bool DGRAD>
+template <int K, bool DGRAD, bool HAS_E>
 struct RsCfg {
     static constexpr int RB = 2 * K;                         // bytes per A row (and per W row in forward)
-    static constexpr int A_BYTES = BM * RB;                  // one ring slot
+    static constexpr int A_BYTES = BM * RB;
+    static constexpr int SLOT = A_BYTES + (HAS_E ? E_BYTES : 0);
     static constexpr int W_ROWS = DGRAD ? K : BN;
     static constexpr int W_RB = DGRAD ? BN * 2 : RB;
     static constexpr int W_BYTES = W_ROWS * W_RB;
-    static constexpr int LDS = W_BYTES + 2 * A_BYTES;
-    static constexpr int A_DMA = A_BYTES / 1024 / 4;         // wave-instructions per wave per tile
-    static constexpr int W_DMA = W_BYTES / 1024 / 4;
-    static_assert(A_BYTES >= 32 * BN * 4, "fp32 staging of 32 rows must fit in one ring slot");
+    static constexpr int NS = (W_BYTES + 3 * SLOT <= 160 * 1024) ? 3 : 2;     // ring slots (NS - 1 tiles in flight)
+    static constexpr int LDS = W_BYTES + NS * SLOT;
+    static constexpr int A_DMA = A_BYTES / 1024 / NW;        // wave-instructions per wave per tile
+    static constexpr int E_DMA = HAS_E ? E_BYTES / 1024 / NW : 0;
+    static constexpr int W_DMA = W_BYTES / 1024 / NW;
+    static constexpr int PER_TILE = A_DMA + E_DMA;
+    static_assert(A_BYTES >= 32 * BN * 4, "fp32 staging of 32 rows must fit in the A part of a ring slot");
+    static_assert(LDS <= 160 * 1024, "LDS budget");
 };
 
-template <int K, bool DGRAD>
+template <int K, bool DGRAD, bool HAS_E>
 __device__ __forceinline__ void issue_w(const RsArgs &a, unsigned char *wimg, int n0, int wave, int lane) {
-    using C = RsCfg<K, DGRAD>;
+    using C = RsCfg<K, DGRAD, HAS_E>;
     constexpr int CH = C::W_RB / 16, RPI = 64 / CH;          // chunks per row, rows per wave-instruction
 #pragma unroll
     for (int i = 0; i < C::W_DMA; ++i) {
@@ -80,9 +89,11 @@ __device__ __forceinline__ void issue_w(const RsArgs &a, unsigned char *wimg, in
     }
 }
 
-template <int K, bool DGRAD>
-__device__ __forceinline__ void issue_a(const RsArgs &a, unsigned char *slot, int m0, int wave, int lane) {
-    using C = RsCfg<K, DGRAD>;
+// one tile = 64 rows of A (swizzled) [+ the 64 x 128 epilogue-operand tile, linear]
+template <int K, bool DGRAD, bool HAS_E>
+__device__ __forceinline__ void issue_tile(const RsArgs &a, const bf16 *E, int64_t lde, unsigned char *slot, int m0, int n0,
+                                           int wave, int lane) {
+    using C = RsCfg<K, DGRAD, HAS_E>;
     constexpr int CH = C::RB / 16, RPI = 64 / CH;
 #pragma unroll
     for (int i = 0; i < C::A_DMA; ++i) {
@@ -92,33 +103,56 @@ __device__ __forceinline__ void issue_a(const RsArgs &a, unsigned char *slot, in
         const int gr = min(m0 + r, a.M - 1);
         dma16(a.A + (int64_t)gr * a.lda + c * 8, slot + inst * 1024);
     }
+    if (HAS_E) {
+        unsigned char *es = slot + C::A_BYTES;
+#pragma unroll
+        for (int i = 0; i < C::E_DMA; ++i) {
+            const int inst = wave * C::E_DMA + i;
+            const int r = inst * 4 + (lane >> 4), s = lane & 15;
+            const int gr = min(m0 + r, a.M - 1);
+            dma16(E + (int64_t)gr * lde + n0 + s * 8, es + inst * 1024);
+        }
+    }
 }
 
-template <int K, bool DGRAD, bool LN>
-__global__ __launch_bounds__(256) void rowstream_kernel(const RsArgs a) {
-    using C = RsCfg<K, DGRAD>;
+// E_KIND: 0 none, 1 residual add (forward), 2 activation-derivative multiply (dgrad), 3 residual add of a gradient
+template <int K, bool DGRAD, bool LN, int E_KIND>
+__global__ __launch_bounds__(NT) void rowstream_kernel(const RsArgs a) {
+    constexpr bool HAS_E = E_KIND != 0;
+    using C = RsCfg<K, DGRAD, HAS_E>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int TM = 2, TN = 4, KS = K / 32;               // wave tile 32 x 64 (waves 2 x 2)
+    constexpr int TM = 2, TN = 2, KS = K / 32, D = C::NS - 1;    // wave tile 32 x 32 (waves 2 x 4)
     unsigned char *Wimg = smem, *ring = smem + C::W_BYTES;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave >> 2, wn = wave & 3;
     const int g = lane >> 4, cq = lane & 15, q = cq >> 2, p = cq & 3;
     const int n0 = blockIdx.x * BN;
     const int ntm = (a.M + BM - 1) / BM;
+    const int stride = gridDim.y;
     int mt = blockIdx.y;
     if (mt >= ntm) return;
+    const bf16 *E = E_KIND == 2 ? a.dact : a.resid;
+    const int64_t lde = E_KIND == 2 ? a.ldd : a.ldr;
 
-    issue_w<K, DGRAD>(a, Wimg, n0, wave, lane);
-    issue_a<K, DGRAD>(a, ring, mt * BM, wave, lane);
-    const bool vec_ok = (a.ldc % 8 == 0) && (!a.resid || a.ldr % 8 == 0) && (!a.dact || a.ldd % 8 == 0) &&
-                        (!LN || a.ldy % 8 == 0);
+    issue_w<K, DGRAD, HAS_E>(a, Wimg, n0, wave, lane);
+#pragma unroll
+    for (int s = 0; s < D; ++s)
+        if (mt + s * stride < ntm) issue_tile<K, DGRAD, HAS_E>(a, E, lde, ring + s * C::SLOT, (mt + s * stride) * BM, n0, wave, lane);
 
-    for (int t = 0; mt < ntm; mt += gridDim.y, ++t) {
+    for (int t = 0; mt < ntm; mt += stride, ++t) {
         const int m0 = mt * BM;
-        wait_all_vm();          // this wave's share of tile t (and of W) has landed
-        barrier();              // ... everyone's; and everyone is done with the staging area of tile t-1
-        if (mt + (int)gridDim.y < ntm) issue_a<K, DGRAD>(a, ring + ((t + 1) & 1) * C::A_BYTES, (mt + gridDim.y) * BM, wave, lane);
-        const unsigned char *As = ring + (t & 1) * C::A_BYTES;
+        // Tile t must have landed.  VMEM retires in order; younger than tile t's DMA are only: the D-1 tiles issued
+        // after it (PER_TILE each, when they exist) and the >= 4 store instructions of the last epilogue (every
+        // earlier tile of this block was a full tile, so each wave stored).  The first tile also waits for W.
+        const bool next_in_flight = D > 1 && mt + (D - 1) * stride < ntm;
+        if (t == 0) { if (next_in_flight) wait_vm<(D - 1) * C::PER_TILE>(); else wait_vm<0>(); }
+        else if (D == 1 || next_in_flight) wait_vm<(D - 1) * C::PER_TILE + 4>();
+        else wait_vm<0>();
+        barrier();              // ... everyone's share landed; and everyone is done with the staging area of tile t-1
+        if (mt + D * stride < ntm)
+            issue_tile<K, DGRAD, HAS_E>(a, E, lde, ring + ((t + D) % C::NS) * C::SLOT, (mt + D * stride) * BM, n0, wave, lane);
+        unsigned char *slot = ring + (t % C::NS) * C::SLOT;
+        const unsigned char *As = slot, *Es = slot + C::A_BYTES;
 
         f32x4 acc[TM][TN];
 #pragma unroll
@@ -137,13 +171,13 @@ __global__ __launch_bounds__(256) void rowstream_kernel(const RsArgs a) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 if (!DGRAD) {
-                    const int n = wn * 64 + j * 16 + cq;
+                    const int n = wn * 32 + j * 16 + cq;
                     const int c = (ks * 4 + g) ^ (n & 15);
                     bf[j] = *reinterpret_cast<const bf16x8 *>(Wimg + n * C::W_RB + c * 16);
                 } else {
                     // B[k = red][n]: k slots 0..3 = rows ks*32 + 8g + 0..3, slots 4..7 = + 4..7; this lane supplies
                     // columns ncol .. ncol + 3 of row (+ q)
-                    const int ncol = wn * 64 + j * 16 + 4 * p;
+                    const int ncol = wn * 32 + j * 16 + 4 * p;
                     s16x4 lo, hi;
                     {
                         const int r = ks * 32 + 8 * g + q;
@@ -166,63 +200,40 @@ __global__ __launch_bounds__(256) void rowstream_kernel(const RsArgs a) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = mma(af[i], bf[j], acc[i][j]);
         }
-        // ---- epilogue: 32 rows per pass through fp32 staging in the ring slot just consumed ----
-        float *Cs = reinterpret_cast<float *>(ring + (t & 1) * C::A_BYTES);
+        // ---- epilogue: 32 rows per pass through fp32 staging in the A part of the ring slot just consumed; every
+        //      operand it needs is already in LDS, so it issues stores only ----
+        float *Cs = reinterpret_cast<float *>(slot);
         for (int h = 0; h < 2; ++h) {
-            barrier();          // all waves finished reading the A slot (h = 0) / the previous pass (h = 1)
+            barrier();          // all waves finished reading the A image (h = 0) / the previous pass (h = 1)
             if (wm == h) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
-                        const int lc = wn * 64 + j * 16 + cq;
-                        const float bv = (a.bias && n0 + lc < a.N) ? a.bias[n0 + lc] : 0.f;
+                        const int lc = wn * 32 + j * 16 + cq;
+                        const float bv = a.bias ? a.bias[n0 + lc] : 0.f;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) Cs[(i * 16 + 4 * g + r) * BN + lc] = acc[i][j][r] + bv;
                     }
             }
             barrier();
-#pragma unroll
-            for (int it = 0; it < 32 * (BN / 8) / NT; ++it) {        // 2 chunks of 8 columns per thread
-                const int c = tid + it * NT;
-                const int lr = c / (BN / 8), lc = (c % (BN / 8)) * 8;
+            {
+                const int lr = tid / (BN / 8), lc = (tid % (BN / 8)) * 8;       // one 8-column chunk per thread
                 const int row = m0 + h * 32 + lr, col = n0 + lc;
-                const bool live = row < a.M && col < a.N;
+                const bool live = row < a.M;
                 float v[8];
                 *reinterpret_cast<float4 *>(v) = *reinterpret_cast<const float4 *>(Cs + lr * BN + lc);
                 *reinterpret_cast<float4 *>(v + 4) = *reinterpret_cast<const float4 *>(Cs + lr * BN + lc + 4);
-                const bool fast = live && vec_ok && col + 8 <= a.N;
-                if (fast) {
-                    if (a.C2) store16(a.C2 + (int64_t)row * a.ldc + col, v);
+                if (live && a.C2) store16(a.C2 + (int64_t)row * a.ldc + col, v);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = act_fwd(a.act, v[e]);
-                    if (a.dact) {
-                        float d[8];
-                        load16(a.dact + (int64_t)row * a.ldd + col, d);
+                for (int e = 0; e < 8; ++e) v[e] = act_fwd(a.act, v[e]);
+                if (HAS_E) {
+                    float d[8];
+                    load16(reinterpret_cast<const bf16 *>(Es + (h * 32 + lr) * 256) + lc, d);
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] *= act_bwd(a.dact_kind, d[e]);
-                    }
-                    if (a.resid) {
-                        float d[8];
-                        load16(a.resid + (int64_t)row * a.ldr + col, d);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] += d[e];
-                    }
-                    store16(a.C + (int64_t)row * a.ldc + col, v);
-                } else if (live) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        if (col + e < a.N) {
-                            float x = v[e];
-                            if (a.C2) a.C2[(int64_t)row * a.ldc + col + e] = from_f32<bf16>(x);
-                            x = act_fwd(a.act, x);
-                            if (a.dact) x *= act_bwd(a.dact_kind, to_f32(a.dact[(int64_t)row * a.ldd + col + e]));
-                            if (a.resid) x += to_f32(a.resid[(int64_t)row * a.ldr + col + e]);
-                            v[e] = x;
-                            a.C[(int64_t)row * a.ldc + col + e] = from_f32<bf16>(x);
-                        }
-                    }
+                    for (int e = 0; e < 8; ++e) v[e] = E_KIND == 2 ? v[e] * act_bwd(a.dact_kind, d[e]) : v[e] + d[e];
                 }
+                if (live) store16(a.C + (int64_t)row * a.ldc + col, v);
                 if (LN) {
                     // the 16 threads holding one row are consecutive lanes: statistics by 4 shuffles.  LayerNorm acts on
                     // the values as STORED (bf16-rounded z), exactly like the unfused LayerNorm kernel reading z back.
@@ -254,10 +265,10 @@ __global__ __launch_bounds__(256) void rowstream_kernel(const RsArgs a) {
     }
 }
 
-template <int K, bool DGRAD, bool LN>
+template <int K, bool DGRAD, bool LN, int E_KIND>
 int rs_launch(const RsArgs &a, hipStream_t s) {
-    using C = RsCfg<K, DGRAD>;
-    auto kern = rowstream_kernel<K, DGRAD, LN>;
+    using C = RsCfg<K, DGRAD, E_KIND != 0>;
+    auto kern = rowstream_kernel<K, DGRAD, LN, E_KIND>;
     MIVIT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
     const int ntn = ceil_div(a.N, BN), ntm = ceil_div(a.M, BM);
     const int per_cu = C::LDS <= 80 * 1024 ? 2 : 1;          // resident blocks per CU by LDS
@@ -282,7 +293,7 @@ bool rowstream_supported(int M, int N, int K, bool dgrad, int64_t lda, int64_t l
     return true;
 }
 
-// forward / dgrad in one entry: C = epilogue(A . W)
+// forward / dgrad in one entry: C = epilogue(A . W).  At most one of {resid, dact} (the engine never needs both).
 int launch_rowstream(bool dgrad, const void *A, int64_t lda, const void *W_bf16, int64_t ldw, int M, int N, int K,
                      const float *bias, int act, const void *dact, int64_t ldd, int dact_kind, const void *resid,
                      int64_t ldr, void *Cout, int64_t ldc, void *C2, const float *gamma, const float *beta, void *Y,
@@ -291,11 +302,22 @@ int launch_rowstream(bool dgrad, const void *A, int64_t lda, const void *W_bf16,
                 static_cast<const bf16 *>(dact), ldd, dact_kind, static_cast<const bf16 *>(resid), ldr,
                 static_cast<bf16 *>(Cout), ldc, static_cast<bf16 *>(C2), gamma, beta, static_cast<bf16 *>(Y), ldy, mean, rstd};
     const bool ln = gamma != nullptr;
-    MIVIT_CHECK(!ln || (N == 128 && !dgrad), "rowstream: fused LayerNorm needs N == 128 (forward)");
+    MIVIT_CHECK(!ln || (N == 128 && !dgrad && resid), "rowstream: fused LayerNorm needs N == 128, forward, with a residual");
+    MIVIT_CHECK(!(dact && resid), "rowstream: at most one epilogue operand");
+    MIVIT_CHECK(ldc % 8 == 0 && (!ln || ldy % 8 == 0) && aligned16(Cout) && (!C2 || aligned16(C2)) && (!Y || aligned16(Y)),
+                "rowstream: outputs must be 16-byte aligned with ld % 8 == 0");
+    MIVIT_CHECK((!resid || (ldr % 8 == 0 && aligned16(resid))) && (!dact || (ldd % 8 == 0 && aligned16(dact))),
+                "rowstream: epilogue operand must be 16-byte aligned with ld % 8 == 0");
+#define RS_GO(KK, DG, LNF, EK) return rs_launch<KK, DG, LNF, EK>(a, s)
     if (K == 128) {
-        if (dgrad) return rs_launch<128, true, false>(a, s);
-        return ln ? rs_launch<128, false, true>(a, s) : rs_launch<128, false, false>(a, s);
+        if (dgrad) { if (dact) RS_GO(128, true, false, 2); if (resid) RS_GO(128, true, false, 3); RS_GO(128, true, false, 0); }
+        if (ln) RS_GO(128, false, true, 1);
+        if (resid) RS_GO(128, false, false, 1);
+        RS_GO(128, false, false, 0);
     }
-    if (dgrad) return rs_launch<256, true, false>(a, s);
-    return ln ? rs_launch<256, false, true>(a, s) : rs_launch<256, false, false>(a, s);
+    if (dgrad) { if (dact) RS_GO(256, true, false, 2); if (resid) RS_GO(256, true, false, 3); RS_GO(256, true, false, 0); }
+    if (ln) RS_GO(256, false, true, 1);
+    if (resid) RS_GO(256, false, false, 1);
+    RS_GO(256, false, false, 0);
+#undef RS_GO
 }
