@@ -73,6 +73,24 @@ size_t mivit_embed_wgrad_bf16_workspace_bytes(int M, int K, int E);
 int mivit_embed_wgrad_bf16(const void *dy_bf16, const float *x, int M, int K, int E, float *dW, void *workspace,
                            size_t workspace_bytes, void *stream);
 
+/* bf16-mode streaming kernels of the encoder-layer projections (csrc/rowstream.hip, csrc/wgrad_dma.hip): weights are
+ * given as bf16 copies, activations are bf16, M = all tokens of the batch.  Return 3 when the shape is outside the
+ * kernels' constraints (then use mivit_linear_*).
+ *   rowstream_fwd  : y = act(x @ W^T + bias) (+ resid); with ln_gamma != NULL (N == 128, resid given) additionally
+ *                    ln_out = LayerNorm(y) and mean/rstd per row -- the post-norm sub-layer of models.py:100-106;
+ *   rowstream_dgrad: dx = (dy @ W) (* act'(saved)) (+ dres), W = [N, K] as in mivit_linear_dgrad (at most one of
+ *                    saved / dres);
+ *   wgrad_bf16     : dW[N, K] (fp32, overwritten) = dy[M, N]^T @ x[M, K]. */
+int mivit_rowstream_fwd(const void *x, int64_t ldx, const void *W_bf16, const float *bias, int M, int N, int K, int act,
+                        const void *resid, int64_t ldr, void *y, int64_t ldy, void *y_preact, const float *ln_gamma,
+                        const float *ln_beta, void *ln_out, float *mean, float *rstd, void *stream);
+int mivit_rowstream_dgrad(const void *dy, int64_t lddy, const void *W_bf16, int M, int N, int K, int act,
+                          const void *saved, int64_t lds, const void *dres, int64_t lddr, void *dx, int64_t lddx,
+                          void *stream);
+size_t mivit_wgrad_bf16_workspace_bytes(int M, int N, int K);
+int mivit_wgrad_bf16(const void *dy, int64_t lddy, const void *x, int64_t ldx, int M, int N, int K, float *dW,
+                     void *workspace, size_t workspace_bytes, void *stream);
+
 /* Row LayerNorm over E, eps 1e-5, biased variance, affine (nn.LayerNorm: models.py:88-89,134,301).
  * Row r of the output goes to row  (r / rows_per_seq) * out_seq_stride + r % rows_per_seq + out_row_off  when
  * rows_per_seq > 0 (token assembly behind the regression token, models.py:347), else to row r.

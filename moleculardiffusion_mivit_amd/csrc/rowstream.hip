@@ -49,11 +49,14 @@ struct RsArgs {
     bf16 *Y; int64_t ldy; float *mean, *rstd;
 };
 
-constexpr int BM = 64, BN = 128, NW = 8, NT = NW * 64;
-constexpr int E_BYTES = BM * BN * 2;                         // optional epilogue-operand tile (residual or saved act.)
+constexpr int BN = 128, NW = 8, NT = NW * 64;
 
 template <int K, bool DGRAD, bool HAS_E>
 struct RsCfg {
+    static constexpr int BM = K > 256 ? 32 : 64;             // rows per tile (the K = 384 weight slice leaves less LDS)
+    static constexpr int E_BYTES = BM * BN * 2;              // optional epilogue-operand tile (residual or saved act.)
+    static constexpr int WMW = BM / 32, WNW = NW / WMW;      // wave grid: WMW x WNW, wave tile 32 x (128 / WNW)
+    static constexpr int TN = BN / WNW / 16;
     static constexpr int RB = 2 * K;                         // bytes per A row (and per W row in forward)
     static constexpr int A_BYTES = BM * RB;
     static constexpr int SLOT = A_BYTES + (HAS_E ? E_BYTES : 0);
@@ -73,11 +76,11 @@ struct RsCfg {
 template <int K, bool DGRAD, bool HAS_E>
 __device__ __forceinline__ void issue_w(const RsArgs &a, unsigned char *wimg, int n0, int wave, int lane) {
     using C = RsCfg<K, DGRAD, HAS_E>;
-    constexpr int CH = C::W_RB / 16, RPI = 64 / CH;          // chunks per row, rows per wave-instruction
+    constexpr int CH = C::W_RB / 16;                         // 16-byte chunks per row; the image is chunk-linear
 #pragma unroll
     for (int i = 0; i < C::W_DMA; ++i) {
         const int inst = wave * C::W_DMA + i;
-        const int r = inst * RPI + lane / CH, s = lane % CH;
+        const int ci = inst * 64 + lane, r = ci / CH, s = ci % CH;
         if (!DGRAD) {       // row = output column n0 + r, chunks along k
             const int c = s ^ (r & 15);
             const int gr = min(n0 + r, a.N - 1);
@@ -94,11 +97,11 @@ template <int K, bool DGRAD, bool HAS_E>
 __device__ __forceinline__ void issue_tile(const RsArgs &a, const bf16 *E, int64_t lde, unsigned char *slot, int m0, int n0,
                                            int wave, int lane) {
     using C = RsCfg<K, DGRAD, HAS_E>;
-    constexpr int CH = C::RB / 16, RPI = 64 / CH;
+    constexpr int CH = C::RB / 16;
 #pragma unroll
     for (int i = 0; i < C::A_DMA; ++i) {
         const int inst = wave * C::A_DMA + i;
-        const int r = inst * RPI + lane / CH, s = lane % CH;
+        const int ci = inst * 64 + lane, r = ci / CH, s = ci % CH;
         const int c = s ^ (r & 15);
         const int gr = min(m0 + r, a.M - 1);
         dma16(a.A + (int64_t)gr * a.lda + c * 8, slot + inst * 1024);
@@ -121,11 +124,13 @@ __global__ __launch_bounds__(NT) void rowstream_kernel(const RsArgs a) {
     constexpr bool HAS_E = E_KIND != 0;
     using C = RsCfg<K, DGRAD, HAS_E>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int TM = 2, TN = 2, KS = K / 32, D = C::NS - 1;    // wave tile 32 x 32 (waves 2 x 4)
+    constexpr int TM = 2, TN = C::TN, KS = K / 32, D = C::NS - 1;
     unsigned char *Wimg = smem, *ring = smem + C::W_BYTES;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 2, wn = wave & 3;
+    const int wm = wave / C::WNW, wn = wave % C::WNW;
+    constexpr int WCOLS = BN / C::WNW;                       // columns per wave
     const int g = lane >> 4, cq = lane & 15, q = cq >> 2, p = cq & 3;
+    constexpr int BM = C::BM;
     const int n0 = blockIdx.x * BN;
     const int ntm = (a.M + BM - 1) / BM;
     const int stride = gridDim.y;
@@ -171,13 +176,13 @@ __global__ __launch_bounds__(NT) void rowstream_kernel(const RsArgs a) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 if (!DGRAD) {
-                    const int n = wn * 32 + j * 16 + cq;
+                    const int n = wn * WCOLS + j * 16 + cq;
                     const int c = (ks * 4 + g) ^ (n & 15);
                     bf[j] = *reinterpret_cast<const bf16x8 *>(Wimg + n * C::W_RB + c * 16);
                 } else {
                     // B[k = red][n]: k slots 0..3 = rows ks*32 + 8g + 0..3, slots 4..7 = + 4..7; this lane supplies
                     // columns ncol .. ncol + 3 of row (+ q)
-                    const int ncol = wn * 32 + j * 16 + 4 * p;
+                    const int ncol = wn * WCOLS + j * 16 + 4 * p;
                     s16x4 lo, hi;
                     {
                         const int r = ks * 32 + 8 * g + q;
@@ -203,14 +208,14 @@ __global__ __launch_bounds__(NT) void rowstream_kernel(const RsArgs a) {
         // ---- epilogue: 32 rows per pass through fp32 staging in the A part of the ring slot just consumed; every
         //      operand it needs is already in LDS, so it issues stores only ----
         float *Cs = reinterpret_cast<float *>(slot);
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < BM / 32; ++h) {
             barrier();          // all waves finished reading the A image (h = 0) / the previous pass (h = 1)
             if (wm == h) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
-                        const int lc = wn * 32 + j * 16 + cq;
+                        const int lc = wn * WCOLS + j * 16 + cq;
                         const float bv = a.bias ? a.bias[n0 + lc] : 0.f;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) Cs[(i * 16 + 4 * g + r) * BN + lc] = acc[i][j][r] + bv;
@@ -268,6 +273,7 @@ __global__ __launch_bounds__(NT) void rowstream_kernel(const RsArgs a) {
 template <int K, bool DGRAD, bool LN, int E_KIND>
 int rs_launch(const RsArgs &a, hipStream_t s) {
     using C = RsCfg<K, DGRAD, E_KIND != 0>;
+    constexpr int BM = C::BM;
     auto kern = rowstream_kernel<K, DGRAD, LN, E_KIND>;
     MIVIT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
     const int ntn = ceil_div(a.N, BN), ntm = ceil_div(a.M, BM);
@@ -287,9 +293,8 @@ bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 
 bool rowstream_supported(int M, int N, int K, bool dgrad, int64_t lda, int64_t ldw, const void *A, const void *W) {
     static const bool off = getenv("MIVIT_NO_ROWSTREAM") != nullptr;
     if (off) return false;
-    if (!(K == 128 || K == 256) || N % 128 != 0 || M < 256) return false;
+    if (!(K == 128 || K == 256 || (K == 384 && dgrad)) || N % 128 != 0 || M < 256) return false;
     if (lda % 8 || ldw % 8 || !aligned16(A) || !aligned16(W)) return false;
-    (void)dgrad;
     return true;
 }
 
@@ -315,9 +320,31 @@ int launch_rowstream(bool dgrad, const void *A, int64_t lda, const void *W_bf16,
         if (resid) RS_GO(128, false, false, 1);
         RS_GO(128, false, false, 0);
     }
+    if (K == 384) { if (dact) RS_GO(384, true, false, 2); if (resid) RS_GO(384, true, false, 3); RS_GO(384, true, false, 0); }
     if (dgrad) { if (dact) RS_GO(256, true, false, 2); if (resid) RS_GO(256, true, false, 3); RS_GO(256, true, false, 0); }
     if (ln) RS_GO(256, false, true, 1);
     if (resid) RS_GO(256, false, false, 1);
     RS_GO(256, false, false, 0);
 #undef RS_GO
+}
+
+extern "C" int mivit_rowstream_fwd(const void *x, int64_t ldx, const void *W_bf16, const float *bias, int M, int N, int K,
+                                   int act, const void *resid, int64_t ldr, void *y, int64_t ldy, void *y_preact,
+                                   const float *ln_gamma, const float *ln_beta, void *ln_out, float *mean, float *rstd,
+                                   void *stream) {
+    MIVIT_CHECK(x && W_bf16 && y, "rowstream_fwd: null pointer");
+    if (!rowstream_supported(M, N, K, false, ldx, K, x, W_bf16)) { mivit_set_error("rowstream_fwd: unsupported shape"); return 3; }
+    prof_set_tag(MIVIT_PROF_OP);
+    return launch_rowstream(false, x, ldx, W_bf16, K, M, N, K, bias, act, nullptr, 0, 0, resid, ldr, y, ldy, y_preact, ln_gamma,
+                            ln_beta, ln_out, N, mean, rstd, static_cast<hipStream_t>(stream));
+}
+extern "C" int mivit_rowstream_dgrad(const void *dy, int64_t lddy, const void *W_bf16, int M, int N, int K, int act,
+                                     const void *saved, int64_t lds, const void *dres, int64_t lddr, void *dx, int64_t lddx,
+                                     void *stream) {
+    MIVIT_CHECK(dy && W_bf16 && dx, "rowstream_dgrad: null pointer");
+    if (!rowstream_supported(M, K, N, true, lddy, K, dy, W_bf16)) { mivit_set_error("rowstream_dgrad: unsupported shape"); return 3; }
+    prof_set_tag(MIVIT_PROF_OP);
+    return launch_rowstream(true, dy, lddy, W_bf16, K, M, K, N, nullptr, MIVIT_ACT_NONE, act != MIVIT_ACT_NONE ? saved : nullptr,
+                            lds, act, dres, lddr, dx, lddx, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr,
+                            static_cast<hipStream_t>(stream));
 }

@@ -168,3 +168,14 @@ int launch_wgrad_dma(const void *dy, int64_t lddy, const void *x, int64_t ldx, i
     }
     return launch_slab_reduce(static_cast<const float *>(ws), nz, (int64_t)N * K, dW, 0, s);
 }
+
+extern "C" size_t mivit_wgrad_bf16_workspace_bytes(int M, int N, int K) {
+    return (N % TILE == 0 && K % TILE == 0) ? wgrad_dma_ws_bytes(M, N, K) : 0;
+}
+extern "C" int mivit_wgrad_bf16(const void *dy, int64_t lddy, const void *x, int64_t ldx, int M, int N, int K, float *dW,
+                                void *workspace, size_t workspace_bytes, void *stream) {
+    MIVIT_CHECK(dy && x && dW && workspace, "wgrad_bf16: null pointer");
+    if (!wgrad_dma_supported(M, N, K, lddy, ldx, dy, x)) { mivit_set_error("wgrad_bf16: unsupported shape"); return 3; }
+    prof_set_tag(MIVIT_PROF_OP);
+    return launch_wgrad_dma(dy, lddy, x, ldx, M, N, K, dW, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+}

@@ -169,3 +169,84 @@ def test_embed_streaming_kernels_reject_odd_shapes():
     p = ctypes.c_void_p(z.data_ptr())
     assert N.lib.mivit_embed_fwd_bf16(p, p, p, 240, 81, 64, p, None) == 3      # reference shape: general GEMM instead
     assert N.lib.mivit_embed_wgrad_bf16_workspace_bytes(240, 81, 64) == 0
+
+
+def _ints(shape, lo, hi, seed):
+    return torch.randint(lo, hi + 1, shape, generator=torch.Generator().manual_seed(seed)).float()
+
+
+@pytest.mark.parametrize("M,N,K", [(264, 128, 128), (1000, 384, 128), (4130, 256, 128), (777, 128, 256)])
+@pytest.mark.parametrize("variant", ["plain", "relu_preact", "resid", "resid_ln"])
+def test_rowstream_forward_exact(M, N, K, variant):
+    """Row-stream GEMM (csrc/rowstream.hip), forward, on small integers: exact up to the final bf16 rounding."""
+    import ctypes
+    from moleculardiffusion_mivit_amd import _native as N_
+    if variant == "resid_ln" and N != 128:
+        pytest.skip("fused LayerNorm needs N == 128")
+    x, W, b = _ints((M, K), -2, 2, 1), _ints((N, K), -2, 2, 2), _ints((N,), -3, 3, 3)
+    r = _ints((M, N), -4, 4, 4)
+    p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())   # noqa: E731
+    xg, Wg, bg, rg = x.bfloat16().cuda(), W.bfloat16().cuda(), b.cuda(), r.bfloat16().cuda()
+    y = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    pre = torch.empty_like(y) if variant == "relu_preact" else None
+    has_r = variant in ("resid", "resid_ln")
+    ln = variant == "resid_ln"
+    gam = (1 + 0.1 * torch.randn(N, generator=torch.Generator().manual_seed(5))).cuda() if ln else None
+    bet = (0.1 * torch.randn(N, generator=torch.Generator().manual_seed(6))).cuda() if ln else None
+    lno = torch.empty_like(y) if ln else None
+    mean = torch.empty(M, device="cuda") if ln else None
+    rstd = torch.empty(M, device="cuda") if ln else None
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    N_.check(N_.lib.mivit_rowstream_fwd(p(xg), K, p(Wg), p(bg), M, N, K, 1 if variant == "relu_preact" else 0,
+                                        p(rg) if has_r else None, N, p(y), N, p(pre), p(gam), p(bet), p(lno), p(mean), p(rstd),
+                                        st), "rowstream_fwd")
+    u = x.double() @ W.double().t() + b.double()
+    ref = torch.relu(u) if variant == "relu_preact" else u
+    if has_r:
+        ref = ref + r.double()
+    assert torch.equal(y.float().cpu(), ref.float().bfloat16().float())
+    if pre is not None:
+        assert torch.equal(pre.float().cpu(), u.float().bfloat16().float())
+    if ln:
+        z = ref.float().bfloat16().float()
+        want = torch.nn.functional.layer_norm(z, (N,), gam.cpu(), bet.cpu())
+        assert float((lno.float().cpu() - want).abs().max()) < 2e-2 * float(want.abs().max())
+        assert float((mean.cpu() - z.mean(-1)).abs().max()) < 1e-4
+        assert float((rstd.cpu() - torch.rsqrt(z.var(-1, unbiased=False) + 1e-5)).abs().max()) < 1e-3
+
+
+@pytest.mark.parametrize("M,N,K", [(264, 128, 128), (1000, 128, 256), (4130, 256, 128), (900, 384, 128)])
+@pytest.mark.parametrize("variant", ["plain", "dact_relu", "dres"])
+def test_rowstream_dgrad_exact(M, N, K, variant):
+    """dx[M,K] = dy[M,N] @ W[N,K] (* relu'(saved)) (+ dres): W consumed through transposed LDS reads."""
+    import ctypes
+    from moleculardiffusion_mivit_amd import _native as N_
+    dy, W = _ints((M, N), -2, 2, 7), _ints((N, K), -2, 2, 8)
+    saved, dres = _ints((M, K), -1, 2, 9), _ints((M, K), -4, 4, 10)
+    p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())   # noqa: E731
+    dyg, Wg, sg, rg = dy.bfloat16().cuda(), W.bfloat16().cuda(), saved.bfloat16().cuda(), dres.bfloat16().cuda()
+    dx = torch.empty(M, K, dtype=torch.bfloat16, device="cuda")
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    N_.check(N_.lib.mivit_rowstream_dgrad(p(dyg), N, p(Wg), M, N, K, 1 if variant == "dact_relu" else 0,
+                                          p(sg) if variant == "dact_relu" else None, K,
+                                          p(rg) if variant == "dres" else None, K, p(dx), K, st), "rowstream_dgrad")
+    ref = dy.double() @ W.double()
+    if variant == "dact_relu":
+        ref = ref * (saved > 0).double()
+    if variant == "dres":
+        ref = ref + dres.double()
+    assert torch.equal(dx.float().cpu(), ref.float().bfloat16().float())
+
+
+@pytest.mark.parametrize("M,N,K", [(264, 128, 128), (1000, 384, 128), (4130, 128, 256), (70000, 256, 128)])
+def test_wgrad_dma_exact(M, N, K):
+    import ctypes
+    from moleculardiffusion_mivit_amd import _native as N_
+    dy, x = _ints((M, N), -2, 2, 11), _ints((M, K), -2, 2, 12)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())   # noqa: E731
+    dyg, xg = dy.bfloat16().cuda(), x.bfloat16().cuda()
+    ws = torch.empty(max(N_.lib.mivit_wgrad_bf16_workspace_bytes(M, N, K), 16), dtype=torch.uint8, device="cuda")
+    dW = torch.empty(N, K, device="cuda")
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    N_.check(N_.lib.mivit_wgrad_bf16(p(dyg), N, p(xg), K, M, N, K, p(dW), p(ws), ws.numel(), st), "wgrad_bf16")
+    assert torch.equal(dW.cpu(), (dy.double().t() @ x.double()).float())
