@@ -278,7 +278,8 @@ int rs_launch(const RsArgs &a, hipStream_t s) {
     MIVIT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
     const int ntn = ceil_div(a.N, BN), ntm = ceil_div(a.M, BM);
     const int per_cu = C::LDS <= 80 * 1024 ? 2 : 1;          // resident blocks per CU by LDS
-    int gy = (256 * per_cu + ntn - 1) / ntn;
+    int gy = (256 * per_cu) / ntn;                           // never more blocks than can be resident: no tail round
+    if (gy < 1) gy = 1;
     if (gy > ntm) gy = ntm;
     ProfScope prof(s);
     hipLaunchKernelGGL(kern, dim3(ntn, gy), dim3(NT), C::LDS, s, a);
