@@ -1,0 +1,120 @@
+"""Pieces shared by the experiment mirrors: the constants every reference ``trainSettings*.py`` repeats, validation
+sets (reference .npy files when ``MIVIT_VALIDATION_ROOT`` / ``../validation_trajectories`` exists, seeded Brownian
+otherwise), and the cycle loop every reference ``trainModels*.py`` repeats (data refresh -> per-model epoch ->
+StepLR -> validation at D = 1,3,5,7,9 with predictions * D_max_normalization -> save_results)."""
+import datetime
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.utils.data import DataLoader
+
+from ..helpers import generation as gen
+
+D_VALUES = (1, 3, 5, 7, 9)
+
+# values from real data, shared by Framerate / Embeddings / ImagesFeatures (e.g. trainSettingsEmbeddings.py:52-53)
+BACKGROUND_MEAN, BACKGROUND_SIGMA = 1420, 290
+PART_MEAN, PART_STD = 6000 - BACKGROUND_MEAN, 500
+
+
+def real_data_image_props(patch_size):
+    return {"particle_intensity": [PART_MEAN, PART_STD], "NA": 1.46, "wavelength": 500e-9, "psf_division_factor": 1.3,
+            "resolution": 100e-9, "output_size": patch_size, "upsampling_factor": 5,
+            "background_intensity": [BACKGROUND_MEAN, BACKGROUND_SIGMA], "poisson_noise": 100, "trajectory_unit": 1200}
+
+
+def validation_root():
+    for cand in (os.environ.get("MIVIT_VALIDATION_ROOT"), "../validation_trajectories"):
+        if cand and os.path.isdir(cand):
+            return cand
+    return None
+
+
+def validation_trajectories(length, T, traj_div_factor, generator, n_synthetic=50, in_order=None):
+    """[(N,T,2) array for D in 1,3,5,7,9] (+ the in-order set when `in_order` = (d_values, n_per_d))."""
+    root = validation_root()
+    sets = []
+    for D in D_VALUES:
+        if root is not None:
+            sets.append(np.load(os.path.join(root, str(length), f"val{D}.npy")) / traj_div_factor)
+        else:
+            tr, _ = gen.brownian_single_state(n_synthetic, T, Ds=[D, 0.0], generator=generator)
+            sets.append(tr.permute(1, 0, 2).numpy() / traj_div_factor)
+    tio = None
+    if in_order is not None:
+        dvals, n = in_order
+        if root is not None:
+            tio = (np.load(os.path.join(root, "valTrajsInOrder.npy")) / traj_div_factor).reshape(-1, T, 2)
+        else:
+            tio = torch.cat([gen.brownian_single_state(n, T, Ds=[float(d), 0.0], generator=generator)[0].permute(1, 0, 2)
+                             for d in dvals]).numpy() / traj_div_factor
+    return sets, tio
+
+
+def run_cycles(S, models, optimizers, schedulers, make_batch_data, predict, num_cycles, val_sets, results_name,
+               batch_size=None, device=None, out_dir=".", save=True, shuffle=True, generator=None, verbose=False):
+    """The reference's cycle loop.  `make_batch_data(cycle)` -> (tensors..., labels, raw_labels);
+    `predict(model, name, *batch_tensors)` -> predictions; `val_sets` = list of (tensors tuple, D value)."""
+    device = device or S.device
+    for name in models:
+        if models[name] is not None:
+            models[name] = models[name].to(device)
+    if batch_size is None:
+        batch_size = 1 if S.adaptive_batch_size != -1 else 16
+    validation_losses = {name: {**{f"val_{float(D)}": [] for D in D_VALUES}, "val_avg": []} for name in models}
+    all_gen_labels = np.array([])
+    print("StartTime: ", datetime.datetime.now())
+    for cycle in range(num_cycles):
+        if S.adaptive_batch_size != -1 and cycle != 0 and cycle % S.adaptive_batch_size == 0:
+            batch_size *= 2
+            print(f"Cycle: {cycle} new batch size: {batch_size}")
+        print(f"Cycle {cycle + 1} out of {num_cycles}: {(cycle + 1) / num_cycles * 100:.2f}%")
+        *tensors, labels, raw = make_batch_data(cycle)
+        all_gen_labels = np.append(all_gen_labels, raw)
+        ds = torch.utils.data.TensorDataset(*tensors, labels)
+        loader = DataLoader(ds, batch_size=batch_size, shuffle=shuffle, generator=generator)
+        for name, model in models.items():
+            if model is None:
+                continue
+            model.train()
+            opt, sch = optimizers[name], schedulers[name]
+            for *bt, bl in loader:
+                bt = [t.to(device) for t in bt]
+                opt.zero_grad()
+                loss = S.loss_function(predict(model, name, *bt), bl.to(device))
+                loss.backward()
+                opt.step()
+            sch.step()
+        for name, model in models.items():
+            if model is None:
+                continue
+            model.eval()
+            with torch.no_grad():
+                per = []
+                for vt, D in val_sets:
+                    vt = [t.to(device) for t in vt]
+                    label = torch.full((vt[0].shape[0], 1), float(D), device=device)
+                    v = S.loss_function(predict(model, name, *vt) * S.D_max_normalization, label).item()
+                    validation_losses[name][f"val_{float(D)}"].append(v)
+                    per.append(v)
+                    if verbose:
+                        print(f"{name} on val_{float(D)}: Validation Loss = {v:.4f}")
+                validation_losses[name]["val_avg"].append(float(np.mean(per)))
+        if save and num_cycles - cycle - 1 < 5:
+            save_results(validation_losses, all_gen_labels, models, results_name, str(num_cycles - cycle), out_dir)
+    if save:
+        save_results(validation_losses, all_gen_labels, models, results_name, "", out_dir)
+    print(datetime.datetime.now())
+    return models, validation_losses, all_gen_labels
+
+
+def save_results(validation_losses, all_gen_labels, models, results_name, path_addition="", out_dir="."):
+    """Same dict schema as every reference save_results (e.g. trainModelsPSFNoise.py:14-22)."""
+    save_path = f"{out_dir}/training_results_{results_name}{path_addition}.pth"
+    torch.save({"validation_losses": validation_losses, "all_labels": all_gen_labels,
+                "model_weights": {n: m.state_dict() for n, m in models.items() if m is not None}}, save_path)
+    print(f"\nTraining results saved to {save_path}")
+    return save_path

@@ -33,3 +33,34 @@ def test_reduced_psfnoise_run(tmp_path, embedding):
         a = S.make_prediction(models["tr_1_3"].eval(), "tr_1_3", x)
         b = S.make_prediction(fresh["tr_1_3"].cuda().eval(), "tr_1_3", x)
     assert torch.equal(a, b)
+
+
+def test_reduced_framerate_run_ragged_sequence_lengths(tmp_path):
+    """Exposure-time experiment: sequences of 60 / 30 / 20 / 15 / 10 / 6 frames (+ regression token) at 13x13 go through
+    the same model class (reference trainSettingsFramerate.py:157-166)."""
+    from moleculardiffusion_mivit_amd.experiments.Framerate import trainModelsFramerate as TM
+    models, vlosses, labels = TM.run_training(num_cycles=2, N=4, seed=1, out_dir=str(tmp_path), embedding="linear",
+                                              include_resnet=False)
+    assert sorted(models) == [f"tr_{i}" for i in range(6)]
+    for n in models:
+        assert len(vlosses[n]["val_avg"]) == 2 and np.isfinite(vlosses[n]["val_avg"]).all()
+    assert (tmp_path / "training_results_Framerate.pth").exists()
+
+
+def test_reduced_embeddings_run_and_rotation_tta(tmp_path):
+    from moleculardiffusion_mivit_amd.experiments.Embeddings import trainModelsEmbeddings as TM
+    from moleculardiffusion_mivit_amd.experiments.ImagesFeatures import trainSettingsImagesFeatures as IF
+    models, vlosses, _ = TM.run_training(num_cycles=1, N=4, seed=2, out_dir=str(tmp_path), save=False,
+                                         model_filter=["linear_s", "cnn_n"])
+    assert sorted(models) == ["cnn_n", "linear_s"] and np.isfinite(vlosses["cnn_n"]["val_avg"]).all()
+    # ImagesFeatures: name-dispatched predictions incl. early / late fusion and rotation test-time augmentation
+    zoo, _, _ = IF.getTrainingModels(embedding_cls=IF.LinearProjectionEmbedding)
+    x = torch.rand(3, IF.nFrames, 9, 9)
+    f = torch.randn(3, IF.N_features)
+    for n in (IF.im_tr, IF.im_ft_late_tr, IF.im_ft_early_tr, IF.im_resnet, IF.im_ft_resnet, IF.ft_mlp):
+        zoo[n] = zoo[n].cuda()
+        out = IF.make_prediction(zoo[n], n, x, f)
+        assert out.shape == (3, 1) and torch.isfinite(out).all(), n
+    tta = IF.predict_with_rotations(zoo[IF.im_tr], x.cuda())
+    manual = torch.stack([zoo[IF.im_tr](torch.rot90(x.cuda(), k, (2, 3)).contiguous()) for k in range(4)]).mean(0)
+    assert torch.allclose(tta, manual)
