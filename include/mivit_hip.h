@@ -80,7 +80,8 @@ int mivit_embed_wgrad_bf16(const void *dy_bf16, const float *x, int M, int K, in
  *                    ln_out = LayerNorm(y) and mean/rstd per row -- the post-norm sub-layer of models.py:100-106;
  *   rowstream_dgrad: dx = (dy @ W) (* act'(saved)) (+ dres), W = [N, K] as in mivit_linear_dgrad (at most one of
  *                    saved / dres);
- *   wgrad_bf16     : dW[N, K] (fp32, overwritten) = dy[M, N]^T @ x[M, K]. */
+ *   wgrad_bf16     : dW[N, K] (fp32, overwritten) = dy[M, N]^T @ x[M, K]; db[N] (optional) = column sums of dy, taken
+ *                    from the same LDS tiles. */
 int mivit_rowstream_fwd(const void *x, int64_t ldx, const void *W_bf16, const float *bias, int M, int N, int K, int act,
                         const void *resid, int64_t ldr, void *y, int64_t ldy, void *y_preact, const float *ln_gamma,
                         const float *ln_beta, void *ln_out, float *mean, float *rstd, void *stream);
@@ -88,7 +89,7 @@ int mivit_rowstream_dgrad(const void *dy, int64_t lddy, const void *W_bf16, int 
                           const void *saved, int64_t lds, const void *dres, int64_t lddr, void *dx, int64_t lddx,
                           void *stream);
 size_t mivit_wgrad_bf16_workspace_bytes(int M, int N, int K);
-int mivit_wgrad_bf16(const void *dy, int64_t lddy, const void *x, int64_t ldx, int M, int N, int K, float *dW,
+int mivit_wgrad_bf16(const void *dy, int64_t lddy, const void *x, int64_t ldx, int M, int N, int K, float *dW, float *db,
                      void *workspace, size_t workspace_bytes, void *stream);
 
 /* Row LayerNorm over E, eps 1e-5, biased variance, affine (nn.LayerNorm: models.py:88-89,134,301).

@@ -44,8 +44,8 @@ SYMBOLS = {
     "mivit_rowstream_dgrad": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int64, c_void_p,
                                       c_int64, c_void_p, c_int64, c_void_p]),
     "mivit_wgrad_bf16_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
-    "mivit_wgrad_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t,
-                                 c_void_p]),
+    "mivit_wgrad_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                 c_size_t, c_void_p]),
     "mivit_layernorm_fwd": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int64,
                                     c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mivit_layernorm_bwd_workspace_bytes": (c_size_t, [c_int, c_int]),

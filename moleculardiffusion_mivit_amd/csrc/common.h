@@ -250,12 +250,15 @@ int launch_rowstream(bool dgrad, const void *A, int64_t lda, const void *W_bf16,
 // bf16 LDS-DMA weight gradient of the layer projections (wgrad_dma.hip)
 bool wgrad_dma_supported(int M, int N, int K, int64_t lddy, int64_t ldx, const void *dy, const void *x);
 size_t wgrad_dma_ws_bytes(int M, int N, int K);
-int launch_wgrad_dma(const void *dy, int64_t lddy, const void *x, int64_t ldx, int M, int N, int K, float *dW, void *ws,
-                     size_t ws_bytes, hipStream_t s);
+int launch_wgrad_dma(const void *dy, int64_t lddy, const void *x, int64_t ldx, int M, int N, int K, float *dW, float *db,
+                     void *ws, size_t ws_bytes, hipStream_t s);
 
 // small elementwise / reduction helpers (misc.hip)
 // out[n] (+)= sum_p part[p*n_stride + n]   (deterministic slab reduce)
 int launch_slab_reduce(const float *part, int nparts, int64_t n, float *out, int accumulate, hipStream_t s);
+// up to three (slab, output) pairs of the same shape in one launch; pass null outputs from the end
+int launch_slab_reduce3(const float *p0, float *o0, const float *p1, float *o1, const float *p2, float *o2, int nparts,
+                        int n, int accumulate, hipStream_t s);
 // tokens[b, 0, :] = reg[:] (+ add[b, :]) (+ pos[0, :])   -- regression token row (models.py:339-347)
 int launch_reg_token_fill(int dtype, void *tokens, int B, int S, int E, const float *reg, const void *add,
                           const float *pos, hipStream_t s);

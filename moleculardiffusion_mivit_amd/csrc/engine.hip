@@ -165,9 +165,7 @@ int lin_wgrad(int dtype, const void *dy, int64_t lddy, const void *x, int x_f32,
     if (dtype == MIVIT_BF16 && !x_f32 && dW && wgrad_dma_supported(M, N, K, lddy, ldx, dy, x) &&
         wsb >= wgrad_dma_ws_bytes(M, N, K) + linear_wgrad_ws_bytes(M, N, K)) {
         prof_set_tag(MIVIT_PROF_LINEAR_WGRAD);
-        RC(launch_wgrad_dma(dy, lddy, x, ldx, M, N, K, dW, ws, wsb, s));
-        if (!db) return 0;
-        dW = nullptr;     // bias gradient only, through the general path below
+        return launch_wgrad_dma(dy, lddy, x, ldx, M, N, K, dW, db, ws, wsb, s);      // db (optional) from the same pass
     }
     LinearWgradArgs a = {};
     a.dtype = dtype; a.dy = dy; a.dy_is_f32 = dtype == MIVIT_F32; a.lddy = lddy; a.x = x;

@@ -383,12 +383,17 @@ int launch_layernorm_bwd(const LayerNormBwdArgs &a, hipStream_t s) {
     bool did_z = false;
     int rc = a.dtype == MIVIT_F32 ? ln_bwd_dispatch<float>(k, blocks, &did_z, s) : ln_bwd_dispatch<bf16>(k, blocks, &did_z, s);
     if (rc) return rc;
-    if (a.dgamma && (rc = launch_slab_reduce(pg, blocks, a.E, a.dgamma, a.accumulate, s))) return rc;
-    if (a.dbeta && (rc = launch_slab_reduce(pb, blocks, a.E, a.dbeta, a.accumulate, s))) return rc;
-    if (a.dzsum) {
-        if (did_z) return launch_slab_reduce(pz, blocks, a.E, a.dzsum, a.accumulate, s);
-        return 2;   // caller must fall back to a column-sum kernel (scalar LayerNorm path was taken)
+    if (a.dgamma && a.dbeta) {
+        const bool z = a.dzsum && did_z;
+        if ((rc = launch_slab_reduce3(pg, a.dgamma, pb, a.dbeta, z ? pz : nullptr, z ? a.dzsum : nullptr, blocks, a.E,
+                                      a.accumulate, s)))
+            return rc;
+    } else {
+        if (a.dgamma && (rc = launch_slab_reduce(pg, blocks, a.E, a.dgamma, a.accumulate, s))) return rc;
+        if (a.dbeta && (rc = launch_slab_reduce(pb, blocks, a.E, a.dbeta, a.accumulate, s))) return rc;
+        if (a.dzsum && did_z && (rc = launch_slab_reduce(pz, blocks, a.E, a.dzsum, a.accumulate, s))) return rc;
     }
+    if (a.dzsum && !did_z) return 2;   // caller must fall back to a column-sum kernel (scalar LayerNorm path was taken)
     return 0;
 }
 

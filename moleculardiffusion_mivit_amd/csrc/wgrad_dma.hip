@@ -29,6 +29,7 @@ __device__ __forceinline__ f32x4 mma(bf16x8 a, bf16x8 b, f32x4 c) {
 struct WgArgs {
     const bf16 *dY; int64_t lddy; const bf16 *X; int64_t ldx; float *slabs;
     int M, N, K, rows_per_split;
+    float *bias_part;      // optional [splits][N]: column sums of dY (bias gradient), taken from the LDS image
 };
 
 constexpr int BMR = 64, TILE = 128, NS = 3, IMG = BMR * TILE * 2, STAGE = 2 * IMG;   // 16 KiB per image
@@ -89,6 +90,8 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgArgs a) {
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool do_bias = a.bias_part != nullptr && blockIdx.x == 0;      // one k-tile column of blocks sums dY
+    float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
 #pragma unroll
     for (int s = 0; s < D; ++s)
@@ -107,6 +110,18 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgArgs a) {
         }
         const unsigned char *As = smem + (s % NS) * STAGE, *Bs = As + IMG;
         const int valid = min(BMR, me - (mb + s * BMR));
+        if (do_bias) {      // thread = (16-byte chunk tid & 15 = 8 columns, row lane tid >> 4): rows lane, lane + 16, ...
+            const int ch = tid & 15;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = (tid >> 4) + 16 * i;
+                float v[8];
+                load16(reinterpret_cast<const bf16 *>(As + r * 256 + ((ch ^ (2 * (r & 7))) << 4)), v);
+                if (r < valid)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) bsum[e] += v[e];
+            }
+        }
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int mr = kk * 32 + 8 * g;
@@ -119,6 +134,19 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgArgs a) {
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = mma(af[i], bf[j], acc[i][j]);
+        }
+    }
+    if (do_bias) {
+        barrier();
+        float *red = reinterpret_cast<float *>(smem);           // [16 row lanes][128 columns]
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[(tid >> 4) * 128 + (tid & 15) * 8 + e] = bsum[e];
+        barrier();
+        if (tid < 128) {
+            float t = 0.f;
+#pragma unroll
+            for (int y = 0; y < 16; ++y) t += red[y * 128 + tid];
+            a.bias_part[(int64_t)blockIdx.z * a.N + n0 + tid] = t;
         }
     }
     float *out = a.slabs + (int64_t)blockIdx.z * a.N * a.K;
@@ -149,16 +177,20 @@ bool wgrad_dma_supported(int M, int N, int K, int64_t lddy, int64_t ldx, const v
            ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(x)) & 15) == 0;
 }
 
-size_t wgrad_dma_ws_bytes(int M, int N, int K) { return (size_t)dma_splits(M, N, K) * N * K * sizeof(float); }
+size_t wgrad_dma_ws_bytes(int M, int N, int K) {
+    return align_up((size_t)dma_splits(M, N, K) * N * (K + 1) * sizeof(float), 256);
+}
 
-int launch_wgrad_dma(const void *dy, int64_t lddy, const void *x, int64_t ldx, int M, int N, int K, float *dW,
+int launch_wgrad_dma(const void *dy, int64_t lddy, const void *x, int64_t ldx, int M, int N, int K, float *dW, float *db,
                      void *ws, size_t ws_bytes, hipStream_t s) {
     MIVIT_CHECK(ws_bytes >= wgrad_dma_ws_bytes(M, N, K), "wgrad_dma: workspace too small");
     const int splits = dma_splits(M, N, K);
     int rps = ceil_div(M, splits);
     rps = (rps + BMR - 1) / BMR * BMR;
     const int nz = ceil_div(M, rps);
-    WgArgs a = {static_cast<const bf16 *>(dy), lddy, static_cast<const bf16 *>(x), ldx, static_cast<float *>(ws), M, N, K, rps};
+    float *bias_part = db ? static_cast<float *>(ws) + (size_t)nz * N * K : nullptr;
+    WgArgs a = {static_cast<const bf16 *>(dy), lddy, static_cast<const bf16 *>(x), ldx, static_cast<float *>(ws), M, N, K, rps,
+                bias_part};
     const size_t bytes = (size_t)NS * STAGE;
     MIVIT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wgrad_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     {
@@ -166,16 +198,18 @@ int launch_wgrad_dma(const void *dy, int64_t lddy, const void *x, int64_t ldx, i
         hipLaunchKernelGGL(wgrad_dma_kernel, dim3(K / TILE, N / TILE, nz), dim3(256), bytes, s, a);
         MIVIT_LAUNCH_CHECK();
     }
-    return launch_slab_reduce(static_cast<const float *>(ws), nz, (int64_t)N * K, dW, 0, s);
+    int rc = launch_slab_reduce(static_cast<const float *>(ws), nz, (int64_t)N * K, dW, 0, s);
+    if (rc || !db) return rc;
+    return launch_slab_reduce(bias_part, nz, N, db, 0, s);
 }
 
 extern "C" size_t mivit_wgrad_bf16_workspace_bytes(int M, int N, int K) {
     return (N % TILE == 0 && K % TILE == 0) ? wgrad_dma_ws_bytes(M, N, K) : 0;
 }
 extern "C" int mivit_wgrad_bf16(const void *dy, int64_t lddy, const void *x, int64_t ldx, int M, int N, int K, float *dW,
-                                void *workspace, size_t workspace_bytes, void *stream) {
+                                float *db, void *workspace, size_t workspace_bytes, void *stream) {
     MIVIT_CHECK(dy && x && dW && workspace, "wgrad_bf16: null pointer");
     if (!wgrad_dma_supported(M, N, K, lddy, ldx, dy, x)) { mivit_set_error("wgrad_bf16: unsupported shape"); return 3; }
     prof_set_tag(MIVIT_PROF_OP);
-    return launch_wgrad_dma(dy, lddy, x, ldx, M, N, K, dW, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+    return launch_wgrad_dma(dy, lddy, x, ldx, M, N, K, dW, db, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
 }
