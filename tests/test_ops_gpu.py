@@ -109,7 +109,8 @@ def _attn_ref(qkv, H):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("B,S,H,Dh", [(8, 33, 4, 32), (4, 31, 4, 16), (2, 65, 8, 64), (3, 7, 2, 16), (2, 16, 2, 32),
-                                      (2, 17, 4, 16), (1, 1, 1, 16), (2, 61, 4, 16), (2, 48, 8, 16), (1, 80, 2, 64)])
+                                      (2, 17, 4, 16), (1, 1, 1, 16), (2, 61, 4, 16), (2, 48, 8, 16), (1, 80, 2, 64),
+                                      (2, 64, 2, 32), (1, 65, 4, 32), (3, 49, 4, 32), (2, 32, 4, 16), (1, 96, 2, 32)])
 def test_attention(dtype, B, S, H, Dh):
     from moleculardiffusion_mivit_amd import ops
     E = H * Dh
