@@ -92,6 +92,19 @@ size_t mivit_wgrad_bf16_workspace_bytes(int M, int N, int K);
 int mivit_wgrad_bf16(const void *dy, int64_t lddy, const void *x, int64_t ldx, int M, int N, int K, float *dW, float *db,
                      void *workspace, size_t workspace_bytes, void *stream);
 
+/* DeepResNetEmbedding in inference mode (helpers/models.py:230-257; ResidualBlock :202-228): conv3x3(1->32)+BN+ReLU,
+ * ResidualBlock(32->64), ResidualBlock(64->128), global average pool, Linear(128->E), fused in one kernel that keeps F
+ * whole frames in LDS.  Eval-mode BatchNorm is folded by the caller: conv weights are pre-scaled by
+ * gamma/sqrt(running_var+eps) and laid out [c_out][tap][c_in] (tap = 3*ky+kx) in the compute dtype (fp32 or bf16);
+ * the biases are the folded shifts (b12/b22 = main-path shift + skip-path shift), fp32.  w0 [32][9], wfc [E][128] fp32.
+ * x [N,P,P] fp32 frames, tokens [N,E] fp32.  Returns 3 if the frame side does not fit
+ * (mivit_deepresnet_eval_supported tells beforehand). */
+int mivit_deepresnet_eval_supported(int dtype, int patch_size);
+int mivit_deepresnet_eval_fwd(int dtype, const float *x, int N, int P, int E, const float *w0, const float *b0,
+                              const void *w11, const void *w12, const void *w1s, const void *w21, const void *w22,
+                              const void *w2s, const float *b11, const float *b12, const float *b21, const float *b22,
+                              const float *wfc, const float *bfc, float *tokens, void *stream);
+
 /* Row LayerNorm over E, eps 1e-5, biased variance, affine (nn.LayerNorm: models.py:88-89,134,301).
  * Row r of the output goes to row  (r / rows_per_seq) * out_seq_stride + r % rows_per_seq + out_row_off  when
  * rows_per_seq > 0 (token assembly behind the regression token, models.py:347), else to row r.

@@ -46,6 +46,8 @@ SYMBOLS = {
     "mivit_wgrad_bf16_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "mivit_wgrad_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                  c_size_t, c_void_p]),
+    "mivit_deepresnet_eval_supported": (c_int, [c_int, c_int]),
+    "mivit_deepresnet_eval_fwd": (c_int, [c_int, c_void_p, c_int, c_int, c_int] + [c_void_p] * 16),
     "mivit_layernorm_fwd": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int64,
                                     c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mivit_layernorm_bwd_workspace_bytes": (c_size_t, [c_int, c_int]),

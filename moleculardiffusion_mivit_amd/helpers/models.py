@@ -193,8 +193,10 @@ class ResidualBlock(nn.Module):
 
 
 class DeepResNetEmbedding(nn.Module):
-    """Per-frame conv stack (reference models.py:230-257).  NOT yet a hand-written HIP kernel: it runs on stock
-    PyTorch-ROCm (MIOpen) and hands pre-norm tokens [B,T,E] to the HIP engine (MIVIT_EMBED_EXTERNAL).
+    """Per-frame conv stack (reference models.py:230-257), handing pre-norm tokens [B,T,E] to the HIP engine
+    (MIVIT_EMBED_EXTERNAL).  Inference (``eval()`` + no grad) runs one fused hand-written HIP kernel with BatchNorm
+    folded into the convolutions (csrc/deepresnet.hip); training (batch-statistics BatchNorm) runs on stock
+    PyTorch-ROCm (MIOpen).
     ``patch_size`` is accepted and ignored, as in the reference."""
     _mivit_embedding = N.EMBED_EXTERNAL
 
@@ -208,8 +210,43 @@ class DeepResNetEmbedding(nn.Module):
         self.global_pool = nn.AdaptiveAvgPool2d((1, 1))
         self.fc = nn.Linear(128, embed_dim)
 
+    # -- inference: eval-mode BatchNorm folded into the convolutions, one fused HIP kernel (csrc/deepresnet.hip) ----
+    @staticmethod
+    def _fold(conv, bn, dtype):
+        a = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+        w = (conv.weight * a.view(-1, 1, 1, 1)).permute(0, 2, 3, 1).reshape(conv.out_channels, -1)   # [co][tap][ci]
+        return w.to(dtype).contiguous(), (bn.bias - bn.running_mean * a).float().contiguous()
+
+    @torch.no_grad()
+    def folded(self, dtype=torch.float32):
+        """BN-folded weight pack for ``ops.deepresnet_eval``; cached until a parameter or running statistic changes."""
+        tensors = list(self.parameters()) + list(self.buffers())
+        key = (dtype, tensors[0].device, tuple(t._version for t in tensors), tuple(t.data_ptr() for t in tensors))
+        if getattr(self, "_fold_key", None) != key:
+            pk = {}
+            pk["w0"], pk["b0"] = self._fold(self.initial_conv, self.bn1, torch.float32)
+            for i, blk in ((1, self.res_block1), (2, self.res_block2)):
+                pk[f"w{i}1"], pk[f"b{i}1"] = self._fold(blk.conv1, blk.bn1, dtype)
+                pk[f"w{i}2"], b2 = self._fold(blk.conv2, blk.bn2, dtype)
+                pk[f"w{i}s"], bs = self._fold(blk.skip[0], blk.skip[1], dtype)
+                pk[f"b{i}2"] = (b2 + bs).contiguous()
+            pk["wfc"], pk["bfc"] = self.fc.weight.float().contiguous(), self.fc.bias.float().contiguous()
+            self.__dict__["_fold_pack"], self.__dict__["_fold_key"] = pk, key
+        return self._fold_pack
+
+    def _native_eval_ok(self, x):
+        if self.training or x.device.type != "cuda" or x.shape[-1] != x.shape[-2]:
+            return False
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            return False
+        dtype = torch.bfloat16 if getattr(self, "_mivit_precision", "fp32") == "bf16" else torch.float32
+        return _ops.deepresnet_eval_supported(dtype, x.shape[-1]) and os.environ.get("MIVIT_NO_DEEPRESNET_EVAL") != "1"
+
     def forward(self, x):
         b, n, h, w = x.shape
+        if self._native_eval_ok(x):
+            dtype = torch.bfloat16 if getattr(self, "_mivit_precision", "fp32") == "bf16" else torch.float32
+            return _ops.deepresnet_eval(x.reshape(b * n, h, w), self.folded(dtype), self.fc.out_features).view(b, n, -1)
         y = x.reshape(b * n, 1, h, w)
         y = self.relu(self.bn1(self.initial_conv(y)))
         y = self.res_block2(self.res_block1(y))
@@ -296,6 +333,7 @@ class GeneralTransformer(nn.Module):
     def set_precision(self, precision: str):
         """'fp32': fp32 MFMA, the 1e-4 parity mode.  'bf16': bf16 MFMA operands / stored activations."""
         self.precision = precision
+        self.embedding.__dict__["_mivit_precision"] = precision      # picks the fused inference kernel's operand type
         self._plan = MivitPlan(precision=precision, **self._plan_kwargs)
         self._flatten()
         return self

@@ -157,3 +157,23 @@ class _Attention(torch.autograd.Function):
 def attention(qkv, num_heads):
     """softmax(q k^T / sqrt(Dh)) v per head, heads merged.  qkv: [B, S, 3E] = [q | k | v] per token."""
     return _Attention.apply(qkv, num_heads)
+
+
+def deepresnet_eval_supported(dtype: torch.dtype, patch_size: int) -> bool:
+    return bool(N.lib.mivit_deepresnet_eval_supported(N.BF16 if dtype == torch.bfloat16 else N.F32, int(patch_size)))
+
+
+def deepresnet_eval(x: torch.Tensor, pack: dict, embed_dim: int) -> torch.Tensor:
+    """Inference-mode DeepResNetEmbedding (reference models.py:230-257) in one fused kernel.
+    x [N,P,P] fp32 frames; ``pack`` = BN-folded weights from ``DeepResNetEmbedding.folded``; returns [N,E] fp32."""
+    _gpu(x)
+    x = x.contiguous().float()
+    n, p, p2 = x.shape
+    assert p == p2, "square frames expected"
+    out = torch.empty(n, embed_dim, device=x.device, dtype=torch.float32)
+    if n == 0:
+        return out
+    order = ("w0", "b0", "w11", "w12", "w1s", "w21", "w22", "w2s", "b11", "b12", "b21", "b22", "wfc", "bfc")
+    N.check(N.lib.mivit_deepresnet_eval_fwd(_dt(pack["w11"]), _p(x), n, p, embed_dim, *[_p(pack[k]) for k in order],
+                                            _p(out), _s(x)), "mivit_deepresnet_eval_fwd")
+    return out
