@@ -105,6 +105,29 @@ int mivit_deepresnet_eval_fwd(int dtype, const float *x, int N, int P, int E, co
                               const void *w2s, const float *b11, const float *b12, const float *b21, const float *b22,
                               const float *wfc, const float *bfc, float *tokens, void *stream);
 
+/* DeepResNetEmbedding in TRAINING mode (batch-statistics BatchNorm2d, helpers/models.py:202-257), forward + backward.
+ * Parameters are passed in the reference's own layouts (Conv2d weight [c_out, c_in, kh, kw] fp32, BatchNorm vectors),
+ * in the order: 0 initial_conv/bn1, 1 res_block1.conv1/bn1, 2 res_block1.conv2/bn2, 3 res_block1.skip.0/.1,
+ * 4 res_block2.conv1/bn1, 5 res_block2.conv2/bn2, 6 res_block2.skip.0/.1.
+ * train_fwd: x [N,P,P] fp32 frames -> tokens [N,E] fp32; updates running_mean / running_var in place
+ * (running = (1-momentum)*running + momentum*batch, unbiased variance; pass null to skip) and leaves the raw
+ * convolution outputs + statistics in `workspace`, which train_bwd of the same step reads (same dtype, N, P, E).
+ * train_bwd: dtokens [N,E] fp32 -> every parameter gradient (fp32, reference layouts, overwritten).  There is no
+ * gradient w.r.t. x (frames are data).  Activations are stored in the compute dtype (fp32 or bf16), statistics,
+ * pooling and the final Linear in fp32.  Returns 3 when the frame side does not fit (ask *_supported first). */
+typedef struct { const float *weight, *gamma, *beta; float *running_mean, *running_var; } mivit_conv_bn;
+typedef struct { mivit_conv_bn conv[7]; const float *fc_weight, *fc_bias; } mivit_deepresnet_params;
+typedef struct { float *weight, *gamma, *beta; } mivit_conv_bn_grad;
+typedef struct { mivit_conv_bn_grad conv[7]; float *fc_weight, *fc_bias; } mivit_deepresnet_grads;
+int mivit_deepresnet_train_supported(int dtype, int patch_size);
+size_t mivit_deepresnet_train_workspace_bytes(int dtype, int N, int P, int E);
+int mivit_deepresnet_train_fwd(int dtype, const mivit_deepresnet_params *params, const float *x, int N, int P, int E,
+                               float momentum, float eps, float *tokens, void *workspace, size_t workspace_bytes,
+                               void *stream);
+int mivit_deepresnet_train_bwd(int dtype, const mivit_deepresnet_params *params, const float *x, const float *dtokens,
+                               int N, int P, int E, float eps, const mivit_deepresnet_grads *grads, void *workspace,
+                               size_t workspace_bytes, void *stream);
+
 /* Row LayerNorm over E, eps 1e-5, biased variance, affine (nn.LayerNorm: models.py:88-89,134,301).
  * Row r of the output goes to row  (r / rows_per_seq) * out_seq_stride + r % rows_per_seq + out_row_off  when
  * rows_per_seq > 0 (token assembly behind the regression token, models.py:347), else to row r.

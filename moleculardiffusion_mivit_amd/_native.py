@@ -24,6 +24,22 @@ class MivitConfig(Structure):
         "output_dim")]
 
 
+class ConvBn(Structure):                    # mivit_conv_bn
+    _fields_ = [(n, c_void_p) for n in ("weight", "gamma", "beta", "running_mean", "running_var")]
+
+
+class DeepResNetParams(Structure):          # mivit_deepresnet_params
+    _fields_ = [("conv", ConvBn * 7), ("fc_weight", c_void_p), ("fc_bias", c_void_p)]
+
+
+class ConvBnGrad(Structure):                # mivit_conv_bn_grad
+    _fields_ = [(n, c_void_p) for n in ("weight", "gamma", "beta")]
+
+
+class DeepResNetGrads(Structure):           # mivit_deepresnet_grads
+    _fields_ = [("conv", ConvBnGrad * 7), ("fc_weight", c_void_p), ("fc_bias", c_void_p)]
+
+
 # every symbol include/mivit_hip.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "mivit_abi_version": (c_int, []),
@@ -48,6 +64,12 @@ SYMBOLS = {
                                  c_size_t, c_void_p]),
     "mivit_deepresnet_eval_supported": (c_int, [c_int, c_int]),
     "mivit_deepresnet_eval_fwd": (c_int, [c_int, c_void_p, c_int, c_int, c_int] + [c_void_p] * 16),
+    "mivit_deepresnet_train_supported": (c_int, [c_int, c_int]),
+    "mivit_deepresnet_train_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "mivit_deepresnet_train_fwd": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p,
+                                           c_void_p, c_size_t, c_void_p]),
+    "mivit_deepresnet_train_bwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p,
+                                           c_void_p, c_size_t, c_void_p]),
     "mivit_layernorm_fwd": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int64,
                                     c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mivit_layernorm_bwd_workspace_bytes": (c_size_t, [c_int, c_int]),

@@ -1,0 +1,906 @@
+// DeepResNetEmbedding, TRAINING mode (batch-statistics BatchNorm) -- reference helpers/models.py:230-257 (+ ResidualBlock
+// :202-228), forward and backward, hand-written for gfx950.
+//
+// Data layout: every activation is a pixel-major matrix [N*P*P, C] (NHWC) of the compute type T (fp32 / bf16) in HBM.
+// The RAW convolution outputs y_i are what is stored; BatchNorm + ReLU (and the residual add) are never materialised:
+// every consumer applies them while it copies its input tile into LDS ("normalise on load"):
+//      ACT1: a  = relu(scale*y + shift)                          ACT2: o = relu(scale*y + shift + scale'*y' + shift')
+//      DY  : dy = k*g + c0 + c1*y   (BatchNorm backward folded into three per-channel coefficients; g = masked upstream
+//                                    gradient, written once by the mask/reduce kernel)
+// A convolution is an implicit GEMM on MFMA over F whole frames that sit in LDS as zero-haloed [pixel][channel] images
+// (rows = output pixels, k = (tap, input channel)); weights are read from an L2-resident [c_out][tap][c_in] pack.  The
+// same kernel serves forward (epilogue: raw output + per-channel sum / sum-of-squares partials for the batch
+// statistics) and data-gradient (flipped-tap pack, DY prologue; the 1x1 skip branch accumulates into the same tile).
+// The weight gradient contracts over pixels: both operands are read TRANSPOSED out of their natural LDS images with
+// ds_read_tr16_b64 (bf16) / scalar reads (fp32); partial sums per workgroup go to a slab that is reduced
+// deterministically (no atomics anywhere).
+#include "common.h"
+#include <algorithm>
+
+namespace {
+
+constexpr int NT = 512, MAXM = 11;          // 8 waves; <= 176 output pixels (11 MFMA row tiles) per workgroup
+constexpr int PADB = 16;                    // bytes of padding per pixel row in LDS (bank spread)
+constexpr int CSTR = 128;                   // stride of the per-channel coefficient tables
+template <typename T> constexpr int pad_el() { return PADB / (int)sizeof(T); }
+template <typename T> constexpr int vec_el() { return 16 / (int)sizeof(T); }
+
+const int DRN_CO[7] = {32, 64, 64, 64, 128, 128, 128};
+const int DRN_CI[7] = {1, 32, 64, 32, 64, 128, 64};
+const int DRN_TAPS[7] = {9, 9, 9, 1, 9, 9, 1};
+// conv / BatchNorm index: 0 initial, 1 block1.conv1, 2 block1.conv2, 3 block1.skip, 4 block2.conv1, 5 block2.conv2, 6 block2.skip
+
+template <typename T>
+__device__ __forceinline__ typename Mma<T>::Frag frag_at(const T *p);
+template <>
+__device__ __forceinline__ float frag_at<float>(const float *p) { return *p; }
+template <>
+__device__ __forceinline__ bf16x8 frag_at<bf16>(const bf16 *p) { return *reinterpret_cast<const bf16x8 *>(p); }
+
+// halo cell of logical row r (= f*P*P + y*P + x); rows past the block's last frame alias the first interior pixel
+__device__ __forceinline__ int halo_index(int r, int rows, int P) {
+    if (r >= rows) return P + 3;
+    const int pp = P * P, f = r / pp, rem = r - f * pp, y = rem / P, x = rem - y * P;
+    return f * (P + 2) * (P + 2) + (y + 1) * (P + 2) + x + 1;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// normalise-on-load
+// ---------------------------------------------------------------------------------------------------------------
+enum { PRO_ACT1 = 0, PRO_ACT2 = 1, PRO_DY = 2 };
+struct TileSrc {
+    const void *p0;     // ACT: y            DY: g
+    const void *p1;     // ACT2: y'          DY: y
+    const float *ca;    // ACT: forward table of BN(y)  [mean | rstd | scale | shift]     DY: backward table [k | c0 | c1]
+    const float *cb;    // ACT2: forward table of BN(y')
+};
+
+template <typename T, int C, int PRO, bool HALO>
+__device__ __forceinline__ void fill_tile(T *tile, const TileSrc &s, size_t row0, int rows, int P, int tid) {
+    constexpr int V = vec_el<T>(), CV = C / V, CS = C + pad_el<T>();
+    const T *p0 = static_cast<const T *>(s.p0) + row0 * C;
+    const T *p1 = static_cast<const T *>(s.p1) + row0 * C;
+    for (int i = tid; i < rows * CV; i += NT) {
+        const int r = i / CV, c = (i - r * CV) * V;
+        float a[V], b[V], o[V];
+        load16(p0 + (size_t)r * C + c, a);
+        if (PRO != PRO_ACT1) load16(p1 + (size_t)r * C + c, b);
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            if (PRO == PRO_ACT1) o[e] = fmaxf(s.ca[2 * CSTR + c + e] * a[e] + s.ca[3 * CSTR + c + e], 0.f);
+            else if (PRO == PRO_ACT2)
+                o[e] = fmaxf(s.ca[2 * CSTR + c + e] * a[e] + s.ca[3 * CSTR + c + e] + s.cb[2 * CSTR + c + e] * b[e] +
+                             s.cb[3 * CSTR + c + e], 0.f);
+            else o[e] = s.ca[c + e] * a[e] + s.ca[CSTR + c + e] + s.ca[2 * CSTR + c + e] * b[e];
+        }
+        store16(tile + (HALO ? halo_index(r, rows, P) : r) * CS + c, o);
+    }
+}
+
+__device__ __forceinline__ void zero_lds(void *p, int bytes, int tid) {
+    for (int i = tid; i < bytes / 16; i += NT) reinterpret_cast<uint4 *>(p)[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// implicit-GEMM core: acc[j][mt] += sum_{tap, ci} in[pixel(mt) + tap][ci] * W[co(j)][tap][ci]   (two column tiles / wave)
+// weight fragments are prefetched one chunk (G k-steps) ahead: they come from L2, the image fragments from LDS
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T, int CIN, int TAPS, int MT>
+__device__ __forceinline__ void conv_accum2(f32x4 (&acc)[2][MT], const T *in, const T *w0, const T *w1,
+                                            const int (&hidx)[MT], int nm, int HW2, int lane) {
+    typedef typename Mma<T>::Frag Frag;
+    constexpr int KS = Mma<T>::KS, KL = sizeof(T) == 2 ? 8 : 1, CS = CIN + pad_el<T>();
+    constexpr int NC = CIN / KS, TOT = TAPS * NC, G = 4, NCH = (TOT + G - 1) / G;
+    static_assert(CIN % KS == 0, "channel count must be a multiple of the MFMA k step");
+    const int g = lane >> 4;
+    w0 += g * KL; w1 += g * KL; in += g * KL;
+    Frag cur[2][G], nxt[2][G];
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+        const int s = j < TOT ? j : TOT - 1;
+        cur[0][j] = frag_at<T>(w0 + s * KS); cur[1][j] = frag_at<T>(w1 + s * KS);
+    }
+#pragma unroll 1
+    for (int ch = 0; ch < NCH; ++ch) {
+        if (ch + 1 < NCH) {
+#pragma unroll
+            for (int j = 0; j < G; ++j) {
+                int s = (ch + 1) * G + j;
+                s = s < TOT ? s : TOT - 1;
+                nxt[0][j] = frag_at<T>(w0 + s * KS); nxt[1][j] = frag_at<T>(w1 + s * KS);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            const int s = ch * G + j;
+            if (s < TOT) {
+                const int tap = s / NC, c0 = (s - tap * NC) * KS;
+                const int off = TAPS == 9 ? ((tap / 3 - 1) * HW2 + (tap % 3 - 1)) : 0;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    if (mt < nm) {
+                        const Frag a = frag_at<T>(in + (hidx[mt] + off) * CS + c0);
+                        acc[0][mt] = Mma<T>::mma(a, cur[0][j], acc[0][mt]);
+                        acc[1][mt] = Mma<T>::mma(a, cur[1][j], acc[1][mt]);
+                    }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < G; ++j) { cur[0][j] = nxt[0][j]; cur[1][j] = nxt[1][j]; }
+    }
+}
+
+struct ConvArgs {
+    int N, P, F;
+    TileSrc A, B;
+    const void *W, *W2;          // [COUT][9][CIN], [COUT][CIN or CIN2]
+    void *out, *out2;            // [N*P*P, COUT]
+    float *stats, *stats2;       // [blocks][2][COUT] partial sum / sum of squares
+};
+
+template <typename T, int COUT, int MT, bool STATS>
+__device__ __forceinline__ void conv_epilogue(const f32x4 (&acc)[2][MT], T *out, float *stats, float *red, size_t row0, int rows,
+                                              int mt0, int nm, int ng, int lane, int wave, int tid) {
+    constexpr int NG = COUT / 32, MQ = 8 / NG;
+    const int g = lane >> 4, cq = lane & 15;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int co = (2 * ng + j) * 16 + cq;
+        float s = 0.f, ss = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+            if (mt < nm) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = (mt0 + mt) * 16 + 4 * g + r;
+                    if (row < rows) {
+                        const float v = acc[j][mt][r];
+                        out[(row0 + row) * COUT + co] = from_f32<T>(v);
+                        s += v; ss += v * v;
+                    }
+                }
+            }
+        if (STATS) {
+            s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
+            ss += __shfl_xor(ss, 16, 64); ss += __shfl_xor(ss, 32, 64);
+            if (g == 0) { red[(wave * 2 + 0) * 32 + j * 16 + cq] = s; red[(wave * 2 + 1) * 32 + j * 16 + cq] = ss; }
+        }
+    }
+    if (STATS) {
+        __syncthreads();
+        for (int t = tid; t < 2 * COUT; t += NT) {
+            const int which = t / COUT, c = t - which * COUT, ngc = c >> 5, cc = c & 31;
+            float v = 0.f;
+#pragma unroll
+            for (int mq = 0; mq < MQ; ++mq) v += red[((mq * NG + ngc) * 2 + which) * 32 + cc];
+            stats[which * COUT + c] = v;
+        }
+        __syncthreads();
+    }
+}
+
+// SECOND: 0 none | 1 second OUTPUT out2 = conv1x1(tile A, W2) (forward skip branch) | 2 second INPUT tile B (CIN2 channels,
+// DY prologue) whose 1x1 convolution accumulates into the same output (data gradient of conv1 + skip)
+template <typename T, int CIN, int COUT, int SECOND, int PRO, int CIN2>
+__global__ __launch_bounds__(NT) void drn_conv_kernel(const ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NG = COUT / 32, MQ = 8 / NG, MT = (MAXM + MQ - 1) / MQ;
+    constexpr int CS = CIN + pad_el<T>(), CS2 = CIN2 + pad_el<T>();
+    constexpr bool STATS = PRO != PRO_DY;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, cq = lane & 15;
+    const int P = a.P, HW2 = P + 2, HP = HW2 * HW2, PP = P * P;
+    const int f0 = blockIdx.x * a.F, nf = min(a.F, a.N - f0), rows = nf * PP, NM = (rows + 15) / 16;
+    const size_t row0 = (size_t)f0 * PP;
+    T *tileA = reinterpret_cast<T *>(smem);
+    T *tileB = tileA + a.F * HP * CS;
+    float *red = reinterpret_cast<float *>(tileB + (SECOND == 2 ? a.F * HP * CS2 : 0));
+
+    zero_lds(smem, (a.F * HP * CS + (SECOND == 2 ? a.F * HP * CS2 : 0)) * (int)sizeof(T), tid);
+    __syncthreads();
+    fill_tile<T, CIN, PRO, true>(tileA, a.A, row0, rows, P, tid);
+    if (SECOND == 2) fill_tile<T, CIN2, PRO_DY, true>(tileB, a.B, row0, rows, P, tid);
+    __syncthreads();
+
+    const int ng = wave % NG, mq = wave / NG, per = (NM + MQ - 1) / MQ, mt0 = mq * per;
+    const int nm = max(0, min(per, NM - mt0));
+    int hidx[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) hidx[mt] = halo_index((mt0 + mt) * 16 + cq, rows, P);
+    f32x4 acc[2][MT];
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) { acc[0][mt] = zero; acc[1][mt] = zero; }
+
+    const T *w = static_cast<const T *>(a.W) + (size_t)(2 * ng * 16 + cq) * 9 * CIN;
+    conv_accum2<T, CIN, 9, MT>(acc, tileA, w, w + (size_t)16 * 9 * CIN, hidx, nm, HW2, lane);
+    if (SECOND == 2) {
+        const T *w2 = static_cast<const T *>(a.W2) + (size_t)(2 * ng * 16 + cq) * CIN2;
+        conv_accum2<T, CIN2, 1, MT>(acc, tileB, w2, w2 + (size_t)16 * CIN2, hidx, nm, HW2, lane);
+    }
+    conv_epilogue<T, COUT, MT, STATS>(acc, static_cast<T *>(a.out), STATS ? a.stats + (size_t)blockIdx.x * 2 * COUT : nullptr, red,
+                                      row0, rows, mt0, nm, ng, lane, wave, tid);
+    if (SECOND == 1) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) { acc[0][mt] = zero; acc[1][mt] = zero; }
+        const T *w2 = static_cast<const T *>(a.W2) + (size_t)(2 * ng * 16 + cq) * CIN;
+        conv_accum2<T, CIN, 1, MT>(acc, tileA, w2, w2 + (size_t)16 * CIN, hidx, nm, HW2, lane);
+        conv_epilogue<T, COUT, MT, STATS>(acc, static_cast<T *>(a.out2), a.stats2 + (size_t)blockIdx.x * 2 * COUT, red, row0, rows,
+                                          mt0, nm, ng, lane, wave, tid);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// first convolution (1 -> 32 channels): VALU, x tile in LDS.  y0 [R,32] + statistics partials [blocks][2][32]
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(NT) void drn_conv0_kernel(const float *x, const float *w0, T *y0, float *stats, int N, int P, int F) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, HW2 = P + 2, HP = HW2 * HW2, PP = P * P;
+    const int f0 = blockIdx.x * F, nf = min(F, N - f0), rows = nf * PP;
+    float *xs = reinterpret_cast<float *>(smem);            // [F][HP]
+    float *red = xs + F * HP;                               // [16][2][32]
+    for (int i = tid; i < F * HP; i += NT) xs[i] = 0.f;
+    __syncthreads();
+    for (int i = tid; i < rows; i += NT) xs[halo_index(i, rows, P)] = x[(size_t)f0 * PP + i];
+    __syncthreads();
+    const int co = tid & 31, rs = tid >> 5;
+    float w[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) w[t] = w0[co * 9 + t];
+    float s = 0.f, ss = 0.f;
+    for (int r = rs; r < rows; r += NT / 32) {
+        const int h = halo_index(r, rows, P);
+        float v = 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) v += xs[h + (t / 3 - 1) * HW2 + (t % 3 - 1)] * w[t];
+        y0[((size_t)f0 * PP + r) * 32 + co] = from_f32<T>(v);
+        s += v; ss += v * v;
+    }
+    red[(rs * 2 + 0) * 32 + co] = s; red[(rs * 2 + 1) * 32 + co] = ss;
+    __syncthreads();
+    if (tid < 64) {
+        float v = 0.f;
+        for (int k = 0; k < NT / 32; ++k) v += red[(k * 2 + (tid >> 5)) * 32 + (tid & 31)];
+        stats[(size_t)blockIdx.x * 64 + tid] = v;
+    }
+}
+
+// weight gradient of the first convolution: dW0[co][tap] = sum_r dy0[r][co] * x[pixel(r) + tap]
+template <typename T>
+__global__ __launch_bounds__(NT) void drn_wgrad0_kernel(const float *x, const TileSrc d, float *slab, int N, int P, int F, int ngroups) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, HW2 = P + 2, HP = HW2 * HW2, PP = P * P;
+    float *xs = reinterpret_cast<float *>(smem);            // [F][HP]
+    float *red = xs + F * HP;                               // [16][32*9]
+    const int co = tid & 31, rs = tid >> 5;
+    const float k = d.ca[co], c0 = d.ca[CSTR + co], c1 = d.ca[2 * CSTR + co];
+    float acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = 0.f;
+    for (int i = tid; i < F * HP; i += NT) xs[i] = 0.f;
+    for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        __syncthreads();
+        const int f0 = grp * F, nf = min(F, N - f0), rows = nf * PP;
+        for (int i = tid; i < rows; i += NT) xs[halo_index(i, rows, P)] = x[(size_t)f0 * PP + i];
+        __syncthreads();
+        const T *g = static_cast<const T *>(d.p0) + (size_t)f0 * PP * 32, *y = static_cast<const T *>(d.p1) + (size_t)f0 * PP * 32;
+        for (int r = rs; r < rows; r += NT / 32) {
+            const float dy = k * to_f32(g[(size_t)r * 32 + co]) + c0 + c1 * to_f32(y[(size_t)r * 32 + co]);
+            const int h = halo_index(r, rows, P);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc[t] += dy * xs[h + (t / 3 - 1) * HW2 + (t % 3 - 1)];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 9; ++t) red[rs * 288 + co * 9 + t] = acc[t];
+    __syncthreads();
+    if (tid < 288) {
+        float v = 0.f;
+        for (int kk = 0; kk < NT / 32; ++kk) v += red[kk * 288 + tid];
+        slab[(size_t)blockIdx.x * 288 + tid] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// BatchNorm statistics: partial [nb][2][C] -> forward table [mean | rstd | scale | shift] + running-statistics update
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void drn_bn_finalize_kernel(const float *part, int nb, int C, double count, const float *gamma,
+                                                             const float *beta, float *rmean, float *rvar, float momentum,
+                                                             float eps, float *coef) {
+    __shared__ double red[2][4][128];
+    const int c = threadIdx.x & 127, sl = threadIdx.x >> 7;
+    double s = 0.0, q = 0.0;
+    if (c < C)
+        for (int b = sl; b < nb; b += 4) { s += part[((size_t)b * 2 + 0) * C + c]; q += part[((size_t)b * 2 + 1) * C + c]; }
+    red[0][sl][c] = s; red[1][sl][c] = q;
+    __syncthreads();
+    if (sl == 0 && c < C) {
+        s = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
+        q = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
+        const double mean = s / count;
+        double var = q / count - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float scale = gamma[c] * rstd;
+        coef[c] = (float)mean; coef[CSTR + c] = rstd; coef[2 * CSTR + c] = scale; coef[3 * CSTR + c] = beta[c] - (float)mean * scale;
+        if (rmean) {
+            rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
+            rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)(var * count / (count > 1.0 ? count - 1.0 : 1.0));
+        }
+    }
+}
+
+// partial [nb][W] -> [nb2][W]  (out[b2] = sum of the parts b = b2, b2 + nb2, ...), used when a kernel left many partials
+__global__ void drn_part_reduce_kernel(const float *part, int nb, int W, float *out, int nb2) {
+    const int w = blockIdx.y * blockDim.x + threadIdx.x, b2 = blockIdx.x;
+    if (w >= W) return;
+    double s = 0.0;
+    for (int b = b2; b < nb; b += nb2) s += part[(size_t)b * W + w];
+    out[(size_t)b2 * W + w] = (float)s;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// global average pooling of o2 = relu(BN(y22) + BN(y2s)):  pooled [N,128] fp32
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(128) void drn_pool_kernel(const T *ya, const T *yb, const float *ca, const float *cb, float *pooled, int PP) {
+    const int c = threadIdx.x;
+    const size_t base = (size_t)blockIdx.x * PP * 128;
+    const float sa = ca[2 * CSTR + c], ha = ca[3 * CSTR + c], sb = cb[2 * CSTR + c], hb = cb[3 * CSTR + c];
+    float s = 0.f;
+    for (int p = 0; p < PP; ++p)
+        s += fmaxf(sa * to_f32(ya[base + (size_t)p * 128 + c]) + ha + sb * to_f32(yb[base + (size_t)p * 128 + c]) + hb, 0.f);
+    pooled[(size_t)blockIdx.x * 128 + c] = s / (float)PP;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// backward, step 1 of every BatchNorm: g = upstream * [activation > 0]  (written), and per-channel partial sums
+//      s1 = sum g,  sa = sum g*y,  sb = sum g*y'      -> part [blocks][3][C]
+// TOP: upstream = dpooled[frame][c] / (P*P) (gradient of the average pooling) instead of a [R,C] tensor
+// ---------------------------------------------------------------------------------------------------------------
+struct MaskArgs {
+    const void *up; const void *y; const void *y2; const float *ca; const float *cb;
+    void *g; float *part; int64_t R; int PP; int rows_per_block;
+};
+
+template <typename T, int C, bool DUAL, bool TOP>
+__global__ __launch_bounds__(NT) void drn_mask_reduce_kernel(const MaskArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int V = vec_el<T>(), CV = C / V, NRS = NT / CV;
+    float *red = reinterpret_cast<float *>(smem);             // [NRS][3][C]
+    const int tid = threadIdx.x, cv = tid % CV, rs = tid / CV, c = cv * V;
+    float sA[V], hA[V], sB[V], hB[V], s1[V], sa[V], sb[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+        sA[e] = a.ca[2 * CSTR + c + e]; hA[e] = a.ca[3 * CSTR + c + e];
+        sB[e] = DUAL ? a.cb[2 * CSTR + c + e] : 0.f; hB[e] = DUAL ? a.cb[3 * CSTR + c + e] : 0.f;
+        s1[e] = sa[e] = sb[e] = 0.f;
+    }
+    const int64_t rbeg = (int64_t)blockIdx.x * a.rows_per_block;
+    const int64_t rend = rbeg + a.rows_per_block < a.R ? rbeg + a.rows_per_block : a.R;
+    const T *y = static_cast<const T *>(a.y), *y2 = static_cast<const T *>(a.y2);
+    T *g = static_cast<T *>(a.g);
+    const float inv = 1.f / (float)a.PP;
+    for (int64_t r = rbeg + rs; r < rend; r += NRS) {
+        float yv[V], y2v[V], up[V], gv[V];
+        load16(y + r * C + c, yv);
+        if (DUAL) load16(y2 + r * C + c, y2v);
+        if (TOP) {
+            const float *dp = static_cast<const float *>(a.up) + (r / a.PP) * C + c;
+#pragma unroll
+            for (int e = 0; e < V; ++e) up[e] = dp[e] * inv;
+        } else {
+            load16(static_cast<const T *>(a.up) + r * C + c, up);
+        }
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            float act = sA[e] * yv[e] + hA[e];
+            if (DUAL) act += sB[e] * y2v[e] + hB[e];
+            gv[e] = act > 0.f ? up[e] : 0.f;
+            s1[e] += gv[e]; sa[e] += gv[e] * yv[e];
+            if (DUAL) sb[e] += gv[e] * y2v[e];
+        }
+        store16(g + r * C + c, gv);
+    }
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+        red[(rs * 3 + 0) * C + c + e] = s1[e]; red[(rs * 3 + 1) * C + c + e] = sa[e]; red[(rs * 3 + 2) * C + c + e] = sb[e];
+    }
+    __syncthreads();
+    for (int t = tid; t < 3 * C; t += NT) {
+        float v = 0.f;
+        for (int k = 0; k < NRS; ++k) v += red[k * 3 * C + t];
+        a.part[(size_t)blockIdx.x * 3 * C + t] = v;
+    }
+}
+
+// partial [nb][3][C] -> d gamma, d beta and the DY table [k | c0 | c1]:  dy = k*g + c0 + c1*y
+__global__ __launch_bounds__(NT) void drn_bn_bwd_finalize_kernel(const float *part, int nb, int C, int which, double count,
+                                                                 const float *gamma, const float *fcoef, float *bcoef,
+                                                                 float *dgamma, float *dbeta) {
+    __shared__ double red[2][4][128];
+    const int c = threadIdx.x & 127, sl = threadIdx.x >> 7;
+    double s = 0.0, q = 0.0;
+    if (c < C)
+        for (int b = sl; b < nb; b += 4) { s += part[((size_t)b * 3 + 0) * C + c]; q += part[((size_t)b * 3 + which) * C + c]; }
+    red[0][sl][c] = s; red[1][sl][c] = q;
+    __syncthreads();
+    if (sl == 0 && c < C) {
+        s = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
+        q = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
+        const double mean = fcoef[c], rstd = fcoef[CSTR + c];
+        const double dg = rstd * (q - mean * s);
+        const double k = (double)gamma[c] * rstd;
+        const double c1 = -k * rstd * dg / count;
+        bcoef[c] = (float)k; bcoef[CSTR + c] = (float)(-k * s / count - c1 * mean); bcoef[2 * CSTR + c] = (float)c1;
+        dgamma[c] = (float)dg; dbeta[c] = (float)s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// weight gradient: dW[co][tap][ci] = sum_r dy[r][co] * a[pixel(r) + tap][ci]      (contraction over pixels)
+// grid (G, TAPS/TPP): a workgroup walks frame groups blockIdx.x, +G, ... holding TPP taps (one kernel row) of the whole
+// [COUT x CIN] block in accumulators; 8 waves = 4 (c_out) x 2 (c_in)
+// ---------------------------------------------------------------------------------------------------------------
+struct WgradArgs {
+    int N, P, F, ngroups;
+    TileSrc A;       // input activation of the convolution (ACT1 / ACT2)
+    TileSrc D;       // dy (DY)
+    float *slab;     // [gridDim.x][COUT][TAPS][CIN]
+};
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+__device__ __forceinline__ bf16x8 tr_pair(const bf16 *lo, const bf16 *hi) {
+    typedef __attribute__((address_space(3))) s16x4 lds_v4;
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4 *)(lo));
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4 *)(hi));
+    struct { s16x4 a, b; } pr = {a, b};
+    return __builtin_bit_cast(bf16x8, pr);
+}
+
+template <typename T, int CIN, int COUT, int TAPS, int PROA>
+__global__ __launch_bounds__(NT) void drn_wgrad_kernel(const WgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int TPP = TAPS == 9 ? 3 : 1, WM = COUT / 64, WN = CIN / 32;
+    constexpr int CSA = CIN + pad_el<T>(), CSD = COUT + pad_el<T>();
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, cq = lane & 15, q = cq >> 2, p = cq & 3;
+    const int wm = wave & 3, wn = wave >> 2;
+    const int P = a.P, HW2 = P + 2, HP = HW2 * HW2, PP = P * P;
+    const int RP = (a.F * PP + 31) / 32 * 32;
+    T *tileA = reinterpret_cast<T *>(smem);                     // [F*HP][CSA]  zero-haloed input activation
+    T *tileD = tileA + a.F * HP * CSA;                          // [RP][CSD]    dy, plain row order, zero beyond `rows`
+    int *hmap = reinterpret_cast<int *>(tileD + RP * CSD);      // [RP]         row -> halo cell
+    f32x4 acc[TPP][WM][WN];
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < TPP; ++t)
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j) acc[t][i][j] = zero;
+    zero_lds(smem, (a.F * HP * CSA + RP * CSD) * (int)sizeof(T), tid);
+    int prev_rows = RP;
+    for (int grp = blockIdx.x; grp < a.ngroups; grp += gridDim.x) {
+        __syncthreads();
+        const int f0 = grp * a.F, nf = min(a.F, a.N - f0), rows = nf * PP;
+        const size_t row0 = (size_t)f0 * PP;
+        fill_tile<T, CIN, PROA, true>(tileA, a.A, row0, rows, P, tid);
+        fill_tile<T, COUT, PRO_DY, false>(tileD, a.D, row0, rows, P, tid);
+        if (rows < prev_rows)                                    // a shorter (last) group: clear the stale dy rows
+            for (int i = tid; i < (prev_rows - rows) * CSD; i += NT) tileD[rows * CSD + i] = from_f32<T>(0.f);
+        prev_rows = rows;
+        for (int r = tid; r < RP; r += NT) hmap[r] = halo_index(r, rows, P);
+        __syncthreads();
+        const int ksteps = (rows + 31) / 32;
+#pragma unroll 1
+        for (int ks = 0; ks < ksteps; ++ks) {
+            const int r0 = ks * 32;
+            if constexpr (sizeof(T) == 2) {
+                const int rlo = r0 + 4 * g + q, rhi = rlo + 16;
+                bf16x8 af[WM];
+#pragma unroll
+                for (int i = 0; i < WM; ++i) {
+                    const int co0 = (wm * WM + i) * 16 + 4 * p;
+                    af[i] = tr_pair(reinterpret_cast<const bf16 *>(tileD) + rlo * CSD + co0, reinterpret_cast<const bf16 *>(tileD) + rhi * CSD + co0);
+                }
+                const int hl = hmap[rlo], hh = hmap[rhi];
+#pragma unroll
+                for (int t = 0; t < TPP; ++t) {
+                    const int tap = blockIdx.y * TPP + t;
+                    const int off = TAPS == 9 ? ((tap / 3 - 1) * HW2 + (tap % 3 - 1)) : 0;
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) {
+                        const int ci0 = (wn * WN + j) * 16 + 4 * p;
+                        const bf16x8 bfr = tr_pair(reinterpret_cast<const bf16 *>(tileA) + (hl + off) * CSA + ci0,
+                                                   reinterpret_cast<const bf16 *>(tileA) + (hh + off) * CSA + ci0);
+#pragma unroll
+                        for (int i = 0; i < WM; ++i) acc[t][i][j] = Mma<bf16>::mma(af[i], bfr, acc[t][i][j]);
+                    }
+                }
+            } else {
+#pragma unroll 2
+                for (int ss = 0; ss < 8; ++ss) {
+                    const int r = r0 + 4 * ss + g;
+                    float af[WM];
+#pragma unroll
+                    for (int i = 0; i < WM; ++i) af[i] = reinterpret_cast<const float *>(tileD)[r * CSD + (wm * WM + i) * 16 + cq];
+                    const int h = hmap[r];
+#pragma unroll
+                    for (int t = 0; t < TPP; ++t) {
+                        const int tap = blockIdx.y * TPP + t;
+                        const int off = TAPS == 9 ? ((tap / 3 - 1) * HW2 + (tap % 3 - 1)) : 0;
+#pragma unroll
+                        for (int j = 0; j < WN; ++j) {
+                            const float bfr = reinterpret_cast<const float *>(tileA)[(h + off) * CSA + (wn * WN + j) * 16 + cq];
+#pragma unroll
+                            for (int i = 0; i < WM; ++i) acc[t][i][j] = Mma<float>::mma(af[i], bfr, acc[t][i][j]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    float *slab = a.slab + (size_t)blockIdx.x * COUT * TAPS * CIN;
+#pragma unroll
+    for (int t = 0; t < TPP; ++t) {
+        const int tap = blockIdx.y * TPP + t;
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int co = (wm * WM + i) * 16 + 4 * g + r, ci = (wn * WN + j) * 16 + cq;
+                    slab[((size_t)co * TAPS + tap) * CIN + ci] = acc[t][i][j][r];
+                }
+    }
+}
+
+// slab [nparts][COUT][TAPS][CIN] -> dW in the reference layout [COUT][CIN][TAPS] (Conv2d weight, taps = ky*3+kx)
+__global__ void drn_wgrad_reduce_kernel(const float *slab, int nparts, int COUT, int TAPS, int CIN, float *dW) {
+    const int n = COUT * TAPS * CIN, idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    float s = 0.f;
+    for (int k = 0; k < nparts; ++k) s += slab[(size_t)k * n + idx];
+    const int ci = idx % CIN, tap = (idx / CIN) % TAPS, co = idx / (CIN * TAPS);
+    dW[((size_t)co * CIN + ci) * TAPS + tap] = s;
+}
+
+// reference layout [COUT][CIN][TAPS] fp32 -> forward pack [COUT][TAPS][CIN] and data-gradient pack [CIN][TAPS-1-tap][COUT]
+template <typename T>
+__global__ void drn_pack_kernel(const float *W, int COUT, int CIN, int TAPS, T *Wf, T *Wd) {
+    const int n = COUT * CIN * TAPS, idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const int tap = idx % TAPS, ci = (idx / TAPS) % CIN, co = idx / (TAPS * CIN);
+    const T v = from_f32<T>(W[idx]);
+    Wf[((size_t)co * TAPS + tap) * CIN + ci] = v;
+    Wd[((size_t)ci * TAPS + (TAPS - 1 - tap)) * COUT + co] = v;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------
+struct DrnWs {
+    size_t y[7], wf[7], wd[7], fcoef, bcoef, pooled, dpooled, part, part2, X[3], slab, lin, total;
+    int parts_cap;
+};
+
+constexpr int MASK_ROWS = 512, WG_GROUPS = 128, PART_MAX = 2048;
+
+size_t tile_bytes(int dtype, int P, int F, int C) { return (size_t)F * (P + 2) * (P + 2) * (C * dtype_size(dtype) + PADB); }
+
+// frames per workgroup: as many as fit 176 output pixels and the LDS need(F) <= 160 KB
+template <typename NeedFn>
+int frames_fit(int P, NeedFn need) {
+    int F = (MAXM * 16) / (P * P);
+    while (F >= 1 && need(F) > (size_t)160 * 1024) --F;
+    return F;
+}
+int conv_frames(int dtype, int P, int CIN, int CIN2) {
+    return frames_fit(P, [&](int F) { return tile_bytes(dtype, P, F, CIN) + (CIN2 ? tile_bytes(dtype, P, F, CIN2) : 0) + 8 * 2 * 32 * 4; });
+}
+size_t wgrad_lds(int dtype, int P, int F, int CIN, int COUT) {
+    const int RP = (F * P * P + 31) / 32 * 32;
+    return tile_bytes(dtype, P, F, CIN) + (size_t)RP * (COUT * dtype_size(dtype) + PADB) + (size_t)RP * 4;
+}
+int wgrad_frames(int dtype, int P, int CIN, int COUT) {
+    return frames_fit(P, [&](int F) { return wgrad_lds(dtype, P, F, CIN, COUT); });
+}
+int conv0_frames(int P) { return std::max(1, std::min(512 / (P * P), 64)); }
+
+bool drn_train_supported(int dtype, int P) {
+    if (P < 3) return false;
+    return conv_frames(dtype, P, 128, 128) >= 1 && wgrad_frames(dtype, P, 128, 128) >= 1;
+}
+
+DrnWs make_ws(int dtype, int N, int P, int E) {
+    DrnWs w{};
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off += align_up(bytes, 256); return o; };
+    const size_t R = (size_t)N * P * P, es = dtype_size(dtype);
+    for (int i = 0; i < 7; ++i) w.y[i] = take(R * DRN_CO[i] * es);
+    for (int i = 0; i < 7; ++i) { w.wf[i] = take((size_t)DRN_CO[i] * DRN_CI[i] * DRN_TAPS[i] * es); w.wd[i] = take((size_t)DRN_CO[i] * DRN_CI[i] * DRN_TAPS[i] * es); }
+    w.fcoef = take(7 * 4 * CSTR * 4);
+    w.bcoef = take(7 * 3 * CSTR * 4);
+    w.pooled = take((size_t)N * 128 * 4);
+    w.dpooled = take((size_t)N * 128 * 4);
+    w.parts_cap = std::max(N, (int)((R + MASK_ROWS - 1) / MASK_ROWS)) + 8;
+    w.part = take((size_t)w.parts_cap * 3 * 128 * 4 * 2);
+    w.part2 = take((size_t)PART_MAX * 3 * 128 * 4);
+    for (int i = 0; i < 3; ++i) w.X[i] = take(R * 128 * es);
+    w.slab = take((size_t)WG_GROUPS * 128 * 9 * 128 * 4);
+    w.lin = take(linear_wgrad_ws_bytes(N, E, 128));
+    w.total = off;
+    return w;
+}
+
+inline void *at(void *ws, size_t off) { return static_cast<char *>(ws) + off; }
+
+template <typename K>
+int set_lds(K kernel, size_t bytes) {
+    MIVIT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return 0;
+}
+#define RC(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
+
+struct Ctx {
+    int dtype, N, P, E;
+    float eps, momentum;
+    void *ws; DrnWs w; hipStream_t s;
+    const mivit_deepresnet_params *prm;
+    float *fco(int i) const { return static_cast<float *>(at(ws, w.fcoef)) + (size_t)i * 4 * CSTR; }
+    float *bco(int i) const { return static_cast<float *>(at(ws, w.bcoef)) + (size_t)i * 3 * CSTR; }
+    void *y(int i) const { return at(ws, w.y[i]); }
+    float *part() const { return static_cast<float *>(at(ws, w.part)); }
+    double count() const { return (double)N * P * P; }
+};
+
+// many partials -> at most PART_MAX (deterministic), returns the pointer / count the finalize kernels should read
+int squeeze_parts(const Ctx &c, const float *&part, int &nb, int W) {
+    if (nb <= PART_MAX) return 0;
+    float *out = static_cast<float *>(at(c.ws, c.w.part2));
+    hipLaunchKernelGGL(drn_part_reduce_kernel, dim3(PART_MAX, ceil_div(W, 128)), dim3(128), 0, c.s, part, nb, W, out, PART_MAX);
+    MIVIT_LAUNCH_CHECK();
+    part = out; nb = PART_MAX;
+    return 0;
+}
+
+int bn_finalize(const Ctx &c, int i, const float *part, int nb) {
+    const int C = DRN_CO[i];
+    RC(squeeze_parts(c, part, nb, 2 * C));
+    const mivit_conv_bn &b = c.prm->conv[i];
+    hipLaunchKernelGGL(drn_bn_finalize_kernel, dim3(1), dim3(NT), 0, c.s, part, nb, C, c.count(), b.gamma, b.beta, b.running_mean,
+                       b.running_var, c.momentum, c.eps, c.fco(i));
+    MIVIT_LAUNCH_CHECK();
+    return 0;
+}
+
+template <typename T, int CIN, int COUT, int SECOND, int PRO, int CIN2>
+int run_conv(const Ctx &c, const ConvArgs &proto, int *nblocks) {
+    ConvArgs a = proto;
+    a.N = c.N; a.P = c.P;
+    a.F = conv_frames(c.dtype, c.P, CIN, SECOND == 2 ? CIN2 : 0);
+    const size_t lds = tile_bytes(c.dtype, c.P, a.F, CIN) + (SECOND == 2 ? tile_bytes(c.dtype, c.P, a.F, CIN2) : 0) + 8 * 2 * 32 * 4;
+    auto kern = drn_conv_kernel<T, CIN, COUT, SECOND, PRO, CIN2>;
+    RC(set_lds(kern, lds));
+    const int blocks = ceil_div(c.N, a.F);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(NT), lds, c.s, a);
+    MIVIT_LAUNCH_CHECK();
+    if (nblocks) *nblocks = blocks;
+    return 0;
+}
+
+template <typename T>
+int pack_weights(const Ctx &c) {
+    for (int i = 1; i < 7; ++i) {
+        const int n = DRN_CO[i] * DRN_CI[i] * DRN_TAPS[i];
+        hipLaunchKernelGGL(drn_pack_kernel<T>, dim3(ceil_div(n, 256)), dim3(256), 0, c.s, c.prm->conv[i].weight, DRN_CO[i], DRN_CI[i],
+                           DRN_TAPS[i], static_cast<T *>(at(c.ws, c.w.wf[i])), static_cast<T *>(at(c.ws, c.w.wd[i])));
+        MIVIT_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+template <typename T>
+int forward_t(const Ctx &c, const float *x, float *tokens) {
+    RC(pack_weights<T>(c));
+    float *part = c.part(), *part_b = part + (size_t)c.w.parts_cap * 3 * 128;
+    int nb = 0;
+    {   // conv0
+        const int F = conv0_frames(c.P), HP = (c.P + 2) * (c.P + 2);
+        nb = ceil_div(c.N, F);
+        const size_t lds = (size_t)F * HP * 4 + 16 * 2 * 32 * 4;
+        hipLaunchKernelGGL(drn_conv0_kernel<T>, dim3(nb), dim3(NT), lds, c.s, x, c.prm->conv[0].weight, static_cast<T *>(c.y(0)), part,
+                           c.N, c.P, F);
+        MIVIT_LAUNCH_CHECK();
+        RC(bn_finalize(c, 0, part, nb));
+    }
+    ConvArgs a{};
+    // block 1: conv1 (32->64) + skip (1x1) from a0 = relu(BN0(y0))
+    a = ConvArgs{};
+    a.A = TileSrc{c.y(0), nullptr, c.fco(0), nullptr};
+    a.W = at(c.ws, c.w.wf[1]); a.W2 = at(c.ws, c.w.wf[3]); a.out = c.y(1); a.out2 = c.y(3); a.stats = part; a.stats2 = part_b;
+    RC((run_conv<T, 32, 64, 1, PRO_ACT1, 32>(c, a, &nb)));
+    RC(bn_finalize(c, 1, part, nb)); RC(bn_finalize(c, 3, part_b, nb));
+    // block 1: conv2 (64->64) from relu(BN1(y11))
+    a = ConvArgs{};
+    a.A = TileSrc{c.y(1), nullptr, c.fco(1), nullptr};
+    a.W = at(c.ws, c.w.wf[2]); a.out = c.y(2); a.stats = part;
+    RC((run_conv<T, 64, 64, 0, PRO_ACT1, 64>(c, a, &nb)));
+    RC(bn_finalize(c, 2, part, nb));
+    // block 2: conv1 (64->128) + skip from o1 = relu(BN2(y12) + BN3(y1s))
+    a = ConvArgs{};
+    a.A = TileSrc{c.y(2), c.y(3), c.fco(2), c.fco(3)};
+    a.W = at(c.ws, c.w.wf[4]); a.W2 = at(c.ws, c.w.wf[6]); a.out = c.y(4); a.out2 = c.y(6); a.stats = part; a.stats2 = part_b;
+    RC((run_conv<T, 64, 128, 1, PRO_ACT2, 64>(c, a, &nb)));
+    RC(bn_finalize(c, 4, part, nb)); RC(bn_finalize(c, 6, part_b, nb));
+    // block 2: conv2 (128->128)
+    a = ConvArgs{};
+    a.A = TileSrc{c.y(4), nullptr, c.fco(4), nullptr};
+    a.W = at(c.ws, c.w.wf[5]); a.out = c.y(5); a.stats = part;
+    RC((run_conv<T, 128, 128, 0, PRO_ACT1, 128>(c, a, &nb)));
+    RC(bn_finalize(c, 5, part, nb));
+    // pooling + fc
+    float *pooled = static_cast<float *>(at(c.ws, c.w.pooled));
+    hipLaunchKernelGGL(drn_pool_kernel<T>, dim3(c.N), dim3(128), 0, c.s, static_cast<const T *>(c.y(5)), static_cast<const T *>(c.y(6)),
+                       c.fco(5), c.fco(6), pooled, c.P * c.P);
+    MIVIT_LAUNCH_CHECK();
+    LinearFwdArgs l{};
+    l.dtype = MIVIT_F32; l.x = pooled; l.x_is_f32 = 1; l.ldx = 128; l.W = c.prm->fc_weight; l.bias = c.prm->fc_bias;
+    l.M = c.N; l.N = c.E; l.K = 128; l.act = MIVIT_ACT_NONE; l.y = tokens; l.ldy = c.E; l.y_is_f32 = 1;
+    return launch_linear_fwd(l, c.s);
+}
+
+template <typename T, int C, bool DUAL, bool TOP>
+int run_mask(const Ctx &c, const void *up, int ya, int yb, void *g, int *nblocks) {
+    constexpr int V = vec_el<T>(), NRS = NT / (C / V);
+    MaskArgs m{up, c.y(ya), DUAL ? c.y(yb) : nullptr, c.fco(ya), DUAL ? c.fco(yb) : nullptr, g, c.part(), (int64_t)c.N * c.P * c.P,
+               c.P * c.P, MASK_ROWS};
+    const int blocks = (int)((m.R + MASK_ROWS - 1) / MASK_ROWS);
+    const size_t lds = (size_t)NRS * 3 * C * 4;
+    auto kern = drn_mask_reduce_kernel<T, C, DUAL, TOP>;
+    RC(set_lds(kern, lds));
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(NT), lds, c.s, m);
+    MIVIT_LAUNCH_CHECK();
+    *nblocks = blocks;
+    return 0;
+}
+
+int bn_bwd_finalize(const Ctx &c, int i, int which, int nb, const mivit_deepresnet_grads *gr) {
+    const int C = DRN_CO[i];
+    const float *part = c.part();
+    RC(squeeze_parts(c, part, nb, 3 * C));
+    hipLaunchKernelGGL(drn_bn_bwd_finalize_kernel, dim3(1), dim3(NT), 0, c.s, part, nb, C, which, c.count(), c.prm->conv[i].gamma,
+                       c.fco(i), c.bco(i), gr->conv[i].gamma, gr->conv[i].beta);
+    MIVIT_LAUNCH_CHECK();
+    return 0;
+}
+
+template <typename T, int CIN, int COUT, int TAPS, int PROA>
+int run_wgrad(const Ctx &c, const TileSrc &A, const TileSrc &D, float *dW) {
+    WgradArgs a{};
+    a.N = c.N; a.P = c.P; a.F = wgrad_frames(c.dtype, c.P, CIN, COUT);
+    a.ngroups = ceil_div(c.N, a.F);
+    a.A = A; a.D = D; a.slab = static_cast<float *>(at(c.ws, c.w.slab));
+    const int G = std::min(a.ngroups, WG_GROUPS);
+    const size_t lds = wgrad_lds(c.dtype, c.P, a.F, CIN, COUT);
+    auto kern = drn_wgrad_kernel<T, CIN, COUT, TAPS, PROA>;
+    RC(set_lds(kern, lds));
+    hipLaunchKernelGGL(kern, dim3(G, TAPS == 9 ? 3 : 1), dim3(NT), lds, c.s, a);
+    MIVIT_LAUNCH_CHECK();
+    const int n = COUT * TAPS * CIN;
+    hipLaunchKernelGGL(drn_wgrad_reduce_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, c.s, a.slab, G, COUT, TAPS, CIN, dW);
+    MIVIT_LAUNCH_CHECK();
+    return 0;
+}
+
+template <typename T>
+int backward_t(const Ctx &c, const float *x, const float *dtokens, const mivit_deepresnet_grads *gr) {
+    float *pooled = static_cast<float *>(at(c.ws, c.w.pooled)), *dpooled = static_cast<float *>(at(c.ws, c.w.dpooled));
+    // fc: dpooled = dtokens W ; dW = dtokens^T pooled ; db
+    LinearDgradArgs d{};
+    d.dtype = MIVIT_F32; d.dy = dtokens; d.dy_is_f32 = 1; d.lddy = c.E; d.W = c.prm->fc_weight; d.M = c.N; d.N = c.E; d.K = 128;
+    d.act = MIVIT_ACT_NONE; d.dx = dpooled; d.lddx = 128; d.dx_is_f32 = 1;
+    RC(launch_linear_dgrad(d, c.s));
+    LinearWgradArgs wg{};
+    wg.dtype = MIVIT_F32; wg.dy = dtokens; wg.dy_is_f32 = 1; wg.lddy = c.E; wg.x = pooled; wg.x_is_f32 = 1; wg.ldx = 128;
+    wg.M = c.N; wg.N = c.E; wg.K = 128; wg.dW = gr->fc_weight; wg.db = gr->fc_bias; wg.ws = at(c.ws, c.w.lin);
+    wg.ws_bytes = linear_wgrad_ws_bytes(c.N, c.E, 128);
+    RC(launch_linear_wgrad(wg, c.s));
+
+    void *X1 = at(c.ws, c.w.X[0]), *X2 = at(c.ws, c.w.X[1]), *X3 = at(c.ws, c.w.X[2]);
+    int nb = 0;
+    // ---- top: g2 = pool-gradient * [o2 > 0] -> X1 ; BatchNorm 5 (conv2) and 6 (skip) of block 2
+    RC((run_mask<T, 128, true, true>(c, dpooled, 5, 6, X1, &nb)));
+    RC(bn_bwd_finalize(c, 5, 1, nb, gr)); RC(bn_bwd_finalize(c, 6, 2, nb, gr));
+    const TileSrc dy22{X1, c.y(5), c.bco(5), nullptr}, dy2s{X1, c.y(6), c.bco(6), nullptr};
+    const TileSrc a21{c.y(4), nullptr, c.fco(4), nullptr}, o1{c.y(2), c.y(3), c.fco(2), c.fco(3)};
+    RC((run_wgrad<T, 128, 128, 9, PRO_ACT1>(c, a21, dy22, gr->conv[5].weight)));
+    RC((run_wgrad<T, 64, 128, 1, PRO_ACT2>(c, o1, dy2s, gr->conv[6].weight)));
+    ConvArgs a{};
+    a.A = dy22; a.W = at(c.ws, c.w.wd[5]); a.out = X2;                                   // d a21 -> X2
+    RC((run_conv<T, 128, 128, 0, PRO_DY, 128>(c, a, nullptr)));
+    // ---- BatchNorm 4 (block 2 conv1): g21 in place in X2
+    RC((run_mask<T, 128, false, false>(c, X2, 4, 4, X2, &nb)));
+    RC(bn_bwd_finalize(c, 4, 1, nb, gr));
+    const TileSrc dy21{X2, c.y(4), c.bco(4), nullptr};
+    RC((run_wgrad<T, 64, 128, 9, PRO_ACT2>(c, o1, dy21, gr->conv[4].weight)));
+    a = ConvArgs{};
+    a.A = dy21; a.B = dy2s; a.W = at(c.ws, c.w.wd[4]); a.W2 = at(c.ws, c.w.wd[6]); a.out = X3;   // d o1 -> X3 [R,64]
+    RC((run_conv<T, 128, 64, 2, PRO_DY, 128>(c, a, nullptr)));
+    // ---- block 1 output: g1 in place in X3 ; BatchNorm 2 (conv2) and 3 (skip)
+    RC((run_mask<T, 64, true, false>(c, X3, 2, 3, X3, &nb)));
+    RC(bn_bwd_finalize(c, 2, 1, nb, gr)); RC(bn_bwd_finalize(c, 3, 2, nb, gr));
+    const TileSrc dy12{X3, c.y(2), c.bco(2), nullptr}, dy1s{X3, c.y(3), c.bco(3), nullptr};
+    const TileSrc a11{c.y(1), nullptr, c.fco(1), nullptr}, a0{c.y(0), nullptr, c.fco(0), nullptr};
+    RC((run_wgrad<T, 64, 64, 9, PRO_ACT1>(c, a11, dy12, gr->conv[2].weight)));
+    RC((run_wgrad<T, 32, 64, 1, PRO_ACT1>(c, a0, dy1s, gr->conv[3].weight)));
+    a = ConvArgs{};
+    a.A = dy12; a.W = at(c.ws, c.w.wd[2]); a.out = X1;                                   // d a11 -> X1 [R,64]
+    RC((run_conv<T, 64, 64, 0, PRO_DY, 64>(c, a, nullptr)));
+    RC((run_mask<T, 64, false, false>(c, X1, 1, 1, X1, &nb)));
+    RC(bn_bwd_finalize(c, 1, 1, nb, gr));
+    const TileSrc dy11{X1, c.y(1), c.bco(1), nullptr};
+    RC((run_wgrad<T, 32, 64, 9, PRO_ACT1>(c, a0, dy11, gr->conv[1].weight)));
+    a = ConvArgs{};
+    a.A = dy11; a.B = dy1s; a.W = at(c.ws, c.w.wd[1]); a.W2 = at(c.ws, c.w.wd[3]); a.out = X2;   // d a0 -> X2 [R,32]
+    RC((run_conv<T, 64, 32, 2, PRO_DY, 64>(c, a, nullptr)));
+    RC((run_mask<T, 32, false, false>(c, X2, 0, 0, X2, &nb)));
+    RC(bn_bwd_finalize(c, 0, 1, nb, gr));
+    {   // first convolution's weight gradient
+        const int F = conv0_frames(c.P), HP = (c.P + 2) * (c.P + 2), ngroups = ceil_div(c.N, F), G = std::min(ngroups, 256);
+        const size_t lds = (size_t)F * HP * 4 + 16 * 288 * 4;
+        float *slab = static_cast<float *>(at(c.ws, c.w.slab));
+        const TileSrc dy0{X2, c.y(0), c.bco(0), nullptr};
+        hipLaunchKernelGGL(drn_wgrad0_kernel<T>, dim3(G), dim3(NT), lds, c.s, x, dy0, slab, c.N, c.P, F, ngroups);
+        MIVIT_LAUNCH_CHECK();
+        RC(launch_slab_reduce(slab, G, 288, gr->conv[0].weight, 0, c.s));
+    }
+    return 0;
+}
+
+int check_params(const mivit_deepresnet_params *p) {
+    MIVIT_CHECK(p && p->fc_weight && p->fc_bias, "deepresnet: null fc parameters");
+    for (int i = 0; i < 7; ++i)
+        MIVIT_CHECK(p->conv[i].weight && p->conv[i].gamma && p->conv[i].beta, "deepresnet: null parameter in conv/bn %d", i);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int mivit_deepresnet_train_supported(int dtype, int patch_size) { return drn_train_supported(dtype, patch_size) ? 1 : 0; }
+
+extern "C" size_t mivit_deepresnet_train_workspace_bytes(int dtype, int N, int P, int E) {
+    if (N <= 0 || E <= 0 || !drn_train_supported(dtype, P)) return 0;
+    return make_ws(dtype, N, P, E).total;
+}
+
+extern "C" int mivit_deepresnet_train_fwd(int dtype, const mivit_deepresnet_params *params, const float *x, int N, int P, int E,
+                                          float momentum, float eps, float *tokens, void *workspace, size_t workspace_bytes,
+                                          void *stream) {
+    MIVIT_CHECK(dtype == MIVIT_F32 || dtype == MIVIT_BF16, "bad dtype %d", dtype);
+    RC(check_params(params));
+    MIVIT_CHECK(x && tokens && workspace, "deepresnet_train_fwd: null pointer");
+    MIVIT_CHECK(N > 0 && E > 0, "deepresnet_train_fwd: empty problem");
+    if (!drn_train_supported(dtype, P)) { mivit_set_error("deepresnet_train_fwd: frame side %d does not fit the LDS-resident kernels", P); return 3; }
+    Ctx c{dtype, N, P, E, eps, momentum, workspace, make_ws(dtype, N, P, E), static_cast<hipStream_t>(stream), params};
+    MIVIT_CHECK(workspace_bytes >= c.w.total, "deepresnet_train_fwd: workspace too small (%zu < %zu)", workspace_bytes, c.w.total);
+    prof_set_tag(MIVIT_PROF_OP);
+    return dtype == MIVIT_F32 ? forward_t<float>(c, x, tokens) : forward_t<bf16>(c, x, tokens);
+}
+
+extern "C" int mivit_deepresnet_train_bwd(int dtype, const mivit_deepresnet_params *params, const float *x, const float *dtokens,
+                                          int N, int P, int E, float eps, const mivit_deepresnet_grads *grads, void *workspace,
+                                          size_t workspace_bytes, void *stream) {
+    MIVIT_CHECK(dtype == MIVIT_F32 || dtype == MIVIT_BF16, "bad dtype %d", dtype);
+    RC(check_params(params));
+    MIVIT_CHECK(x && dtokens && workspace && grads && grads->fc_weight && grads->fc_bias, "deepresnet_train_bwd: null pointer");
+    for (int i = 0; i < 7; ++i)
+        MIVIT_CHECK(grads->conv[i].weight && grads->conv[i].gamma && grads->conv[i].beta, "deepresnet_train_bwd: null gradient %d", i);
+    if (!drn_train_supported(dtype, P)) { mivit_set_error("deepresnet_train_bwd: frame side %d does not fit the LDS-resident kernels", P); return 3; }
+    Ctx c{dtype, N, P, E, eps, 0.f, workspace, make_ws(dtype, N, P, E), static_cast<hipStream_t>(stream), params};
+    MIVIT_CHECK(workspace_bytes >= c.w.total, "deepresnet_train_bwd: workspace too small (%zu < %zu)", workspace_bytes, c.w.total);
+    prof_set_tag(MIVIT_PROF_OP);
+    return dtype == MIVIT_F32 ? backward_t<float>(c, x, dtokens, grads) : backward_t<bf16>(c, x, dtokens, grads);
+}

@@ -242,11 +242,47 @@ class DeepResNetEmbedding(nn.Module):
         dtype = torch.bfloat16 if getattr(self, "_mivit_precision", "fp32") == "bf16" else torch.float32
         return _ops.deepresnet_eval_supported(dtype, x.shape[-1]) and os.environ.get("MIVIT_NO_DEEPRESNET_EVAL") != "1"
 
+    # -- training: batch-statistics BatchNorm, hand-written conv / BN forward + backward (csrc/deepresnet_train.hip) --
+    def _conv_bn_pairs(self):
+        b1, b2 = self.res_block1, self.res_block2
+        return [(self.initial_conv, self.bn1), (b1.conv1, b1.bn1), (b1.conv2, b1.bn2), (b1.skip[0], b1.skip[1]),
+                (b2.conv1, b2.bn1), (b2.conv2, b2.bn2), (b2.skip[0], b2.skip[1])]
+
+    def _native_train_ok(self, x):
+        if not self.training or x.device.type != "cuda" or x.shape[-1] != x.shape[-2] or x.requires_grad:
+            return False
+        if os.environ.get("MIVIT_NO_DEEPRESNET_TRAIN") == "1":
+            return False
+        pairs = self._conv_bn_pairs()
+        bn0 = pairs[0][1]
+        if any(bn.momentum != bn0.momentum or bn.eps != bn0.eps or not bn.affine or bn.momentum is None for _, bn in pairs):
+            return False
+        dtype = torch.bfloat16 if getattr(self, "_mivit_precision", "fp32") == "bf16" else torch.float32
+        return _ops.deepresnet_train_supported(dtype, x.shape[-1])
+
+    def _forward_native_train(self, frames):
+        pairs = self._conv_bn_pairs()
+        dtype = torch.bfloat16 if getattr(self, "_mivit_precision", "fp32") == "bf16" else torch.float32
+        params, running = [], []
+        for conv, bn in pairs:
+            params += [conv.weight, bn.weight, bn.bias]
+            running.append((bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None))
+        params += [self.fc.weight, self.fc.bias]
+        out = _ops.deepresnet_train(frames, dtype, pairs[0][1].momentum, pairs[0][1].eps, running, params)
+        with torch.no_grad():
+            for _, bn in pairs:
+                if bn.track_running_stats:
+                    bn.num_batches_tracked += 1
+                    torch.autograd.graph.increment_version(bn.running_mean)   # the kernel wrote it: invalidate fold cache
+        return out
+
     def forward(self, x):
         b, n, h, w = x.shape
         if self._native_eval_ok(x):
             dtype = torch.bfloat16 if getattr(self, "_mivit_precision", "fp32") == "bf16" else torch.float32
             return _ops.deepresnet_eval(x.reshape(b * n, h, w), self.folded(dtype), self.fc.out_features).view(b, n, -1)
+        if self._native_train_ok(x):
+            return self._forward_native_train(x.reshape(b * n, h, w)).view(b, n, -1)
         y = x.reshape(b * n, 1, h, w)
         y = self.relu(self.bn1(self.initial_conv(y)))
         y = self.res_block2(self.res_block1(y))

@@ -177,3 +177,62 @@ def deepresnet_eval(x: torch.Tensor, pack: dict, embed_dim: int) -> torch.Tensor
     N.check(N.lib.mivit_deepresnet_eval_fwd(_dt(pack["w11"]), _p(x), n, p, embed_dim, *[_p(pack[k]) for k in order],
                                             _p(out), _s(x)), "mivit_deepresnet_eval_fwd")
     return out
+
+
+def deepresnet_train_supported(dtype: torch.dtype, patch_size: int) -> bool:
+    return bool(N.lib.mivit_deepresnet_train_supported(N.BF16 if dtype == torch.bfloat16 else N.F32, int(patch_size)))
+
+
+class _DeepResNetTrain(torch.autograd.Function):
+    """Training-mode DeepResNetEmbedding (reference models.py:230-257) on the hand-written conv / BatchNorm kernels.
+    Inputs after ``x``: for each of the 7 conv+BN pairs (weight, gamma, beta), then fc.weight, fc.bias  (23 tensors)."""
+
+    @staticmethod
+    def forward(ctx, x, dtype_code, momentum, eps, running, *params):
+        n, p, _ = x.shape
+        e = params[21].shape[0]
+        prm = N.DeepResNetParams()
+        for i in range(7):
+            w, g, b = params[3 * i:3 * i + 3]
+            rm, rv = running[i]
+            prm.conv[i] = N.ConvBn(w.data_ptr(), g.data_ptr(), b.data_ptr(), rm.data_ptr() if rm is not None else None,
+                                   rv.data_ptr() if rv is not None else None)
+        prm.fc_weight, prm.fc_bias = params[21].data_ptr(), params[22].data_ptr()
+        nbytes = N.lib.mivit_deepresnet_train_workspace_bytes(dtype_code, n, p, e)
+        if nbytes == 0:
+            raise N.MivitError(f"DeepResNet training kernels do not support frame side {p}")
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        tokens = torch.empty(n, e, device=x.device, dtype=torch.float32)
+        N.check(N.lib.mivit_deepresnet_train_fwd(dtype_code, ctypes.addressof(prm), _p(x), n, p, e, momentum, eps, _p(tokens),
+                                                 _p(ws), nbytes, _s(x)), "mivit_deepresnet_train_fwd")
+        ctx.save_for_backward(x, ws, *params)
+        ctx.meta = (dtype_code, n, p, e, eps, nbytes)
+        return tokens
+
+    @staticmethod
+    def backward(ctx, dtokens):
+        x, ws, *params = ctx.saved_tensors
+        dtype_code, n, p, e, eps, nbytes = ctx.meta
+        prm, gr = N.DeepResNetParams(), N.DeepResNetGrads()
+        grads = [torch.empty_like(t) for t in params]
+        for i in range(7):
+            w, g, b = params[3 * i:3 * i + 3]
+            prm.conv[i] = N.ConvBn(w.data_ptr(), g.data_ptr(), b.data_ptr(), None, None)
+            gr.conv[i] = N.ConvBnGrad(*[t.data_ptr() for t in grads[3 * i:3 * i + 3]])
+        prm.fc_weight, prm.fc_bias = params[21].data_ptr(), params[22].data_ptr()
+        gr.fc_weight, gr.fc_bias = grads[21].data_ptr(), grads[22].data_ptr()
+        dtokens = dtokens.contiguous().float()
+        N.check(N.lib.mivit_deepresnet_train_bwd(dtype_code, ctypes.addressof(prm), _p(x), _p(dtokens), n, p, e, eps,
+                                                 ctypes.addressof(gr), _p(ws), nbytes, _s(x)), "mivit_deepresnet_train_bwd")
+        return (None, None, None, None, None, *grads)
+
+
+def deepresnet_train(x, dtype, momentum, eps, running, params):
+    """x [N,P,P] fp32 frames -> tokens [N,E] fp32; ``running`` = 7 pairs (running_mean, running_var) updated in place
+    (or (None, None)); ``params`` = the 23 parameter tensors (fp32, contiguous, reference layouts)."""
+    _gpu(x, *params)
+    for t in params:
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise TypeError("DeepResNet parameters must be contiguous float32 tensors")
+    return _DeepResNetTrain.apply(x.contiguous().float(), N.BF16 if dtype == torch.bfloat16 else N.F32, float(momentum),
+                                  float(eps), running, *params)
