@@ -90,7 +90,7 @@ __device__ __forceinline__ void conv_accum2(f32x4 (&acc)[2][MT], const T *in, co
                                             const int (&hidx)[MT], int nm, int HW2, int lane) {
     typedef typename Mma<T>::Frag Frag;
     constexpr int KS = Mma<T>::KS, KL = sizeof(T) == 2 ? 8 : 1, CS = CIN + pad_el<T>();
-    constexpr int NC = CIN / KS, TOT = TAPS * NC, G = 4, NCH = (TOT + G - 1) / G;
+    constexpr int NC = CIN / KS, TOT = TAPS * NC, G = 2, NCH = (TOT + G - 1) / G;
     static_assert(CIN % KS == 0, "channel count must be a multiple of the MFMA k step");
     const int g = lane >> 4;
     w0 += g * KL; w1 += g * KL; in += g * KL;
@@ -586,7 +586,7 @@ struct DrnWs {
     int parts_cap;
 };
 
-constexpr int MASK_ROWS = 512, WG_GROUPS = 128, PART_MAX = 2048;
+constexpr int MASK_ROWS = 512, WG_GROUPS = 256, PART_MAX = 128;
 
 size_t tile_bytes(int dtype, int P, int F, int C) { return (size_t)F * (P + 2) * (P + 2) * (C * dtype_size(dtype) + PADB); }
 
@@ -629,7 +629,7 @@ DrnWs make_ws(int dtype, int N, int P, int E) {
     w.part = take((size_t)w.parts_cap * 3 * 128 * 4 * 2);
     w.part2 = take((size_t)PART_MAX * 3 * 128 * 4);
     for (int i = 0; i < 3; ++i) w.X[i] = take(R * 128 * es);
-    w.slab = take((size_t)WG_GROUPS * 128 * 9 * 128 * 4);
+    w.slab = take((size_t)85 * 128 * 9 * 128 * 4);      // >= 256 * 128 * 128 * 4 of the 1x1 convolutions
     w.lin = take(linear_wgrad_ws_bytes(N, E, 128));
     w.total = off;
     return w;
@@ -783,7 +783,7 @@ int run_wgrad(const Ctx &c, const TileSrc &A, const TileSrc &D, float *dW) {
     a.N = c.N; a.P = c.P; a.F = wgrad_frames(c.dtype, c.P, CIN, COUT);
     a.ngroups = ceil_div(c.N, a.F);
     a.A = A; a.D = D; a.slab = static_cast<float *>(at(c.ws, c.w.slab));
-    const int G = std::min(a.ngroups, WG_GROUPS);
+    const int G = std::min(a.ngroups, TAPS == 9 ? 85 : WG_GROUPS);
     const size_t lds = wgrad_lds(c.dtype, c.P, a.F, CIN, COUT);
     auto kern = drn_wgrad_kernel<T, CIN, COUT, TAPS, PROA>;
     RC(set_lds(kern, lds));

@@ -1,0 +1,16 @@
+"""Few native DeepResNet training steps for rocprofv3 (bf16, B from argv)."""
+import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+import torch, torch.nn.functional as F
+from moleculardiffusion_mivit_amd.helpers.models import GeneralTransformer, DeepResNetEmbedding, MLPHead
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+prec = sys.argv[2] if len(sys.argv) > 2 else "bf16"
+torch.manual_seed(0)
+m = GeneralTransformer(DeepResNetEmbedding, {"patch_size": 9, "embed_dim": 64}, 64, 4, 128, 6, MLPHead, F.relu,
+                       use_regression_token=True, precision=prec).cuda()
+opt = torch.optim.AdamW(m.parameters(), lr=1e-4, fused=True)
+x = torch.rand(B, 30, 9, 9, device="cuda"); y = torch.rand(B, 1, device="cuda")
+for _ in range(6):
+    opt.zero_grad(set_to_none=True); loss = F.mse_loss(m(x), y); loss.backward(); opt.step()
+torch.cuda.synchronize()
+print("done", float(loss))
