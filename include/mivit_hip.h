@@ -213,6 +213,11 @@ int mivit_backward(const mivit_plan *plan, const float *params, const float *x, 
                    float *grads, float *dfeatures, float *dx_tokens,
                    int stage_begin, int stage_end, void *stream);
 
+/* hipGraph replay statistics.  mivit_forward / mivit_backward / mivit_deepresnet_train_* on small (launch-bound) problems
+ * capture their kernel sequence into a hipGraph the second time they see the same arguments and replay it afterwards
+ * (MIVIT_GRAPHS=0 disables; off while mivit_profile_enable is active). */
+void mivit_graph_stats(uint64_t *replays, uint64_t *captures, int *failures);
+
 /* ------------------------------------------------------------------------------------------------
  * In-library kernel timing (used by bench.py for the roofline line): when a tag's bit is set in `tag_mask`, the
  * MAIN kernel of every launch in that category is bracketed by a hipEvent pair on the launch stream.

@@ -5,6 +5,7 @@
 #include <stddef.h>
 #include <stdio.h>
 #include <string>
+#include <functional>
 
 #include "../../include/mivit_hip.h"
 
@@ -284,3 +285,9 @@ struct ProfScope {
     explicit ProfScope(hipStream_t st) : s(st), on(prof_begin(st)) {}
     ~ProfScope() { if (on) prof_end(s); }
 };
+
+// hipGraph replay of launch-bound call sequences (misc.hip).  `key` must hold every value the body's launches depend on
+// (pointers, sizes).  First sighting of a key: body(s) runs directly.  Second: body is captured on an internal stream,
+// instantiated and launched on s.  Later: replay.  Disabled by MIVIT_GRAPHS=0, while the in-library profiler is on, and
+// after repeated capture failures; small LRU.
+int graph_run(const uint64_t *key, int nkey, hipStream_t s, const std::function<int(hipStream_t)> &body);

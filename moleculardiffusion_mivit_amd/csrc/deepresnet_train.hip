@@ -16,6 +16,7 @@
 // deterministically (no atomics anywhere).
 #include "common.h"
 #include <algorithm>
+#include <vector>
 
 namespace {
 
@@ -860,6 +861,18 @@ int backward_t(const Ctx &c, const float *x, const float *dtokens, const mivit_d
     return 0;
 }
 
+constexpr int64_t GRAPH_MAX_ROWS = 1 << 17;      // below this many pixels a step is launch-bound: replay it as a hipGraph
+
+std::vector<uint64_t> params_key(const mivit_deepresnet_params *p) {
+    std::vector<uint64_t> k;
+    for (int i = 0; i < 7; ++i)
+        for (const float *q : {p->conv[i].weight, p->conv[i].gamma, p->conv[i].beta, (const float *)p->conv[i].running_mean,
+                               (const float *)p->conv[i].running_var})
+            k.push_back((uint64_t)q);
+    k.push_back((uint64_t)p->fc_weight); k.push_back((uint64_t)p->fc_bias);
+    return k;
+}
+
 int check_params(const mivit_deepresnet_params *p) {
     MIVIT_CHECK(p && p->fc_weight && p->fc_bias, "deepresnet: null fc parameters");
     for (int i = 0; i < 7; ++i)
@@ -887,7 +900,16 @@ extern "C" int mivit_deepresnet_train_fwd(int dtype, const mivit_deepresnet_para
     Ctx c{dtype, N, P, E, eps, momentum, workspace, make_ws(dtype, N, P, E), static_cast<hipStream_t>(stream), params};
     MIVIT_CHECK(workspace_bytes >= c.w.total, "deepresnet_train_fwd: workspace too small (%zu < %zu)", workspace_bytes, c.w.total);
     prof_set_tag(MIVIT_PROF_OP);
-    return dtype == MIVIT_F32 ? forward_t<float>(c, x, tokens) : forward_t<bf16>(c, x, tokens);
+    auto body = [&](hipStream_t cs) {
+        Ctx cc = c; cc.s = cs;
+        return dtype == MIVIT_F32 ? forward_t<float>(cc, x, tokens) : forward_t<bf16>(cc, x, tokens);
+    };
+    if ((int64_t)N * P * P > GRAPH_MAX_ROWS) return body(c.s);
+    std::vector<uint64_t> key = params_key(params);
+    for (uint64_t v : {(uint64_t)3, (uint64_t)dtype, (uint64_t)x, (uint64_t)N, (uint64_t)P, (uint64_t)E, (uint64_t)tokens, (uint64_t)workspace,
+                       (uint64_t)__builtin_bit_cast(uint32_t, momentum), (uint64_t)__builtin_bit_cast(uint32_t, eps)})
+        key.push_back(v);
+    return graph_run(key.data(), (int)key.size(), c.s, body);
 }
 
 extern "C" int mivit_deepresnet_train_bwd(int dtype, const mivit_deepresnet_params *params, const float *x, const float *dtokens,
@@ -902,5 +924,16 @@ extern "C" int mivit_deepresnet_train_bwd(int dtype, const mivit_deepresnet_para
     Ctx c{dtype, N, P, E, eps, 0.f, workspace, make_ws(dtype, N, P, E), static_cast<hipStream_t>(stream), params};
     MIVIT_CHECK(workspace_bytes >= c.w.total, "deepresnet_train_bwd: workspace too small (%zu < %zu)", workspace_bytes, c.w.total);
     prof_set_tag(MIVIT_PROF_OP);
-    return dtype == MIVIT_F32 ? backward_t<float>(c, x, dtokens, grads) : backward_t<bf16>(c, x, dtokens, grads);
+    auto body = [&](hipStream_t cs) {
+        Ctx cc = c; cc.s = cs;
+        return dtype == MIVIT_F32 ? backward_t<float>(cc, x, dtokens, grads) : backward_t<bf16>(cc, x, dtokens, grads);
+    };
+    if ((int64_t)N * P * P > GRAPH_MAX_ROWS) return body(c.s);
+    std::vector<uint64_t> key = params_key(params);
+    for (int i = 0; i < 7; ++i)
+        for (const float *p : {grads->conv[i].weight, grads->conv[i].gamma, grads->conv[i].beta}) key.push_back((uint64_t)p);
+    for (uint64_t v : {(uint64_t)4, (uint64_t)dtype, (uint64_t)x, (uint64_t)dtokens, (uint64_t)N, (uint64_t)P, (uint64_t)E, (uint64_t)workspace,
+                       (uint64_t)grads->fc_weight, (uint64_t)grads->fc_bias, (uint64_t)__builtin_bit_cast(uint32_t, eps)})
+        key.push_back(v);
+    return graph_run(key.data(), (int)key.size(), c.s, body);
 }

@@ -336,7 +336,7 @@ extern "C" size_t mivit_plan_workspace_bytes(const mivit_plan *plan, int B, int 
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-extern "C" int mivit_forward(const mivit_plan *plan, const float *params, const float *x, const float *features, int B,
+static int forward_impl(const mivit_plan *plan, const float *params, const float *x, const float *features, int B,
                              int T, void *workspace, size_t workspace_bytes, int need_backward, float *out,
                              void *stream) {
     RC(check_call(plan, B, T, workspace_bytes, need_backward != 0, "mivit_forward"));
@@ -466,7 +466,7 @@ int feature_projector_bwd(const mivit_plan *plan, const Ws &w, void *ws, const f
 
 }  // namespace
 
-extern "C" int mivit_backward(const mivit_plan *plan, const float *params, const float *x, const float *features, int B,
+static int backward_impl(const mivit_plan *plan, const float *params, const float *x, const float *features, int B,
                               int T, void *workspace, size_t workspace_bytes, const float *dout, float *grads,
                               float *dfeatures, float *dx_tokens, int stage_begin, int stage_end, void *stream) {
     RC(check_call(plan, B, T, workspace_bytes, true, "mivit_backward"));
@@ -592,4 +592,41 @@ extern "C" int mivit_backward(const mivit_plan *plan, const float *params, const
         }
     }
     return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// C-ABI entry points.  Small problems are launch-bound (~100 short kernels per call): a call whose arguments were seen
+// before is captured once into a hipGraph on an internal stream and replayed on the caller's stream afterwards.
+// ------------------------------------------------------------------------------------------------
+static bool graph_sized(const mivit_plan *plan, int B, int T) {
+    return plan && (int64_t)B * (T + 1) <= 8192;
+}
+
+extern "C" int mivit_forward(const mivit_plan *plan, const float *params, const float *x, const float *features, int B,
+                             int T, void *workspace, size_t workspace_bytes, int need_backward, float *out,
+                             void *stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (!graph_sized(plan, B, T))
+        return forward_impl(plan, params, x, features, B, T, workspace, workspace_bytes, need_backward, out, s);
+    const uint64_t key[] = {1, (uint64_t)plan, (uint64_t)params, (uint64_t)x, (uint64_t)features, (uint64_t)B, (uint64_t)T,
+                            (uint64_t)workspace, (uint64_t)workspace_bytes, (uint64_t)need_backward, (uint64_t)out};
+    return graph_run(key, (int)(sizeof(key) / sizeof(key[0])), s, [&](hipStream_t cs) {
+        return forward_impl(plan, params, x, features, B, T, workspace, workspace_bytes, need_backward, out, cs);
+    });
+}
+
+extern "C" int mivit_backward(const mivit_plan *plan, const float *params, const float *x, const float *features, int B,
+                              int T, void *workspace, size_t workspace_bytes, const float *dout, float *grads,
+                              float *dfeatures, float *dx_tokens, int stage_begin, int stage_end, void *stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (!graph_sized(plan, B, T))
+        return backward_impl(plan, params, x, features, B, T, workspace, workspace_bytes, dout, grads, dfeatures, dx_tokens,
+                             stage_begin, stage_end, s);
+    const uint64_t key[] = {2, (uint64_t)plan, (uint64_t)params, (uint64_t)x, (uint64_t)features, (uint64_t)B, (uint64_t)T,
+                            (uint64_t)workspace, (uint64_t)workspace_bytes, (uint64_t)dout, (uint64_t)grads,
+                            (uint64_t)dfeatures, (uint64_t)dx_tokens, (uint64_t)stage_begin, (uint64_t)stage_end};
+    return graph_run(key, (int)(sizeof(key) / sizeof(key[0])), s, [&](hipStream_t cs) {
+        return backward_impl(plan, params, x, features, B, T, workspace, workspace_bytes, dout, grads, dfeatures, dx_tokens,
+                             stage_begin, stage_end, cs);
+    });
 }

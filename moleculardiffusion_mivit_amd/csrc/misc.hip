@@ -224,6 +224,99 @@ __global__ __launch_bounds__(256) void slab_reduce3_kernel(const Reduce3 r, int 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// hipGraph cache
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct GraphEntry {
+    std::vector<uint64_t> key;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    uint64_t last_use = 0;
+};
+struct GraphState {
+    std::mutex mu;
+    std::vector<GraphEntry> entries;
+    hipStream_t capture_stream[16] = {};
+    uint64_t tick = 0;
+    int mode = -1, failures = 0;
+    uint64_t replays = 0, captures = 0;
+};
+GraphState g_graph;
+constexpr size_t GRAPH_CAP = 32;
+
+void graph_drop(GraphEntry &e) {
+    if (e.exec) (void)hipGraphExecDestroy(e.exec);
+    if (e.graph) (void)hipGraphDestroy(e.graph);
+    e.exec = nullptr; e.graph = nullptr;
+}
+}  // namespace
+
+int graph_run(const uint64_t *key, int nkey, hipStream_t s, const std::function<int(hipStream_t)> &body) {
+    GraphState &g = g_graph;
+    std::unique_lock<std::mutex> lk(g.mu);
+    if (g.mode < 0) {
+        const char *e = getenv("MIVIT_GRAPHS");
+        g.mode = (e && e[0] == '0') ? 0 : 1;
+    }
+    if (!g.mode || g.failures >= 3 || g_prof.mask != 0) { lk.unlock(); return body(s); }
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) { lk.unlock(); return body(s); }
+    std::vector<uint64_t> k(key, key + nkey);
+    k.push_back((uint64_t)dev);
+    GraphEntry *hit = nullptr;
+    for (auto &e : g.entries)
+        if (e.key == k) { hit = &e; break; }
+    ++g.tick;
+    if (hit && hit->exec) {
+        hit->last_use = g.tick; ++g.replays;
+        MIVIT_HIP(hipGraphLaunch(hit->exec, s));
+        return 0;
+    }
+    if (!hit) {                                   // first sighting: remember, run directly
+        if (g.entries.size() >= GRAPH_CAP) {
+            size_t lru = 0;
+            for (size_t i = 1; i < g.entries.size(); ++i)
+                if (g.entries[i].last_use < g.entries[lru].last_use) lru = i;
+            graph_drop(g.entries[lru]);
+            g.entries.erase(g.entries.begin() + lru);
+        }
+        GraphEntry e; e.key = k; e.last_use = g.tick;
+        g.entries.push_back(e);
+        lk.unlock();
+        return body(s);
+    }
+    // second sighting: capture on the internal stream (the caller's stream may be the legacy default stream)
+    hit->last_use = g.tick;
+    if (!g.capture_stream[dev] && hipStreamCreateWithFlags(&g.capture_stream[dev], hipStreamNonBlocking) != hipSuccess) {
+        ++g.failures; (void)hipGetLastError(); lk.unlock(); return body(s);
+    }
+    hipStream_t cs = g.capture_stream[dev];
+    if (hipStreamBeginCapture(cs, hipStreamCaptureModeRelaxed) != hipSuccess) {
+        ++g.failures; (void)hipGetLastError(); lk.unlock(); return body(s);
+    }
+    const int rc = body(cs);
+    hipGraph_t graph = nullptr;
+    const hipError_t e1 = hipStreamEndCapture(cs, &graph);
+    if (rc != 0) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    hipGraphExec_t exec = nullptr;
+    if (e1 != hipSuccess || !graph || hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+        if (graph) (void)hipGraphDestroy(graph);
+        ++g.failures; (void)hipGetLastError(); lk.unlock();
+        return body(s);
+    }
+    hit->graph = graph; hit->exec = exec; ++g.captures;
+    MIVIT_HIP(hipGraphLaunch(exec, s));
+    return 0;
+}
+
+extern "C" void mivit_graph_stats(uint64_t *replays, uint64_t *captures, int *failures) {
+    std::lock_guard<std::mutex> lk(g_graph.mu);
+    if (replays) *replays = g_graph.replays;
+    if (captures) *captures = g_graph.captures;
+    if (failures) *failures = g_graph.failures;
+}
+
 int launch_slab_reduce3(const float *p0, float *o0, const float *p1, float *o1, const float *p2, float *o2, int nparts,
                         int n, int accumulate, hipStream_t s) {
     Reduce3 r = {{p0, p1, p2}, {o0, o1, o2}};

@@ -350,3 +350,37 @@ def test_deepresnet_native_training_two_steps_then_fused_inference():
         got = nat(x)
     want = ref(x).detach()                 # grad enabled -> torch path
     assert rel_err(got, want) < 2e-4
+
+
+# ---- hipGraph replay of launch-bound steps -----------------------------------------------------------------------------
+@pytest.mark.parametrize("embedding", ["linear", "deepresnet"])
+def test_hipgraph_replay_is_bitwise_identical(embedding):
+    """Same tensors, same addresses: call 1 runs the kernels directly, call 2 captures them into a hipGraph, calls 3+
+    replay it.  All must give bitwise identical outputs and gradients, and the library must report replays."""
+    import ctypes
+    from moleculardiffusion_mivit_amd import _native as N
+    cfg = orc.MiViTConfig(embedding=embedding, patch_size=9, embed_dim=64, num_heads=4, hidden_dim=128, num_layers=2)
+    m = build_product_model(cfg, "bf16", orc.random_params(cfg, seed=3)).train()
+    x = torch.rand(4, 10, 9, 9, device="cuda")
+    y = torch.rand(4, 1, device="cuda")
+
+    def stats():
+        r, c, f = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_int()
+        N.lib.mivit_graph_stats(ctypes.byref(r), ctypes.byref(c), ctypes.byref(f))
+        return r.value, c.value, f.value
+
+    r0, c0, f0 = stats()
+    outs = []
+    for _ in range(5):
+        out, loss, grads = _run(m, x, y, None)
+        outs.append((out.cpu(), {k: g.cpu() for k, g in grads.items()}))     # host copies: keep GPU addresses stable
+        del out, loss, grads
+    r1, c1, f1 = stats()
+    assert f1 == f0, "hipGraph capture failed"
+    assert c1 > c0 and r1 > r0, (r0, c0, r1, c1)
+    for out, grads in outs[1:]:
+        assert torch.equal(out, outs[0][0])
+        for k in grads:
+            if "bn" in k or "skip.1" in k or "running" in k:
+                continue
+            assert torch.equal(grads[k], outs[0][1][k]), k
