@@ -38,11 +38,40 @@ __device__ __forceinline__ float frag_at<float>(const float *p) { return *p; }
 template <>
 __device__ __forceinline__ bf16x8 frag_at<bf16>(const bf16 *p) { return *reinterpret_cast<const bf16x8 *>(p); }
 
-// halo cell of logical row r (= f*P*P + y*P + x); rows past the block's last frame alias the first interior pixel
-__device__ __forceinline__ int halo_index(int r, int rows, int P) {
-    if (r >= rows) return P + 3;
-    const int pp = P * P, f = r / pp, rem = r - f * pp, y = rem / P, x = rem - y * P;
-    return f * (P + 2) * (P + 2) + (y + 1) * (P + 2) + x + 1;
+// Work decomposition.  A frame is cut into tiles of th x tw output pixels (one tile = the whole frame when it is small
+// enough); a workgroup holds F tile "slots", each a zero-haloed (th+2) x (tw+2) image in LDS.  Halo cells that fall
+// inside the frame are loaded from the neighbouring pixels (the activations live in HBM between layers), cells outside
+// the frame are the convolution's zero padding.  Row r of the workgroup = (slot r / (th*tw), ty, tx).
+struct Geom {
+    int N, P, PP;
+    int th, tw, ntx, tpf, units;     // tile size, tiles per frame row, tiles per frame, N * tpf
+    int F, HPt, RT;                  // slots per workgroup, cells per slot image, F * th * tw rows (<= 176)
+};
+
+// per-workgroup lookup tables in LDS: rowg[r] = global pixel row (frame*P*P + y*P + x) or -1, rowc[r] = halo cell of row r
+__device__ __forceinline__ void build_row_tables(const Geom &g, int group, int nrows, int *rowg, int *rowc, int tid) {
+    const int tt = g.th * g.tw, W2 = g.tw + 2;
+    for (int r = tid; r < nrows; r += 512) {
+        int gr = -1, cell = W2 + 1;                        // dead rows alias the first interior cell of slot 0
+        const int s = r / tt;
+        if (s < g.F) {
+            const int u = group * g.F + s, rem = r - s * tt, ty = rem / g.tw, tx = rem - ty * g.tw;
+            const int frame = u / g.tpf, ti = u - frame * g.tpf, y = (ti / g.ntx) * g.th + ty, x = (ti % g.ntx) * g.tw + tx;
+            cell = s * g.HPt + (ty + 1) * W2 + tx + 1;
+            if (u < g.units && y < g.P && x < g.P) gr = frame * g.PP + y * g.P + x;
+        }
+        rowg[r] = gr; rowc[r] = cell;
+    }
+}
+
+// global pixel row behind image cell `cell` of this workgroup, or -1 (zero padding / dead slot)
+__device__ __forceinline__ int cell_source(const Geom &g, int group, int cell) {
+    const int W2 = g.tw + 2, s = cell / g.HPt, rem = cell - s * g.HPt, cy = rem / W2, cx = rem - cy * W2;
+    const int u = group * g.F + s;
+    if (u >= g.units) return -1;
+    const int frame = u / g.tpf, ti = u - frame * g.tpf, y = (ti / g.ntx) * g.th + cy - 1, x = (ti % g.ntx) * g.tw + cx - 1;
+    if (y < 0 || y >= g.P || x < 0 || x >= g.P) return -1;
+    return frame * g.PP + y * g.P + x;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -56,16 +85,16 @@ struct TileSrc {
     const float *cb;    // ACT2: forward table of BN(y')
 };
 
-template <typename T, int C, int PRO, bool HALO>
-__device__ __forceinline__ void fill_tile(T *tile, const TileSrc &s, size_t row0, int rows, int P, int tid) {
-    constexpr int V = vec_el<T>(), CV = C / V, CS = C + pad_el<T>();
-    const T *p0 = static_cast<const T *>(s.p0) + row0 * C;
-    const T *p1 = static_cast<const T *>(s.p1) + row0 * C;
-    for (int i = tid; i < rows * CV; i += NT) {
-        const int r = i / CV, c = (i - r * CV) * V;
-        float a[V], b[V], o[V];
-        load16(p0 + (size_t)r * C + c, a);
-        if (PRO != PRO_ACT1) load16(p1 + (size_t)r * C + c, b);
+template <typename T, int C, int PRO>
+__device__ __forceinline__ void transform_store(T *dst, const TileSrc &s, int64_t grow, int c) {
+    constexpr int V = vec_el<T>();
+    float a[V], b[V], o[V];
+    if (grow < 0) {
+#pragma unroll
+        for (int e = 0; e < V; ++e) o[e] = 0.f;
+    } else {
+        load16(static_cast<const T *>(s.p0) + grow * C + c, a);
+        if (PRO != PRO_ACT1) load16(static_cast<const T *>(s.p1) + grow * C + c, b);
 #pragma unroll
         for (int e = 0; e < V; ++e) {
             if (PRO == PRO_ACT1) o[e] = fmaxf(s.ca[2 * CSTR + c + e] * a[e] + s.ca[3 * CSTR + c + e], 0.f);
@@ -74,12 +103,28 @@ __device__ __forceinline__ void fill_tile(T *tile, const TileSrc &s, size_t row0
                              s.cb[3 * CSTR + c + e], 0.f);
             else o[e] = s.ca[c + e] * a[e] + s.ca[CSTR + c + e] + s.ca[2 * CSTR + c + e] * b[e];
         }
-        store16(tile + (HALO ? halo_index(r, rows, P) : r) * CS + c, o);
+    }
+    store16(dst, o);
+}
+
+// zero-haloed images of all F slots: every cell is written (loaded + transformed, or zero)
+template <typename T, int C, int PRO>
+__device__ __forceinline__ void fill_halo(T *tile, const TileSrc &s, const Geom &g, int group, int tid) {
+    constexpr int V = vec_el<T>(), CV = C / V, CS = C + pad_el<T>();
+    for (int i = tid; i < g.F * g.HPt * CV; i += NT) {
+        const int cell = i / CV, c = (i - cell * CV) * V;
+        transform_store<T, C, PRO>(tile + cell * CS + c, s, cell_source(g, group, cell), c);
     }
 }
 
-__device__ __forceinline__ void zero_lds(void *p, int bytes, int tid) {
-    for (int i = tid; i < bytes / 16; i += NT) reinterpret_cast<uint4 *>(p)[i] = make_uint4(0u, 0u, 0u, 0u);
+// plain row-ordered image [nrows][C] (dead rows zero)
+template <typename T, int C, int PRO>
+__device__ __forceinline__ void fill_rows(T *tile, const TileSrc &s, const int *rowg, int nrows, int tid) {
+    constexpr int V = vec_el<T>(), CV = C / V, CS = C + pad_el<T>();
+    for (int i = tid; i < nrows * CV; i += NT) {
+        const int r = i / CV, c = (i - r * CV) * V;
+        transform_store<T, C, PRO>(tile + r * CS + c, s, rowg[r], c);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -132,7 +177,7 @@ __device__ __forceinline__ void conv_accum2(f32x4 (&acc)[2][MT], const T *in, co
 }
 
 struct ConvArgs {
-    int N, P, F;
+    Geom g;
     TileSrc A, B;
     const void *W, *W2;          // [COUT][9][CIN], [COUT][CIN or CIN2]
     void *out, *out2;            // [N*P*P, COUT]
@@ -140,7 +185,7 @@ struct ConvArgs {
 };
 
 template <typename T, int COUT, int MT, bool STATS>
-__device__ __forceinline__ void conv_epilogue(const f32x4 (&acc)[2][MT], T *out, float *stats, float *red, size_t row0, int rows,
+__device__ __forceinline__ void conv_epilogue(const f32x4 (&acc)[2][MT], T *out, float *stats, float *red, const int *rowg,
                                               int mt0, int nm, int ng, int lane, int wave, int tid) {
     constexpr int NG = COUT / 32, MQ = 8 / NG;
     const int g = lane >> 4, cq = lane & 15;
@@ -153,10 +198,10 @@ __device__ __forceinline__ void conv_epilogue(const f32x4 (&acc)[2][MT], T *out,
             if (mt < nm) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int row = (mt0 + mt) * 16 + 4 * g + r;
-                    if (row < rows) {
+                    const int grow = rowg[(mt0 + mt) * 16 + 4 * g + r];
+                    if (grow >= 0) {
                         const float v = acc[j][mt][r];
-                        out[(row0 + row) * COUT + co] = from_f32<T>(v);
+                        out[(size_t)grow * COUT + co] = from_f32<T>(v);
                         s += v; ss += v * v;
                     }
                 }
@@ -180,6 +225,8 @@ __device__ __forceinline__ void conv_epilogue(const f32x4 (&acc)[2][MT], T *out,
     }
 }
 
+constexpr int ROWS_PAD = MAXM * 16;     // row tables cover all 11 row tiles
+
 // SECOND: 0 none | 1 second OUTPUT out2 = conv1x1(tile A, W2) (forward skip branch) | 2 second INPUT tile B (CIN2 channels,
 // DY prologue) whose 1x1 convolution accumulates into the same output (data gradient of conv1 + skip)
 template <typename T, int CIN, int COUT, int SECOND, int PRO, int CIN2>
@@ -189,44 +236,43 @@ __global__ __launch_bounds__(NT) void drn_conv_kernel(const ConvArgs a) {
     constexpr int CS = CIN + pad_el<T>(), CS2 = CIN2 + pad_el<T>();
     constexpr bool STATS = PRO != PRO_DY;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, cq = lane & 15;
-    const int P = a.P, HW2 = P + 2, HP = HW2 * HW2, PP = P * P;
-    const int f0 = blockIdx.x * a.F, nf = min(a.F, a.N - f0), rows = nf * PP, NM = (rows + 15) / 16;
-    const size_t row0 = (size_t)f0 * PP;
+    const Geom &g = a.g;
+    const int W2 = g.tw + 2, NM = (g.RT + 15) / 16;
     T *tileA = reinterpret_cast<T *>(smem);
-    T *tileB = tileA + a.F * HP * CS;
-    float *red = reinterpret_cast<float *>(tileB + (SECOND == 2 ? a.F * HP * CS2 : 0));
+    T *tileB = tileA + g.F * g.HPt * CS;
+    float *red = reinterpret_cast<float *>(tileB + (SECOND == 2 ? g.F * g.HPt * CS2 : 0));   // [8][2][32]
+    int *rowg = reinterpret_cast<int *>(red + 8 * 2 * 32), *rowc = rowg + ROWS_PAD;
 
-    zero_lds(smem, (a.F * HP * CS + (SECOND == 2 ? a.F * HP * CS2 : 0)) * (int)sizeof(T), tid);
-    __syncthreads();
-    fill_tile<T, CIN, PRO, true>(tileA, a.A, row0, rows, P, tid);
-    if (SECOND == 2) fill_tile<T, CIN2, PRO_DY, true>(tileB, a.B, row0, rows, P, tid);
+    build_row_tables(g, blockIdx.x, ROWS_PAD, rowg, rowc, tid);
+    fill_halo<T, CIN, PRO>(tileA, a.A, g, blockIdx.x, tid);
+    if (SECOND == 2) fill_halo<T, CIN2, PRO_DY>(tileB, a.B, g, blockIdx.x, tid);
     __syncthreads();
 
     const int ng = wave % NG, mq = wave / NG, per = (NM + MQ - 1) / MQ, mt0 = mq * per;
     const int nm = max(0, min(per, NM - mt0));
     int hidx[MT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) hidx[mt] = halo_index((mt0 + mt) * 16 + cq, rows, P);
+    for (int mt = 0; mt < MT; ++mt) hidx[mt] = rowc[min((mt0 + mt) * 16 + cq, ROWS_PAD - 1)];
     f32x4 acc[2][MT];
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) { acc[0][mt] = zero; acc[1][mt] = zero; }
 
     const T *w = static_cast<const T *>(a.W) + (size_t)(2 * ng * 16 + cq) * 9 * CIN;
-    conv_accum2<T, CIN, 9, MT>(acc, tileA, w, w + (size_t)16 * 9 * CIN, hidx, nm, HW2, lane);
+    conv_accum2<T, CIN, 9, MT>(acc, tileA, w, w + (size_t)16 * 9 * CIN, hidx, nm, W2, lane);
     if (SECOND == 2) {
         const T *w2 = static_cast<const T *>(a.W2) + (size_t)(2 * ng * 16 + cq) * CIN2;
-        conv_accum2<T, CIN2, 1, MT>(acc, tileB, w2, w2 + (size_t)16 * CIN2, hidx, nm, HW2, lane);
+        conv_accum2<T, CIN2, 1, MT>(acc, tileB, w2, w2 + (size_t)16 * CIN2, hidx, nm, W2, lane);
     }
     conv_epilogue<T, COUT, MT, STATS>(acc, static_cast<T *>(a.out), STATS ? a.stats + (size_t)blockIdx.x * 2 * COUT : nullptr, red,
-                                      row0, rows, mt0, nm, ng, lane, wave, tid);
+                                      rowg, mt0, nm, ng, lane, wave, tid);
     if (SECOND == 1) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) { acc[0][mt] = zero; acc[1][mt] = zero; }
         const T *w2 = static_cast<const T *>(a.W2) + (size_t)(2 * ng * 16 + cq) * CIN;
-        conv_accum2<T, CIN, 1, MT>(acc, tileA, w2, w2 + (size_t)16 * CIN, hidx, nm, HW2, lane);
-        conv_epilogue<T, COUT, MT, STATS>(acc, static_cast<T *>(a.out2), a.stats2 + (size_t)blockIdx.x * 2 * COUT, red, row0, rows,
-                                          mt0, nm, ng, lane, wave, tid);
+        conv_accum2<T, CIN, 1, MT>(acc, tileA, w2, w2 + (size_t)16 * CIN, hidx, nm, W2, lane);
+        conv_epilogue<T, COUT, MT, STATS>(acc, static_cast<T *>(a.out2), a.stats2 + (size_t)blockIdx.x * 2 * COUT, red, rowg, mt0, nm,
+                                          ng, lane, wave, tid);
     }
 }
 
@@ -234,27 +280,31 @@ __global__ __launch_bounds__(NT) void drn_conv_kernel(const ConvArgs a) {
 // first convolution (1 -> 32 channels): VALU, x tile in LDS.  y0 [R,32] + statistics partials [blocks][2][32]
 // ---------------------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(NT) void drn_conv0_kernel(const float *x, const float *w0, T *y0, float *stats, int N, int P, int F) {
+__global__ __launch_bounds__(NT) void drn_conv0_kernel(const float *x, const float *w0, T *y0, float *stats, const Geom g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, HW2 = P + 2, HP = HW2 * HW2, PP = P * P;
-    const int f0 = blockIdx.x * F, nf = min(F, N - f0), rows = nf * PP;
-    float *xs = reinterpret_cast<float *>(smem);            // [F][HP]
-    float *red = xs + F * HP;                               // [16][2][32]
-    for (int i = tid; i < F * HP; i += NT) xs[i] = 0.f;
-    __syncthreads();
-    for (int i = tid; i < rows; i += NT) xs[halo_index(i, rows, P)] = x[(size_t)f0 * PP + i];
+    const int tid = threadIdx.x, W2 = g.tw + 2;
+    float *xs = reinterpret_cast<float *>(smem);            // [F][HPt]
+    float *red = xs + g.F * g.HPt;                          // [16][2][32]
+    int *rowg = reinterpret_cast<int *>(red + 16 * 2 * 32), *rowc = rowg + g.RT;
+    build_row_tables(g, blockIdx.x, g.RT, rowg, rowc, tid);
+    for (int i = tid; i < g.F * g.HPt; i += NT) {
+        const int src = cell_source(g, blockIdx.x, i);
+        xs[i] = src >= 0 ? x[src] : 0.f;
+    }
     __syncthreads();
     const int co = tid & 31, rs = tid >> 5;
     float w[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) w[t] = w0[co * 9 + t];
     float s = 0.f, ss = 0.f;
-    for (int r = rs; r < rows; r += NT / 32) {
-        const int h = halo_index(r, rows, P);
+    for (int r = rs; r < g.RT; r += NT / 32) {
+        const int grow = rowg[r];
+        if (grow < 0) continue;
+        const int h = rowc[r];
         float v = 0.f;
 #pragma unroll
-        for (int t = 0; t < 9; ++t) v += xs[h + (t / 3 - 1) * HW2 + (t % 3 - 1)] * w[t];
-        y0[((size_t)f0 * PP + r) * 32 + co] = from_f32<T>(v);
+        for (int t = 0; t < 9; ++t) v += xs[h + (t / 3 - 1) * W2 + (t % 3 - 1)] * w[t];
+        y0[(size_t)grow * 32 + co] = from_f32<T>(v);
         s += v; ss += v * v;
     }
     red[(rs * 2 + 0) * 32 + co] = s; red[(rs * 2 + 1) * 32 + co] = ss;
@@ -268,28 +318,33 @@ __global__ __launch_bounds__(NT) void drn_conv0_kernel(const float *x, const flo
 
 // weight gradient of the first convolution: dW0[co][tap] = sum_r dy0[r][co] * x[pixel(r) + tap]
 template <typename T>
-__global__ __launch_bounds__(NT) void drn_wgrad0_kernel(const float *x, const TileSrc d, float *slab, int N, int P, int F, int ngroups) {
+__global__ __launch_bounds__(NT) void drn_wgrad0_kernel(const float *x, const TileSrc d, float *slab, const Geom g, int ngroups) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, HW2 = P + 2, HP = HW2 * HW2, PP = P * P;
-    float *xs = reinterpret_cast<float *>(smem);            // [F][HP]
-    float *red = xs + F * HP;                               // [16][32*9]
+    const int tid = threadIdx.x, W2 = g.tw + 2;
+    float *xs = reinterpret_cast<float *>(smem);            // [F][HPt]
+    float *red = xs + g.F * g.HPt;                          // [16][32*9]
+    int *rowg = reinterpret_cast<int *>(red + 16 * 288), *rowc = rowg + g.RT;
     const int co = tid & 31, rs = tid >> 5;
     const float k = d.ca[co], c0 = d.ca[CSTR + co], c1 = d.ca[2 * CSTR + co];
+    const T *gsrc = static_cast<const T *>(d.p0), *ysrc = static_cast<const T *>(d.p1);
     float acc[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) acc[t] = 0.f;
-    for (int i = tid; i < F * HP; i += NT) xs[i] = 0.f;
     for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
         __syncthreads();
-        const int f0 = grp * F, nf = min(F, N - f0), rows = nf * PP;
-        for (int i = tid; i < rows; i += NT) xs[halo_index(i, rows, P)] = x[(size_t)f0 * PP + i];
+        build_row_tables(g, grp, g.RT, rowg, rowc, tid);
+        for (int i = tid; i < g.F * g.HPt; i += NT) {
+            const int src = cell_source(g, grp, i);
+            xs[i] = src >= 0 ? x[src] : 0.f;
+        }
         __syncthreads();
-        const T *g = static_cast<const T *>(d.p0) + (size_t)f0 * PP * 32, *y = static_cast<const T *>(d.p1) + (size_t)f0 * PP * 32;
-        for (int r = rs; r < rows; r += NT / 32) {
-            const float dy = k * to_f32(g[(size_t)r * 32 + co]) + c0 + c1 * to_f32(y[(size_t)r * 32 + co]);
-            const int h = halo_index(r, rows, P);
+        for (int r = rs; r < g.RT; r += NT / 32) {
+            const int grow = rowg[r];
+            if (grow < 0) continue;
+            const float dy = k * to_f32(gsrc[(size_t)grow * 32 + co]) + c0 + c1 * to_f32(ysrc[(size_t)grow * 32 + co]);
+            const int h = rowc[r];
 #pragma unroll
-            for (int t = 0; t < 9; ++t) acc[t] += dy * xs[h + (t / 3 - 1) * HW2 + (t % 3 - 1)];
+            for (int t = 0; t < 9; ++t) acc[t] += dy * xs[h + (t / 3 - 1) * W2 + (t % 3 - 1)];
         }
     }
     __syncthreads();
@@ -445,7 +500,8 @@ __global__ __launch_bounds__(NT) void drn_bn_bwd_finalize_kernel(const float *pa
 // [COUT x CIN] block in accumulators; 8 waves = 4 (c_out) x 2 (c_in)
 // ---------------------------------------------------------------------------------------------------------------
 struct WgradArgs {
-    int N, P, F, ngroups;
+    Geom g;
+    int ngroups;
     TileSrc A;       // input activation of the convolution (ACT1 / ACT2)
     TileSrc D;       // dy (DY)
     float *slab;     // [gridDim.x][COUT][TAPS][CIN]
@@ -467,11 +523,11 @@ __global__ __launch_bounds__(NT) void drn_wgrad_kernel(const WgradArgs a) {
     constexpr int CSA = CIN + pad_el<T>(), CSD = COUT + pad_el<T>();
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, cq = lane & 15, q = cq >> 2, p = cq & 3;
     const int wm = wave & 3, wn = wave >> 2;
-    const int P = a.P, HW2 = P + 2, HP = HW2 * HW2, PP = P * P;
-    const int RP = (a.F * PP + 31) / 32 * 32;
-    T *tileA = reinterpret_cast<T *>(smem);                     // [F*HP][CSA]  zero-haloed input activation
-    T *tileD = tileA + a.F * HP * CSA;                          // [RP][CSD]    dy, plain row order, zero beyond `rows`
-    int *hmap = reinterpret_cast<int *>(tileD + RP * CSD);      // [RP]         row -> halo cell
+    const Geom &gm = a.g;
+    const int W2 = gm.tw + 2, RP = (gm.RT + 31) / 32 * 32;
+    T *tileA = reinterpret_cast<T *>(smem);                     // [F*HPt][CSA]  zero-haloed input activation
+    T *tileD = tileA + gm.F * gm.HPt * CSA;                     // [RP][CSD]     dy, plain row order, dead rows zero
+    int *rowg = reinterpret_cast<int *>(tileD + RP * CSD), *hmap = rowg + RP;   // [RP] each
     f32x4 acc[TPP][WM][WN];
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -480,20 +536,14 @@ __global__ __launch_bounds__(NT) void drn_wgrad_kernel(const WgradArgs a) {
         for (int i = 0; i < WM; ++i)
 #pragma unroll
             for (int j = 0; j < WN; ++j) acc[t][i][j] = zero;
-    zero_lds(smem, (a.F * HP * CSA + RP * CSD) * (int)sizeof(T), tid);
-    int prev_rows = RP;
     for (int grp = blockIdx.x; grp < a.ngroups; grp += gridDim.x) {
         __syncthreads();
-        const int f0 = grp * a.F, nf = min(a.F, a.N - f0), rows = nf * PP;
-        const size_t row0 = (size_t)f0 * PP;
-        fill_tile<T, CIN, PROA, true>(tileA, a.A, row0, rows, P, tid);
-        fill_tile<T, COUT, PRO_DY, false>(tileD, a.D, row0, rows, P, tid);
-        if (rows < prev_rows)                                    // a shorter (last) group: clear the stale dy rows
-            for (int i = tid; i < (prev_rows - rows) * CSD; i += NT) tileD[rows * CSD + i] = from_f32<T>(0.f);
-        prev_rows = rows;
-        for (int r = tid; r < RP; r += NT) hmap[r] = halo_index(r, rows, P);
+        build_row_tables(gm, grp, RP, rowg, hmap, tid);
+        fill_halo<T, CIN, PROA>(tileA, a.A, gm, grp, tid);
         __syncthreads();
-        const int ksteps = (rows + 31) / 32;
+        fill_rows<T, COUT, PRO_DY>(tileD, a.D, rowg, RP, tid);
+        __syncthreads();
+        const int ksteps = RP / 32;
 #pragma unroll 1
         for (int ks = 0; ks < ksteps; ++ks) {
             const int r0 = ks * 32;
@@ -509,7 +559,7 @@ __global__ __launch_bounds__(NT) void drn_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
                 for (int t = 0; t < TPP; ++t) {
                     const int tap = blockIdx.y * TPP + t;
-                    const int off = TAPS == 9 ? ((tap / 3 - 1) * HW2 + (tap % 3 - 1)) : 0;
+                    const int off = TAPS == 9 ? ((tap / 3 - 1) * W2 + (tap % 3 - 1)) : 0;
 #pragma unroll
                     for (int j = 0; j < WN; ++j) {
                         const int ci0 = (wn * WN + j) * 16 + 4 * p;
@@ -530,7 +580,7 @@ __global__ __launch_bounds__(NT) void drn_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
                     for (int t = 0; t < TPP; ++t) {
                         const int tap = blockIdx.y * TPP + t;
-                        const int off = TAPS == 9 ? ((tap / 3 - 1) * HW2 + (tap % 3 - 1)) : 0;
+                        const int off = TAPS == 9 ? ((tap / 3 - 1) * W2 + (tap % 3 - 1)) : 0;
 #pragma unroll
                         for (int j = 0; j < WN; ++j) {
                             const float bfr = reinterpret_cast<const float *>(tileA)[(h + off) * CSA + (wn * WN + j) * 16 + cq];
@@ -589,30 +639,45 @@ struct DrnWs {
 
 constexpr int MASK_ROWS = 512, WG_GROUPS = 256, PART_MAX = 128;
 
-size_t tile_bytes(int dtype, int P, int F, int C) { return (size_t)F * (P + 2) * (P + 2) * (C * dtype_size(dtype) + PADB); }
+// tile side: whole frame when it fits (bf16: <= 13, fp32: <= 9 -- two 128-channel images must fit 160 KB), else the
+// frame is cut into the fewest equal tiles per dimension
+void choose_tile(int dtype, int P, int *t, int *nt) {
+    const int tsmax = dtype == MIVIT_BF16 ? 13 : 9;
+    *nt = ceil_div(P, tsmax);
+    *t = ceil_div(P, *nt);
+}
+Geom make_geom(int dtype, int N, int P, int F) {
+    Geom g{};
+    int t, nt;
+    choose_tile(dtype, P, &t, &nt);
+    g.N = N; g.P = P; g.PP = P * P; g.th = t; g.tw = t; g.ntx = nt; g.tpf = nt * nt; g.units = N * g.tpf;
+    g.F = F; g.HPt = (t + 2) * (t + 2); g.RT = F * t * t;
+    return g;
+}
+size_t image_bytes(int dtype, int t, int F, int C) { return (size_t)F * (t + 2) * (t + 2) * (C * dtype_size(dtype) + PADB); }
 
-// frames per workgroup: as many as fit 176 output pixels and the LDS need(F) <= 160 KB
+// slots per workgroup: as many as fit 176 output pixels and need(F) <= 160 KB of LDS
 template <typename NeedFn>
-int frames_fit(int P, NeedFn need) {
-    int F = (MAXM * 16) / (P * P);
+int slots_fit(int t, NeedFn need) {
+    int F = (MAXM * 16) / (t * t);
     while (F >= 1 && need(F) > (size_t)160 * 1024) --F;
     return F;
 }
-int conv_frames(int dtype, int P, int CIN, int CIN2) {
-    return frames_fit(P, [&](int F) { return tile_bytes(dtype, P, F, CIN) + (CIN2 ? tile_bytes(dtype, P, F, CIN2) : 0) + 8 * 2 * 32 * 4; });
+size_t conv_lds(int dtype, int t, int F, int CIN, int CIN2) {
+    return image_bytes(dtype, t, F, CIN) + (CIN2 ? image_bytes(dtype, t, F, CIN2) : 0) + 8 * 2 * 32 * 4 + 2 * ROWS_PAD * 4;
 }
-size_t wgrad_lds(int dtype, int P, int F, int CIN, int COUT) {
-    const int RP = (F * P * P + 31) / 32 * 32;
-    return tile_bytes(dtype, P, F, CIN) + (size_t)RP * (COUT * dtype_size(dtype) + PADB) + (size_t)RP * 4;
+size_t wgrad_lds(int dtype, int t, int F, int CIN, int COUT) {
+    const int RP = (F * t * t + 31) / 32 * 32;
+    return image_bytes(dtype, t, F, CIN) + (size_t)RP * (COUT * dtype_size(dtype) + PADB) + (size_t)RP * 8;
 }
-int wgrad_frames(int dtype, int P, int CIN, int COUT) {
-    return frames_fit(P, [&](int F) { return wgrad_lds(dtype, P, F, CIN, COUT); });
-}
-int conv0_frames(int P) { return std::max(1, std::min(512 / (P * P), 64)); }
+int conv0_slots(int t) { return std::max(1, 512 / (t * t)); }
 
 bool drn_train_supported(int dtype, int P) {
-    if (P < 3) return false;
-    return conv_frames(dtype, P, 128, 128) >= 1 && wgrad_frames(dtype, P, 128, 128) >= 1;
+    if (P < 1 || P > 4096) return false;
+    int t, nt;
+    choose_tile(dtype, P, &t, &nt);
+    return slots_fit(t, [&](int F) { return conv_lds(dtype, t, F, 128, 128); }) >= 1 &&
+           slots_fit(t, [&](int F) { return wgrad_lds(dtype, t, F, 128, 128); }) >= 1;
 }
 
 DrnWs make_ws(int dtype, int N, int P, int E) {
@@ -626,7 +691,9 @@ DrnWs make_ws(int dtype, int N, int P, int E) {
     w.bcoef = take(7 * 3 * CSTR * 4);
     w.pooled = take((size_t)N * 128 * 4);
     w.dpooled = take((size_t)N * 128 * 4);
-    w.parts_cap = std::max(N, (int)((R + MASK_ROWS - 1) / MASK_ROWS)) + 8;
+    int t, nt;
+    choose_tile(dtype, P, &t, &nt);
+    w.parts_cap = std::max(N * nt * nt, (int)((R + MASK_ROWS - 1) / MASK_ROWS)) + 8;
     w.part = take((size_t)w.parts_cap * 3 * 128 * 4 * 2);
     w.part2 = take((size_t)PART_MAX * 3 * 128 * 4);
     for (int i = 0; i < 3; ++i) w.X[i] = take(R * 128 * es);
@@ -680,12 +747,14 @@ int bn_finalize(const Ctx &c, int i, const float *part, int nb) {
 template <typename T, int CIN, int COUT, int SECOND, int PRO, int CIN2>
 int run_conv(const Ctx &c, const ConvArgs &proto, int *nblocks) {
     ConvArgs a = proto;
-    a.N = c.N; a.P = c.P;
-    a.F = conv_frames(c.dtype, c.P, CIN, SECOND == 2 ? CIN2 : 0);
-    const size_t lds = tile_bytes(c.dtype, c.P, a.F, CIN) + (SECOND == 2 ? tile_bytes(c.dtype, c.P, a.F, CIN2) : 0) + 8 * 2 * 32 * 4;
+    int t, nt;
+    choose_tile(c.dtype, c.P, &t, &nt);
+    const int F = slots_fit(t, [&](int f) { return conv_lds(c.dtype, t, f, CIN, SECOND == 2 ? CIN2 : 0); });
+    a.g = make_geom(c.dtype, c.N, c.P, F);
+    const size_t lds = conv_lds(c.dtype, t, F, CIN, SECOND == 2 ? CIN2 : 0);
     auto kern = drn_conv_kernel<T, CIN, COUT, SECOND, PRO, CIN2>;
     RC(set_lds(kern, lds));
-    const int blocks = ceil_div(c.N, a.F);
+    const int blocks = ceil_div(a.g.units, F);
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(NT), lds, c.s, a);
     MIVIT_LAUNCH_CHECK();
     if (nblocks) *nblocks = blocks;
@@ -709,11 +778,12 @@ int forward_t(const Ctx &c, const float *x, float *tokens) {
     float *part = c.part(), *part_b = part + (size_t)c.w.parts_cap * 3 * 128;
     int nb = 0;
     {   // conv0
-        const int F = conv0_frames(c.P), HP = (c.P + 2) * (c.P + 2);
-        nb = ceil_div(c.N, F);
-        const size_t lds = (size_t)F * HP * 4 + 16 * 2 * 32 * 4;
-        hipLaunchKernelGGL(drn_conv0_kernel<T>, dim3(nb), dim3(NT), lds, c.s, x, c.prm->conv[0].weight, static_cast<T *>(c.y(0)), part,
-                           c.N, c.P, F);
+        int t, nt;
+        choose_tile(c.dtype, c.P, &t, &nt);
+        const Geom g = make_geom(c.dtype, c.N, c.P, conv0_slots(t));
+        nb = ceil_div(g.units, g.F);
+        const size_t lds = (size_t)g.F * g.HPt * 4 + 16 * 2 * 32 * 4 + (size_t)2 * g.RT * 4;
+        hipLaunchKernelGGL(drn_conv0_kernel<T>, dim3(nb), dim3(NT), lds, c.s, x, c.prm->conv[0].weight, static_cast<T *>(c.y(0)), part, g);
         MIVIT_LAUNCH_CHECK();
         RC(bn_finalize(c, 0, part, nb));
     }
@@ -781,11 +851,14 @@ int bn_bwd_finalize(const Ctx &c, int i, int which, int nb, const mivit_deepresn
 template <typename T, int CIN, int COUT, int TAPS, int PROA>
 int run_wgrad(const Ctx &c, const TileSrc &A, const TileSrc &D, float *dW) {
     WgradArgs a{};
-    a.N = c.N; a.P = c.P; a.F = wgrad_frames(c.dtype, c.P, CIN, COUT);
-    a.ngroups = ceil_div(c.N, a.F);
+    int t, nt;
+    choose_tile(c.dtype, c.P, &t, &nt);
+    const int F = slots_fit(t, [&](int f) { return wgrad_lds(c.dtype, t, f, CIN, COUT); });
+    a.g = make_geom(c.dtype, c.N, c.P, F);
+    a.ngroups = ceil_div(a.g.units, F);
     a.A = A; a.D = D; a.slab = static_cast<float *>(at(c.ws, c.w.slab));
     const int G = std::min(a.ngroups, TAPS == 9 ? 85 : WG_GROUPS);
-    const size_t lds = wgrad_lds(c.dtype, c.P, a.F, CIN, COUT);
+    const size_t lds = wgrad_lds(c.dtype, t, F, CIN, COUT);
     auto kern = drn_wgrad_kernel<T, CIN, COUT, TAPS, PROA>;
     RC(set_lds(kern, lds));
     hipLaunchKernelGGL(kern, dim3(G, TAPS == 9 ? 3 : 1), dim3(NT), lds, c.s, a);
@@ -850,11 +923,14 @@ int backward_t(const Ctx &c, const float *x, const float *dtokens, const mivit_d
     RC((run_mask<T, 32, false, false>(c, X2, 0, 0, X2, &nb)));
     RC(bn_bwd_finalize(c, 0, 1, nb, gr));
     {   // first convolution's weight gradient
-        const int F = conv0_frames(c.P), HP = (c.P + 2) * (c.P + 2), ngroups = ceil_div(c.N, F), G = std::min(ngroups, 256);
-        const size_t lds = (size_t)F * HP * 4 + 16 * 288 * 4;
+        int t, nt;
+        choose_tile(c.dtype, c.P, &t, &nt);
+        const Geom g = make_geom(c.dtype, c.N, c.P, conv0_slots(t));
+        const int ngroups = ceil_div(g.units, g.F), G = std::min(ngroups, 256);
+        const size_t lds = (size_t)g.F * g.HPt * 4 + 16 * 288 * 4 + (size_t)2 * g.RT * 4;
         float *slab = static_cast<float *>(at(c.ws, c.w.slab));
         const TileSrc dy0{X2, c.y(0), c.bco(0), nullptr};
-        hipLaunchKernelGGL(drn_wgrad0_kernel<T>, dim3(G), dim3(NT), lds, c.s, x, dy0, slab, c.N, c.P, F, ngroups);
+        hipLaunchKernelGGL(drn_wgrad0_kernel<T>, dim3(G), dim3(NT), lds, c.s, x, dy0, slab, g, ngroups);
         MIVIT_LAUNCH_CHECK();
         RC(launch_slab_reduce(slab, G, 288, gr->conv[0].weight, 0, c.s));
     }
@@ -896,7 +972,7 @@ extern "C" int mivit_deepresnet_train_fwd(int dtype, const mivit_deepresnet_para
     RC(check_params(params));
     MIVIT_CHECK(x && tokens && workspace, "deepresnet_train_fwd: null pointer");
     MIVIT_CHECK(N > 0 && E > 0, "deepresnet_train_fwd: empty problem");
-    if (!drn_train_supported(dtype, P)) { mivit_set_error("deepresnet_train_fwd: frame side %d does not fit the LDS-resident kernels", P); return 3; }
+    if (!drn_train_supported(dtype, P)) { mivit_set_error("deepresnet_train_fwd: unsupported frame side %d", P); return 3; }
     Ctx c{dtype, N, P, E, eps, momentum, workspace, make_ws(dtype, N, P, E), static_cast<hipStream_t>(stream), params};
     MIVIT_CHECK(workspace_bytes >= c.w.total, "deepresnet_train_fwd: workspace too small (%zu < %zu)", workspace_bytes, c.w.total);
     prof_set_tag(MIVIT_PROF_OP);
@@ -920,7 +996,7 @@ extern "C" int mivit_deepresnet_train_bwd(int dtype, const mivit_deepresnet_para
     MIVIT_CHECK(x && dtokens && workspace && grads && grads->fc_weight && grads->fc_bias, "deepresnet_train_bwd: null pointer");
     for (int i = 0; i < 7; ++i)
         MIVIT_CHECK(grads->conv[i].weight && grads->conv[i].gamma && grads->conv[i].beta, "deepresnet_train_bwd: null gradient %d", i);
-    if (!drn_train_supported(dtype, P)) { mivit_set_error("deepresnet_train_bwd: frame side %d does not fit the LDS-resident kernels", P); return 3; }
+    if (!drn_train_supported(dtype, P)) { mivit_set_error("deepresnet_train_bwd: unsupported frame side %d", P); return 3; }
     Ctx c{dtype, N, P, E, eps, 0.f, workspace, make_ws(dtype, N, P, E), static_cast<hipStream_t>(stream), params};
     MIVIT_CHECK(workspace_bytes >= c.w.total, "deepresnet_train_bwd: workspace too small (%zu < %zu)", workspace_bytes, c.w.total);
     prof_set_tag(MIVIT_PROF_OP);

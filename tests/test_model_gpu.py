@@ -297,7 +297,10 @@ def _worst(got, ref):
 
 @pytest.mark.parametrize("precision,P,B,T,E", [("fp32", 9, 2, 5, 64), ("fp32", 7, 1, 3, 32), ("fp32", 5, 3, 7, 128),
                                                ("bf16", 9, 4, 30, 64), ("bf16", 13, 2, 3, 128), ("bf16", 7, 3, 11, 64),
-                                               ("bf16", 11, 1, 5, 32)])
+                                               ("bf16", 11, 1, 5, 32),
+                                               # frames cut into tiles (halo cells come from the neighbouring pixels)
+                                               ("fp32", 13, 2, 3, 64), ("fp32", 20, 1, 2, 32), ("bf16", 16, 2, 3, 64),
+                                               ("bf16", 30, 1, 2, 32)])
 def test_deepresnet_native_training_matches_torch_stack(precision, P, B, T, E):
     """Same module, same inputs: native forward/backward (batch-statistics BatchNorm, running-stat update, every
     parameter gradient) against the fp32 PyTorch-ROCm conv stack, on frame counts that leave the last workgroup ragged.
