@@ -73,6 +73,9 @@ __device__ __forceinline__ int cell_source(const Geom &g, int group, int cell) {
     if (y < 0 || y >= g.P || x < 0 || x >= g.P) return -1;
     return frame * g.PP + y * g.P + x;
 }
+__device__ __forceinline__ void build_cell_table(const Geom &g, int group, int *cellsrc, int tid) {
+    for (int i = tid; i < g.F * g.HPt; i += 512) cellsrc[i] = cell_source(g, group, i);
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // normalise-on-load
@@ -109,11 +112,11 @@ __device__ __forceinline__ void transform_store(T *dst, const TileSrc &s, int64_
 
 // zero-haloed images of all F slots: every cell is written (loaded + transformed, or zero)
 template <typename T, int C, int PRO>
-__device__ __forceinline__ void fill_halo(T *tile, const TileSrc &s, const Geom &g, int group, int tid) {
+__device__ __forceinline__ void fill_halo(T *tile, const TileSrc &s, const Geom &g, const int *cellsrc, int tid) {
     constexpr int V = vec_el<T>(), CV = C / V, CS = C + pad_el<T>();
     for (int i = tid; i < g.F * g.HPt * CV; i += NT) {
         const int cell = i / CV, c = (i - cell * CV) * V;
-        transform_store<T, C, PRO>(tile + cell * CS + c, s, cell_source(g, group, cell), c);
+        transform_store<T, C, PRO>(tile + cell * CS + c, s, cellsrc[cell], c);
     }
 }
 
@@ -241,11 +244,13 @@ __global__ __launch_bounds__(NT) void drn_conv_kernel(const ConvArgs a) {
     T *tileA = reinterpret_cast<T *>(smem);
     T *tileB = tileA + g.F * g.HPt * CS;
     float *red = reinterpret_cast<float *>(tileB + (SECOND == 2 ? g.F * g.HPt * CS2 : 0));   // [8][2][32]
-    int *rowg = reinterpret_cast<int *>(red + 8 * 2 * 32), *rowc = rowg + ROWS_PAD;
+    int *rowg = reinterpret_cast<int *>(red + 8 * 2 * 32), *rowc = rowg + ROWS_PAD, *cellsrc = rowc + ROWS_PAD;
 
     build_row_tables(g, blockIdx.x, ROWS_PAD, rowg, rowc, tid);
-    fill_halo<T, CIN, PRO>(tileA, a.A, g, blockIdx.x, tid);
-    if (SECOND == 2) fill_halo<T, CIN2, PRO_DY>(tileB, a.B, g, blockIdx.x, tid);
+    build_cell_table(g, blockIdx.x, cellsrc, tid);
+    __syncthreads();
+    fill_halo<T, CIN, PRO>(tileA, a.A, g, cellsrc, tid);
+    if (SECOND == 2) fill_halo<T, CIN2, PRO_DY>(tileB, a.B, g, cellsrc, tid);
     __syncthreads();
 
     const int ng = wave % NG, mq = wave / NG, per = (NM + MQ - 1) / MQ, mt0 = mq * per;
@@ -527,7 +532,7 @@ __global__ __launch_bounds__(NT) void drn_wgrad_kernel(const WgradArgs a) {
     const int W2 = gm.tw + 2, RP = (gm.RT + 31) / 32 * 32;
     T *tileA = reinterpret_cast<T *>(smem);                     // [F*HPt][CSA]  zero-haloed input activation
     T *tileD = tileA + gm.F * gm.HPt * CSA;                     // [RP][CSD]     dy, plain row order, dead rows zero
-    int *rowg = reinterpret_cast<int *>(tileD + RP * CSD), *hmap = rowg + RP;   // [RP] each
+    int *rowg = reinterpret_cast<int *>(tileD + RP * CSD), *hmap = rowg + RP, *cellsrc = hmap + RP;   // [RP], [RP], [F*HPt]
     f32x4 acc[TPP][WM][WN];
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -539,8 +544,9 @@ __global__ __launch_bounds__(NT) void drn_wgrad_kernel(const WgradArgs a) {
     for (int grp = blockIdx.x; grp < a.ngroups; grp += gridDim.x) {
         __syncthreads();
         build_row_tables(gm, grp, RP, rowg, hmap, tid);
-        fill_halo<T, CIN, PROA>(tileA, a.A, gm, grp, tid);
+        build_cell_table(gm, grp, cellsrc, tid);
         __syncthreads();
+        fill_halo<T, CIN, PROA>(tileA, a.A, gm, cellsrc, tid);
         fill_rows<T, COUT, PRO_DY>(tileD, a.D, rowg, RP, tid);
         __syncthreads();
         const int ksteps = RP / 32;
@@ -664,11 +670,13 @@ int slots_fit(int t, NeedFn need) {
     return F;
 }
 size_t conv_lds(int dtype, int t, int F, int CIN, int CIN2) {
-    return image_bytes(dtype, t, F, CIN) + (CIN2 ? image_bytes(dtype, t, F, CIN2) : 0) + 8 * 2 * 32 * 4 + 2 * ROWS_PAD * 4;
+    return image_bytes(dtype, t, F, CIN) + (CIN2 ? image_bytes(dtype, t, F, CIN2) : 0) + 8 * 2 * 32 * 4 + 2 * ROWS_PAD * 4 +
+           (size_t)F * (t + 2) * (t + 2) * 4;
 }
 size_t wgrad_lds(int dtype, int t, int F, int CIN, int COUT) {
     const int RP = (F * t * t + 31) / 32 * 32;
-    return image_bytes(dtype, t, F, CIN) + (size_t)RP * (COUT * dtype_size(dtype) + PADB) + (size_t)RP * 8;
+    return image_bytes(dtype, t, F, CIN) + (size_t)RP * (COUT * dtype_size(dtype) + PADB) + (size_t)RP * 8 +
+           (size_t)F * (t + 2) * (t + 2) * 4;
 }
 int conv0_slots(int t) { return std::max(1, 512 / (t * t)); }
 
