@@ -25,7 +25,7 @@ extern "C" {
 
 #define MIVIT_ABI_VERSION 1
 
-enum { MIVIT_F32 = 0, MIVIT_BF16 = 1 };
+enum { MIVIT_F32 = 0, MIVIT_BF16 = 1, MIVIT_F16 = 2 };
 enum { MIVIT_ACT_NONE = 0, MIVIT_ACT_RELU = 1, MIVIT_ACT_LEAKY_RELU = 2, MIVIT_ACT_GELU = 3 };
 enum { MIVIT_EMBED_LINEAR = 0, MIVIT_EMBED_CNN = 1, MIVIT_EMBED_EXTERNAL = 2 };
 enum { MIVIT_FUSION_NONE = 0, MIVIT_FUSION_EARLY = 1, MIVIT_FUSION_LATE = 2 };

@@ -11,7 +11,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libmivit_hip.so")
 
 ABI_VERSION = 1
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_LEAKY_RELU, ACT_GELU = 0, 1, 2, 3
 EMBED_LINEAR, EMBED_CNN, EMBED_EXTERNAL = 0, 1, 2
 FUSION_NONE, FUSION_EARLY, FUSION_LATE = 0, 1, 2

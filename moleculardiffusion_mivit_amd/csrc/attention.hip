@@ -387,25 +387,26 @@ int attention_max_seq(int dtype, int Dh) {
 int launch_attention_fwd(int dtype, const void *qkv, int B, int S, int H, int Dh, void *ctx, hipStream_t s) {
     MIVIT_CHECK(B > 0 && S > 0 && H > 0 && Dh > 0, "attention_fwd: empty problem");
     if (attention_fast_supported(dtype, S, Dh)) return launch_attention_fwd_fast(qkv, B, S, H, Dh, ctx, s);
-    return dtype == MIVIT_F32 ? attn_fwd_t<float>(qkv, B, S, H, Dh, ctx, s) : attn_fwd_t<bf16>(qkv, B, S, H, Dh, ctx, s);
+    return dtype == MIVIT_F32 ? attn_fwd_t<float>(qkv, B, S, H, Dh, ctx, s)
+         : dtype == MIVIT_BF16 ? attn_fwd_t<bf16>(qkv, B, S, H, Dh, ctx, s) : attn_fwd_t<f16>(qkv, B, S, H, Dh, ctx, s);
 }
 int launch_attention_bwd(int dtype, const void *qkv, const void *dctx, int B, int S, int H, int Dh, void *dqkv,
                          hipStream_t s) {
     MIVIT_CHECK(B > 0 && S > 0 && H > 0 && Dh > 0, "attention_bwd: empty problem");
     if (attention_fast_supported(dtype, S, Dh)) return launch_attention_bwd_fast(qkv, dctx, B, S, H, Dh, dqkv, s);
     return dtype == MIVIT_F32 ? attn_bwd_t<float>(qkv, dctx, B, S, H, Dh, dqkv, s)
-                              : attn_bwd_t<bf16>(qkv, dctx, B, S, H, Dh, dqkv, s);
+         : dtype == MIVIT_BF16 ? attn_bwd_t<bf16>(qkv, dctx, B, S, H, Dh, dqkv, s) : attn_bwd_t<f16>(qkv, dctx, B, S, H, Dh, dqkv, s);
 }
 
 extern "C" int mivit_attention_max_seq(int dtype, int Dh) { return attention_max_seq(dtype, Dh); }
 extern "C" int mivit_attention_fwd(int dtype, const void *qkv, int B, int S, int H, int Dh, void *ctx, void *stream) {
-    MIVIT_CHECK(dtype == MIVIT_F32 || dtype == MIVIT_BF16, "bad dtype %d", dtype);
+    MIVIT_CHECK(dtype == MIVIT_F32 || dtype == MIVIT_BF16 || dtype == MIVIT_F16, "bad dtype %d", dtype);
     MIVIT_CHECK(qkv && ctx, "attention_fwd: null pointer");
     return launch_attention_fwd(dtype, qkv, B, S, H, Dh, ctx, static_cast<hipStream_t>(stream));
 }
 extern "C" int mivit_attention_bwd(int dtype, const void *qkv, const void *dctx, int B, int S, int H, int Dh,
                                    void *dqkv, void *stream) {
-    MIVIT_CHECK(dtype == MIVIT_F32 || dtype == MIVIT_BF16, "bad dtype %d", dtype);
+    MIVIT_CHECK(dtype == MIVIT_F32 || dtype == MIVIT_BF16 || dtype == MIVIT_F16, "bad dtype %d", dtype);
     MIVIT_CHECK(qkv && dctx && dqkv, "attention_bwd: null pointer");
     return launch_attention_bwd(dtype, qkv, dctx, B, S, H, Dh, dqkv, static_cast<hipStream_t>(stream));
 }

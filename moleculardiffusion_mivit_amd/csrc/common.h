@@ -36,15 +36,21 @@ void mivit_set_error(const char *fmt, ...);
 // ------------------------------------------------------------------------------------------------
 // element types
 // ------------------------------------------------------------------------------------------------
-struct bf16 {
+// 16-bit storage types: KIND 0 = bfloat16 (the fast path), 1 = IEEE half (fp16 mode, general kernels only)
+template <int KIND>
+struct h16 {
     uint16_t v;
 };
+typedef h16<0> bf16;
+typedef h16<1> f16;
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 
 __device__ __forceinline__ float to_f32(float x) { return x; }
 __device__ __forceinline__ float to_f32(bf16 x) { return __uint_as_float(((uint32_t)x.v) << 16); }
+__device__ __forceinline__ float to_f32(f16 x) { return (float)__builtin_bit_cast(_Float16, x.v); }
 
 template <typename T>
 __device__ __forceinline__ T from_f32(float x);
@@ -60,7 +66,7 @@ __device__ __forceinline__ bf16 from_f32<bf16>(float x) {
     return r;
 }
 
-static inline size_t dtype_size(int dtype) { return dtype == MIVIT_BF16 ? 2 : 4; }
+static inline size_t dtype_size(int dtype) { return dtype == MIVIT_F32 ? 4 : 2; }
 
 // activation and its derivative.  `saved` is the post-activation for relu/leaky, the PRE-activation for gelu.
 __device__ __forceinline__ float act_fwd(int act, float u) {
@@ -121,6 +127,18 @@ struct Mma<bf16> {
     }
 };
 
+template <>
+struct Mma<f16> {
+    static constexpr int KS = 32;
+    typedef f16x8 Frag;
+    static __device__ __forceinline__ Frag load(const f16 *img, int rs, int /*ks*/, int r0, int k0, int lane) {
+        return *reinterpret_cast<const f16x8 *>(img + (r0 + (lane & 15)) * rs + k0 + 8 * (lane >> 4));
+    }
+    static __device__ __forceinline__ f32x4 mma(Frag a, Frag b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+};
+
 // wave-level helpers (wave = 64 lanes)
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -134,6 +152,12 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // 16-byte vector access of V = 16 / sizeof(T) consecutive elements, widened to fp32
+template <>
+__device__ __forceinline__ f16 from_f32<f16>(float x) {
+    f16 r;
+    r.v = __builtin_bit_cast(unsigned short, (_Float16)x);   // RNE; overflow -> inf (what loss scaling watches for)
+    return r;
+}
 __device__ __forceinline__ void load16(const float *p, float *out) {
     const float4 v = *reinterpret_cast<const float4 *>(p);
     out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
@@ -146,6 +170,17 @@ __device__ __forceinline__ void load16(const bf16 *p, float *out) {
         out[2 * i] = __uint_as_float(w[i] << 16);
         out[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
     }
+}
+__device__ __forceinline__ void load16(const f16 *p, float *out) {
+    const f16x8 v = *reinterpret_cast<const f16x8 *>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) out[i] = (float)v[i];
+}
+__device__ __forceinline__ void store16(f16 *p, const float *v) {
+    f16x8 o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (_Float16)v[i];
+    *reinterpret_cast<f16x8 *>(p) = o;
 }
 __device__ __forceinline__ void store16(float *p, const float *v) {
     *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]);
@@ -272,8 +307,9 @@ size_t batch_colsum_ws_bytes(int B, int rows, int E);
 int launch_batch_colsum(int dtype, const void *x, int B, int S, int E, int s0, int rows, float *out, void *ws,
                         size_t ws_bytes, hipStream_t s);
 // generic conversions / copies
+// 16-bit sides are of kind `dtype16` (MIVIT_BF16 or MIVIT_F16)
 int launch_convert(int src_is_f32, const void *src, int64_t lds_, int dst_dtype_is_f32, void *dst, int64_t ldd,
-                   int rows, int cols, int accumulate, hipStream_t s);
+                   int rows, int cols, int accumulate, hipStream_t s, int dtype16 = MIVIT_BF16);
 int launch_fill_zero(void *p, size_t bytes, hipStream_t s);
 
 // in-library kernel timing (misc.hip): the engine sets the category, launch sites bracket their main kernel

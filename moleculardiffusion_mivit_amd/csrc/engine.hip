@@ -71,7 +71,7 @@ Ws make_ws(const mivit_plan *p, int B, int T, bool bwd) {
     Ws w = {};
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes, 256); return o; };
-    w.wsh = c.dtype == MIVIT_BF16 ? take((size_t)p->arena * 2) : 0;
+    w.wsh = c.dtype != MIVIT_F32 ? take((size_t)p->arena * 2) : 0;
     w.emb = take(Mt * E * ts); w.mean0 = take(Mt * 4); w.rstd0 = take(Mt * 4);
     w.x0 = take(M * E * ts);
     const int nsets = bwd ? L : 1;
@@ -139,7 +139,7 @@ int lin_fwd(int dtype, const void *x, int x_f32, int64_t ldx, const void *W, con
     }
     LinearFwdArgs a = {};
     a.dtype = dtype; a.x = x; a.x_is_f32 = x_f32 || dtype == MIVIT_F32; a.ldx = ldx; a.W = W;
-    a.w_is_bf16 = dtype == MIVIT_BF16; a.bias = b;
+    a.w_is_bf16 = dtype != MIVIT_F32; a.bias = b;
     a.M = M; a.N = N; a.K = K; a.act = act; a.resid = resid; a.ldr = ldr; a.y = y; a.ldy = ldy; a.y_preact = pre;
     a.y_is_f32 = y_f32;
     prof_set_tag(x_f32 && K > 1024 ? MIVIT_PROF_EMBED_FWD : MIVIT_PROF_LINEAR_FWD);
@@ -155,7 +155,7 @@ int lin_dgrad(int dtype, const void *dy, int64_t lddy, const void *W, int M, int
     }
     LinearDgradArgs a = {};
     a.dtype = dtype; a.dy = dy; a.dy_is_f32 = dtype == MIVIT_F32; a.lddy = lddy; a.W = W;
-    a.w_is_bf16 = dtype == MIVIT_BF16; a.M = M; a.N = N; a.K = K;
+    a.w_is_bf16 = dtype != MIVIT_F32; a.M = M; a.N = N; a.K = K;
     a.act = act; a.saved = saved; a.lds = lds; a.dres = dres; a.lddr = lddr; a.dx = dx; a.lddx = lddx; a.dx_is_f32 = dx_f32;
     prof_set_tag(MIVIT_PROF_LINEAR_DGRAD);
     return launch_linear_dgrad(a, s);
@@ -229,7 +229,7 @@ extern "C" mivit_plan *mivit_plan_create(const mivit_config *cfg) {
     const mivit_config &c = *cfg;
 #define PLAN_CHECK(cond, ...) do { if (!(cond)) { mivit_set_error(__VA_ARGS__); return nullptr; } } while (0)
     PLAN_CHECK(c.abi_version == MIVIT_ABI_VERSION, "plan_create: ABI version %d != %d", c.abi_version, MIVIT_ABI_VERSION);
-    PLAN_CHECK(c.dtype == MIVIT_F32 || c.dtype == MIVIT_BF16, "plan_create: bad dtype %d", c.dtype);
+    PLAN_CHECK(c.dtype == MIVIT_F32 || c.dtype == MIVIT_BF16 || c.dtype == MIVIT_F16, "plan_create: bad dtype %d", c.dtype);
     PLAN_CHECK(c.embedding >= MIVIT_EMBED_LINEAR && c.embedding <= MIVIT_EMBED_EXTERNAL, "plan_create: bad embedding %d", c.embedding);
     PLAN_CHECK(c.embed_dim > 0 && c.num_heads > 0 && c.hidden_dim > 0 && c.num_layers >= 0, "plan_create: bad model dims");
     PLAN_CHECK(c.embed_dim % c.num_heads == 0, "embed_dim must be divisible by num_heads");
@@ -351,15 +351,15 @@ static int forward_impl(const mivit_plan *plan, const float *params, const float
     void *ws = workspace;
     const float *P = params;
     // bf16 mode: one conversion of the whole fp32 arena per step; every GEMM then stages bf16 weights
-    if (dt == MIVIT_BF16) RC(launch_convert(1, P, plan->arena, 0, at(ws, w.wsh), plan->arena, 1, (int)plan->arena, 0, s));
+    if (dt != MIVIT_F32) RC(launch_convert(1, P, plan->arena, 0, at(ws, w.wsh), plan->arena, 1, (int)plan->arena, 0, s, dt));
     auto WT = [&](int64_t off) -> const void * {
-        return dt == MIVIT_BF16 ? static_cast<const void *>(static_cast<const bf16 *>(at(ws, w.wsh)) + off)
+        return dt != MIVIT_F32 ? static_cast<const void *>(static_cast<const bf16 *>(at(ws, w.wsh)) + off)
                                 : static_cast<const void *>(P + off);
     };
 
     // 1. frame embedding: one token per whole frame (models.py:146-199), [B*T, P*P] x [E, P*P]^T
     if (c.embedding == MIVIT_EMBED_EXTERNAL) {
-        RC(launch_convert(1, x, E, dt == MIVIT_F32, at(ws, w.emb), E, Mt, E, 0, s));
+        RC(launch_convert(1, x, E, dt == MIVIT_F32, at(ws, w.emb), E, Mt, E, 0, s, dt));
     } else {
         const int K = c.patch_size * c.patch_size;
         if (embed_dma_supported(dt, Mt, K, E)) {
@@ -427,8 +427,8 @@ static int forward_impl(const mivit_plan *plan, const float *params, const float
     const void *head_in = at(ws, w.pooled);
     if (c.fusion == MIVIT_FUSION_LATE) {
         const int f32 = dt == MIVIT_F32;
-        RC(launch_convert(f32, at(ws, w.pooled), E, f32, at(ws, w.head_in), 2 * E, B, E, 0, s));
-        RC(launch_convert(f32, at(ws, w.fp_out), E, f32, col_ptr(at(ws, w.head_in), E, dt), 2 * E, B, E, 0, s));
+        RC(launch_convert(f32, at(ws, w.pooled), E, f32, at(ws, w.head_in), 2 * E, B, E, 0, s, dt));
+        RC(launch_convert(f32, at(ws, w.fp_out), E, f32, col_ptr(at(ws, w.head_in), E, dt), 2 * E, B, E, 0, s, dt));
         head_in = at(ws, w.head_in);
     }
     RC(lin_fwd(dt, head_in, 0, plan->head_in, WT(plan->h0_w), P + plan->h0_b, B, c.head_hidden, plan->head_in,
@@ -449,7 +449,7 @@ int feature_projector_bwd(const mivit_plan *plan, const Ws &w, void *ws, const f
     const mivit_config &c = plan->c;
     const int dt = c.dtype, E = c.embed_dim, Fg = c.global_feature_dim;
     auto WT = [&](int64_t off) -> const void * {
-        return dt == MIVIT_BF16 ? static_cast<const void *>(static_cast<const bf16 *>(at(ws, w.wsh)) + off)
+        return dt != MIVIT_F32 ? static_cast<const void *>(static_cast<const bf16 *>(at(ws, w.wsh)) + off)
                                 : static_cast<const void *>(P + off);
     };
     RC(lin_wgrad(dt, dy, lddy, at(ws, w.fp_h), 0, E, B, E, E, G + plan->fp2_w, G + plan->fp2_b, at(ws, w.wgrad),
@@ -487,7 +487,7 @@ static int backward_impl(const mivit_plan *plan, const float *params, const floa
     void *wg = at(ws, w.wgrad);
     const size_t wgb = w.wgrad_bytes;
     auto WT = [&](int64_t off) -> const void * {
-        return dt == MIVIT_BF16 ? static_cast<const void *>(static_cast<const bf16 *>(at(ws, w.wsh)) + off)
+        return dt != MIVIT_F32 ? static_cast<const void *>(static_cast<const bf16 *>(at(ws, w.wsh)) + off)
                                 : static_cast<const void *>(P + off);
     };
 
@@ -498,7 +498,7 @@ static int backward_impl(const mivit_plan *plan, const float *params, const floa
             const void *xL = L > 0 ? at(ws, w.layer[L - 1].x2) : at(ws, w.x0);
             const void *head_in = c.fusion == MIVIT_FUSION_LATE ? at(ws, w.head_in) : at(ws, w.pooled);
             const void *dy = dout;
-            if (!f32) { RC(launch_convert(1, dout, O, 0, at(ws, w.dout_t), O, B, O, 0, s)); dy = at(ws, w.dout_t); }
+            if (!f32) { RC(launch_convert(1, dout, O, 0, at(ws, w.dout_t), O, B, O, 0, s, dt)); dy = at(ws, w.dout_t); }
             RC(lin_wgrad(dt, dy, O, at(ws, w.hh), 0, Hh, B, O, Hh, G + plan->h3_w, G + plan->h3_b, wg, wgb, s));
             RC(lin_dgrad(dt, dy, O, WT(plan->h3_w), B, O, Hh, MIVIT_ACT_RELU, at(ws, w.hh), Hh, nullptr, 0, at(ws, w.d_hh),
                          Hh, 0, s));
@@ -520,7 +520,7 @@ static int backward_impl(const mivit_plan *plan, const float *params, const floa
             } else {
                 const void *dp = at(ws, w.d_head_in);
                 if (Hin != E) {
-                    RC(launch_convert(f32, at(ws, w.d_head_in), Hin, f32, at(ws, w.d_pool_c), E, B, E, 0, s));
+                    RC(launch_convert(f32, at(ws, w.d_head_in), Hin, f32, at(ws, w.d_pool_c), E, B, E, 0, s, dt));
                     dp = at(ws, w.d_pool_c);
                 }
                 RC(launch_mean_pool_bwd(dt, dp, B, S, E, at(ws, w.dxb), s));
@@ -576,7 +576,7 @@ static int backward_impl(const mivit_plan *plan, const float *params, const floa
             a.ws = at(ws, w.ln); a.ws_bytes = w.ln_bytes;
             if (c.embedding == MIVIT_EMBED_EXTERNAL) {
                 prof_set_tag(MIVIT_PROF_LN_BWD); RC(launch_layernorm_bwd(a, s));                  // dxb = d(tokens)
-                if (dx_tokens) RC(launch_convert(f32, at(ws, w.dxb), E, 1, dx_tokens, E, Mt, E, 0, s));
+                if (dx_tokens) RC(launch_convert(f32, at(ws, w.dxb), E, 1, dx_tokens, E, Mt, E, 0, s, dt));
             } else {
                 bool cs = false;
                 RC(ln_bwd_bias(a, G + plan->emb_b, &cs, s));                                      // dxb = d(embedding out)

@@ -40,17 +40,24 @@ struct Cfg {
 
 template <typename TS> struct VecOf;
 template <> struct VecOf<float> { typedef float4 type; };
-template <> struct VecOf<bf16> { typedef uint4 type; };
+template <int K> struct VecOf<h16<K>> { typedef uint4 type; };
 
-__device__ __forceinline__ void unpack(const float4 &v, float *out) {
-    out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
-}
-__device__ __forceinline__ void unpack(const uint4 &v, float *out) {
-    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+// raw staged vector of source type TS -> floats
+template <typename TS>
+__device__ __forceinline__ void unpack(const typename VecOf<TS>::type &v, float *out) {
+    if constexpr (sizeof(TS) == 4) {
+        out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+    } else if constexpr (sizeof(TS) == 2 && __is_same(TS, bf16)) {
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        out[2 * i] = __uint_as_float(w[i] << 16);
-        out[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+        for (int i = 0; i < 4; ++i) {
+            out[2 * i] = __uint_as_float(w[i] << 16);
+            out[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+        }
+    } else {
+        const f16x8 h = __builtin_bit_cast(f16x8, v);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) out[i] = (float)h[i];
     }
 }
 // element-wise tail / unaligned path: zero fill beyond nvalid (static register indexing only: no scratch)
@@ -62,7 +69,8 @@ __device__ __forceinline__ float4 load_vec_guarded(const float *p, int nvalid) {
     v.w = nvalid > 3 ? p[3] : 0.f;
     return v;
 }
-__device__ __forceinline__ uint4 load_vec_guarded(const bf16 *p, int nvalid) {
+template <int K>
+__device__ __forceinline__ uint4 load_vec_guarded(const h16<K> *p, int nvalid) {
     uint32_t w[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -73,28 +81,21 @@ __device__ __forceinline__ uint4 load_vec_guarded(const bf16 *p, int nvalid) {
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
-template <typename T, int N>
-__device__ __forceinline__ void store_lds(T *dst, const float *v);
-template <>
-__device__ __forceinline__ void store_lds<float, 4>(float *dst, const float *v) {
-    *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-}
-template <>
-__device__ __forceinline__ void store_lds<float, 8>(float *dst, const float *v) {
-    *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-    *reinterpret_cast<float4 *>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
-}
+template <typename T>
 __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
-    return (uint32_t)from_f32<bf16>(lo).v | ((uint32_t)from_f32<bf16>(hi).v << 16);
+    return (uint32_t)from_f32<T>(lo).v | ((uint32_t)from_f32<T>(hi).v << 16);
 }
-template <>
-__device__ __forceinline__ void store_lds<bf16, 4>(bf16 *dst, const float *v) {
-    *reinterpret_cast<uint2 *>(dst) = make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3]));
-}
-template <>
-__device__ __forceinline__ void store_lds<bf16, 8>(bf16 *dst, const float *v) {
-    *reinterpret_cast<uint4 *>(dst) =
-        make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
+template <typename T, int N>
+__device__ __forceinline__ void store_lds(T *dst, const float *v) {
+    if constexpr (sizeof(T) == 4) {
+        *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+        if constexpr (N == 8) *reinterpret_cast<float4 *>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    } else if constexpr (N == 4) {
+        *reinterpret_cast<uint2 *>(dst) = make_uint2(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]));
+    } else {
+        *reinterpret_cast<uint4 *>(dst) =
+            make_uint4(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]), pack2<T>(v[4], v[5]), pack2<T>(v[6], v[7]));
+    }
 }
 
 // Two-phase staging: load() issues the global loads of one k-tile into registers (kept raw, so they can stay in
@@ -126,7 +127,7 @@ struct StageKC {
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             float v[V];
-            unpack(regs[p], v);
+            unpack<TS>(regs[p], v);
             store_lds<T, V>(img + (p * RPP + tid / TPR) * LDK + (tid % TPR) * V, v);
         }
     }
@@ -164,7 +165,7 @@ struct StageKS {
         const int rv = (tid % UR) * V, kg = (tid / UR) * KB;
         float v[KB][V];
 #pragma unroll
-        for (int i = 0; i < KB; ++i) unpack(regs[i], v[i]);
+        for (int i = 0; i < KB; ++i) unpack<TS>(regs[i], v[i]);
 #pragma unroll
         for (int j = 0; j < V; ++j) {
             float t[KB];
@@ -279,10 +280,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
         constexpr int LDC = BN + 4;         // fp32 row stride of the staging tile (16-byte aligned rows)
         static_assert((size_t)HR * LDC * 4 <= (size_t)(BM + BN) * LDK * sizeof(T), "staging tile must fit in the operand LDS");
         float *Cs = reinterpret_cast<float *>(smem);
-        bf16 *Ct = static_cast<bf16 *>(g.C);
-        bf16 *C2 = static_cast<bf16 *>(g.C2);
-        const bf16 *resid = static_cast<const bf16 *>(g.resid);
-        const bf16 *dact = static_cast<const bf16 *>(g.dact);
+        T *Ct = static_cast<T *>(g.C);
+        T *C2 = static_cast<T *>(g.C2);
+        const T *resid = static_cast<const T *>(g.resid);
+        const T *dact = static_cast<const T *>(g.dact);
         const bool vec_c = (g.ldc % 8 == 0) && ((reinterpret_cast<uintptr_t>(Ct) & 15) == 0) &&
                            (!C2 || (reinterpret_cast<uintptr_t>(C2) & 15) == 0) &&
                            (!resid || (g.ldr % 8 == 0 && (reinterpret_cast<uintptr_t>(resid) & 15) == 0)) &&
@@ -311,32 +312,32 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
                 *reinterpret_cast<float4 *>(v) = *reinterpret_cast<const float4 *>(Cs + lr * LDC + lc);
                 *reinterpret_cast<float4 *>(v + 4) = *reinterpret_cast<const float4 *>(Cs + lr * LDC + lc + 4);
                 if (col + 8 <= g.N && vec_c) {
-                    if (C2) store_lds<bf16, 8>(C2 + orow * g.ldc + col, v);
+                    if (C2) store_lds<T, 8>(C2 + orow * g.ldc + col, v);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = act_fwd(g.act, v[e]);
                     if (dact) {
                         float d[8];
-                        unpack(*reinterpret_cast<const uint4 *>(dact + (int64_t)row * g.ldd + col), d);
+                        unpack<T>(*reinterpret_cast<const uint4 *>(dact + (int64_t)row * g.ldd + col), d);
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] *= act_bwd(g.dact_kind, d[e]);
                     }
                     if (resid) {
                         float d[8];
-                        unpack(*reinterpret_cast<const uint4 *>(resid + (int64_t)row * g.ldr + col), d);
+                        unpack<T>(*reinterpret_cast<const uint4 *>(resid + (int64_t)row * g.ldr + col), d);
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] += d[e];
                     }
-                    store_lds<bf16, 8>(Ct + orow * g.ldc + col, v);
+                    store_lds<T, 8>(Ct + orow * g.ldc + col, v);
                 } else {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         if (col + e < g.N) {
                             float x = v[e];
-                            if (C2) C2[orow * g.ldc + col + e] = from_f32<bf16>(x);
+                            if (C2) C2[orow * g.ldc + col + e] = from_f32<T>(x);
                             x = act_fwd(g.act, x);
                             if (dact) x *= act_bwd(g.dact_kind, to_f32(dact[(int64_t)row * g.ldd + col + e]));
                             if (resid) x += to_f32(resid[(int64_t)row * g.ldr + col + e]);
-                            Ct[orow * g.ldc + col + e] = from_f32<bf16>(x);
+                            Ct[orow * g.ldc + col + e] = from_f32<T>(x);
                         }
                     }
                 }
@@ -386,7 +387,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const TS *src, int64_t ld, 
     if (c0 < N) {
         for (int r = rb + ty; r < re; r += 8) {
             float v[V];
-            if (vec_ok) unpack(*reinterpret_cast<const typename VecOf<TS>::type *>(src + (int64_t)r * ld + c0), v);
+            if (vec_ok) unpack<TS>(*reinterpret_cast<const typename VecOf<TS>::type *>(src + (int64_t)r * ld + c0), v);
             else
 #pragma unroll
                 for (int i = 0; i < V; ++i) v[i] = (c0 + i < N) ? to_f32(src[(int64_t)r * ld + c0 + i]) : 0.f;
@@ -429,6 +430,16 @@ int colsum_chunks(int M) {
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
+template <typename H>
+static int linear_fwd_h(const LinearFwdArgs &a, const GemmArgs &g, hipStream_t s) {
+    if (a.w_is_bf16) {      // weights already in the 16-bit compute type (per-step shadow copy)
+        if (a.x_is_f32) return launch_gemm_t<H, float, KC, H, KC>(g, 1, s);
+        return launch_gemm_t<H, H, KC, H, KC>(g, 1, s);
+    }
+    if (a.x_is_f32) return launch_gemm_t<H, float, KC, float, KC>(g, 1, s);
+    return launch_gemm_t<H, H, KC, float, KC>(g, 1, s);
+}
+
 int launch_linear_fwd(const LinearFwdArgs &a, hipStream_t s) {
     MIVIT_CHECK(a.M > 0 && a.N > 0 && a.K > 0, "linear_fwd: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
     GemmArgs g = {};
@@ -440,12 +451,7 @@ int launch_linear_fwd(const LinearFwdArgs &a, hipStream_t s) {
     g.C2 = a.y_preact;
     g.map_rows = a.map_rows; g.map_stride = a.map_stride; g.map_off = a.map_off;
     if (a.dtype == MIVIT_F32) return launch_gemm_t<float, float, KC, float, KC>(g, 1, s);
-    if (a.w_is_bf16) {
-        if (a.x_is_f32) return launch_gemm_t<bf16, float, KC, bf16, KC>(g, 1, s);
-        return launch_gemm_t<bf16, bf16, KC, bf16, KC>(g, 1, s);
-    }
-    if (a.x_is_f32) return launch_gemm_t<bf16, float, KC, float, KC>(g, 1, s);
-    return launch_gemm_t<bf16, bf16, KC, float, KC>(g, 1, s);
+    return a.dtype == MIVIT_BF16 ? linear_fwd_h<bf16>(a, g, s) : linear_fwd_h<f16>(a, g, s);
 }
 
 int launch_linear_dgrad(const LinearDgradArgs &a, hipStream_t s) {
@@ -457,9 +463,13 @@ int launch_linear_dgrad(const LinearDgradArgs &a, hipStream_t s) {
     g.resid = a.dres; g.ldr = a.lddr;
     g.C = a.dx; g.ldc = a.lddx; g.c_is_f32 = (a.dtype == MIVIT_F32) || a.dx_is_f32;
     if (a.dtype == MIVIT_F32) return launch_gemm_t<float, float, KC, float, KSTR>(g, 1, s);
-    MIVIT_CHECK(!a.dy_is_f32, "linear_dgrad: fp32 dy in bf16 mode is not instantiated (convert first)");
-    if (a.w_is_bf16) return launch_gemm_t<bf16, bf16, KC, bf16, KSTR>(g, 1, s);
-    return launch_gemm_t<bf16, bf16, KC, float, KSTR>(g, 1, s);
+    MIVIT_CHECK(!a.dy_is_f32, "linear_dgrad: fp32 dy in 16-bit mode is not instantiated (convert first)");
+    if (a.dtype == MIVIT_BF16) {
+        if (a.w_is_bf16) return launch_gemm_t<bf16, bf16, KC, bf16, KSTR>(g, 1, s);
+        return launch_gemm_t<bf16, bf16, KC, float, KSTR>(g, 1, s);
+    }
+    if (a.w_is_bf16) return launch_gemm_t<f16, f16, KC, f16, KSTR>(g, 1, s);
+    return launch_gemm_t<f16, f16, KC, float, KSTR>(g, 1, s);
 }
 
 size_t linear_wgrad_ws_bytes(int M, int N, int K) {
@@ -486,9 +496,11 @@ int launch_linear_wgrad(const LinearWgradArgs &a, hipStream_t s) {
         else { g.C = a.dW; g.accumulate = a.accumulate; }
         int rc;
         if (a.dtype == MIVIT_F32) rc = launch_gemm_t<float, float, KSTR, float, KSTR>(g, splits, s);
-        else if (a.dy_is_f32) { MIVIT_FAIL("linear_wgrad: fp32 dy in bf16 mode is not instantiated (convert first)"); }
-        else if (a.x_is_f32) rc = launch_gemm_t<bf16, bf16, KSTR, float, KSTR>(g, splits, s);
-        else rc = launch_gemm_t<bf16, bf16, KSTR, bf16, KSTR>(g, splits, s);
+        else if (a.dy_is_f32) { MIVIT_FAIL("linear_wgrad: fp32 dy in 16-bit mode is not instantiated (convert first)"); }
+        else if (a.dtype == MIVIT_BF16 && a.x_is_f32) rc = launch_gemm_t<bf16, bf16, KSTR, float, KSTR>(g, splits, s);
+        else if (a.dtype == MIVIT_BF16) rc = launch_gemm_t<bf16, bf16, KSTR, bf16, KSTR>(g, splits, s);
+        else if (a.x_is_f32) rc = launch_gemm_t<f16, f16, KSTR, float, KSTR>(g, splits, s);
+        else rc = launch_gemm_t<f16, f16, KSTR, f16, KSTR>(g, splits, s);
         if (rc) return rc;
         if (splits > 1) {
             rc = launch_slab_reduce(slabs, splits, (int64_t)a.N * a.K, a.dW, a.accumulate, s);
@@ -503,8 +515,11 @@ int launch_linear_wgrad(const LinearWgradArgs &a, hipStream_t s) {
         if (a.dtype == MIVIT_F32 || a.dy_is_f32)
             hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, s, static_cast<const float *>(a.dy), a.lddy,
                                a.M, a.N, chunk, bias_part);
-        else
+        else if (a.dtype == MIVIT_BF16)
             hipLaunchKernelGGL(colsum_kernel<bf16>, grid, dim3(256), 0, s, static_cast<const bf16 *>(a.dy), a.lddy,
+                               a.M, a.N, chunk, bias_part);
+        else
+            hipLaunchKernelGGL(colsum_kernel<f16>, grid, dim3(256), 0, s, static_cast<const f16 *>(a.dy), a.lddy,
                                a.M, a.N, chunk, bias_part);
         MIVIT_LAUNCH_CHECK();
         int rc = launch_slab_reduce(bias_part, chunks, a.N, a.db, a.accumulate, s);
@@ -519,7 +534,7 @@ int launch_linear_wgrad(const LinearWgradArgs &a, hipStream_t s) {
 extern "C" int mivit_linear_fwd(int dtype, const void *x, int x_is_f32, int64_t ldx, const float *W,
                                 const float *bias, int M, int N, int K, int act, const void *resid, int64_t ldr,
                                 void *y, int64_t ldy, void *y_preact, void *stream) {
-    MIVIT_CHECK(dtype == MIVIT_F32 || dtype == MIVIT_BF16, "bad dtype %d", dtype);
+    MIVIT_CHECK(dtype == MIVIT_F32 || dtype == MIVIT_BF16 || dtype == MIVIT_F16, "bad dtype %d", dtype);
     MIVIT_CHECK(x && W && y, "linear_fwd: null pointer");
     LinearFwdArgs a = {};
     a.dtype = dtype; a.x = x; a.x_is_f32 = x_is_f32 || dtype == MIVIT_F32; a.ldx = ldx; a.W = W; a.w_is_bf16 = 0; a.bias = bias;
@@ -530,7 +545,7 @@ extern "C" int mivit_linear_fwd(int dtype, const void *x, int x_is_f32, int64_t 
 extern "C" int mivit_linear_dgrad(int dtype, const void *dy, int64_t lddy, const float *W, int M, int N, int K,
                                   int act, const void *saved, int64_t lds, const void *dres, int64_t lddr,
                                   void *dx, int64_t lddx, void *stream) {
-    MIVIT_CHECK(dtype == MIVIT_F32 || dtype == MIVIT_BF16, "bad dtype %d", dtype);
+    MIVIT_CHECK(dtype == MIVIT_F32 || dtype == MIVIT_BF16 || dtype == MIVIT_F16, "bad dtype %d", dtype);
     MIVIT_CHECK(dy && W && dx, "linear_dgrad: null pointer");
     MIVIT_CHECK(act == MIVIT_ACT_NONE || saved, "linear_dgrad: activation backward needs `saved`");
     LinearDgradArgs a = {};
@@ -544,7 +559,7 @@ extern "C" size_t mivit_linear_wgrad_workspace_bytes(int M, int N, int K) { retu
 extern "C" int mivit_linear_wgrad(int dtype, const void *dy, int64_t lddy, const void *x, int x_is_f32, int64_t ldx,
                                   int M, int N, int K, float *dW, float *db, int accumulate, void *workspace,
                                   size_t workspace_bytes, void *stream) {
-    MIVIT_CHECK(dtype == MIVIT_F32 || dtype == MIVIT_BF16, "bad dtype %d", dtype);
+    MIVIT_CHECK(dtype == MIVIT_F32 || dtype == MIVIT_BF16 || dtype == MIVIT_F16, "bad dtype %d", dtype);
     MIVIT_CHECK(dy && x && workspace, "linear_wgrad: null pointer");
     LinearWgradArgs a = {};
     a.dtype = dtype; a.dy = dy; a.dy_is_f32 = dtype == MIVIT_F32; a.lddy = lddy;

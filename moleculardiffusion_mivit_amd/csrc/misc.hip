@@ -340,9 +340,12 @@ int launch_reg_token_fill(int dtype, void *tokens, int B, int S, int E, const fl
     if (dtype == MIVIT_F32)
         hipLaunchKernelGGL(reg_token_kernel<float>, dim3(blocks), dim3(256), 0, s, static_cast<float *>(tokens), B, S, E,
                            reg, static_cast<const float *>(add), pos);
-    else
+    else if (dtype == MIVIT_BF16)
         hipLaunchKernelGGL(reg_token_kernel<bf16>, dim3(blocks), dim3(256), 0, s, static_cast<bf16 *>(tokens), B, S, E,
                            reg, static_cast<const bf16 *>(add), pos);
+    else
+        hipLaunchKernelGGL(reg_token_kernel<f16>, dim3(blocks), dim3(256), 0, s, static_cast<f16 *>(tokens), B, S, E,
+                           reg, static_cast<const f16 *>(add), pos);
     MIVIT_LAUNCH_CHECK();
     return 0;
 }
@@ -352,9 +355,12 @@ int launch_mean_pool_fwd(int dtype, const void *x, int B, int S, int E, void *ou
     if (dtype == MIVIT_F32)
         hipLaunchKernelGGL(mean_pool_fwd_kernel<float>, dim3(blocks), dim3(256), 0, s, static_cast<const float *>(x), B,
                            S, E, static_cast<float *>(out));
-    else
+    else if (dtype == MIVIT_BF16)
         hipLaunchKernelGGL(mean_pool_fwd_kernel<bf16>, dim3(blocks), dim3(256), 0, s, static_cast<const bf16 *>(x), B, S,
                            E, static_cast<bf16 *>(out));
+    else
+        hipLaunchKernelGGL(mean_pool_fwd_kernel<f16>, dim3(blocks), dim3(256), 0, s, static_cast<const f16 *>(x), B, S,
+                           E, static_cast<f16 *>(out));
     MIVIT_LAUNCH_CHECK();
     return 0;
 }
@@ -364,9 +370,12 @@ int launch_mean_pool_bwd(int dtype, const void *dout, int B, int S, int E, void 
     if (dtype == MIVIT_F32)
         hipLaunchKernelGGL(mean_pool_bwd_kernel<float>, dim3(blocks), dim3(256), 0, s, static_cast<const float *>(dout),
                            B, S, E, static_cast<float *>(dx));
-    else
+    else if (dtype == MIVIT_BF16)
         hipLaunchKernelGGL(mean_pool_bwd_kernel<bf16>, dim3(blocks), dim3(256), 0, s, static_cast<const bf16 *>(dout), B,
                            S, E, static_cast<bf16 *>(dx));
+    else
+        hipLaunchKernelGGL(mean_pool_bwd_kernel<f16>, dim3(blocks), dim3(256), 0, s, static_cast<const f16 *>(dout), B,
+                           S, E, static_cast<f16 *>(dx));
     MIVIT_LAUNCH_CHECK();
     return 0;
 }
@@ -385,29 +394,41 @@ int launch_batch_colsum(int dtype, const void *x, int B, int S, int E, int s0, i
     if (dtype == MIVIT_F32)
         hipLaunchKernelGGL(batch_colsum_kernel<float>, grid, dim3(256), 0, s, static_cast<const float *>(x), B, S, E, s0,
                            rows, bchunk, part);
-    else
+    else if (dtype == MIVIT_BF16)
         hipLaunchKernelGGL(batch_colsum_kernel<bf16>, grid, dim3(256), 0, s, static_cast<const bf16 *>(x), B, S, E, s0,
+                           rows, bchunk, part);
+    else
+        hipLaunchKernelGGL(batch_colsum_kernel<f16>, grid, dim3(256), 0, s, static_cast<const f16 *>(x), B, S, E, s0,
                            rows, bchunk, part);
     MIVIT_LAUNCH_CHECK();
     return launch_slab_reduce(part, chunks, (int64_t)rows * E, out, 0, s);
 }
 
+template <typename H>
+static void convert_h(int src_is_f32, const void *src, int64_t lds_, int dst_is_f32, void *dst, int64_t ldd, int rows, int cols,
+                      int accumulate, int blocks, hipStream_t s) {
+    if (src_is_f32)
+        hipLaunchKernelGGL((convert_kernel<float, H>), dim3(blocks), dim3(256), 0, s, static_cast<const float *>(src),
+                           lds_, static_cast<H *>(dst), ldd, rows, cols, accumulate);
+    else if (dst_is_f32)
+        hipLaunchKernelGGL((convert_kernel<H, float>), dim3(blocks), dim3(256), 0, s, static_cast<const H *>(src),
+                           lds_, static_cast<float *>(dst), ldd, rows, cols, accumulate);
+    else
+        hipLaunchKernelGGL((convert_kernel<H, H>), dim3(blocks), dim3(256), 0, s, static_cast<const H *>(src),
+                           lds_, static_cast<H *>(dst), ldd, rows, cols, accumulate);
+}
+
 int launch_convert(int src_is_f32, const void *src, int64_t lds_, int dst_is_f32, void *dst, int64_t ldd, int rows,
-                   int cols, int accumulate, hipStream_t s) {
+                   int cols, int accumulate, hipStream_t s, int dtype16) {
     if (rows <= 0 || cols <= 0) return 0;
     const int blocks = (int)(((int64_t)rows * cols + 255) / 256);
     if (src_is_f32 && dst_is_f32)
         hipLaunchKernelGGL((convert_kernel<float, float>), dim3(blocks), dim3(256), 0, s, static_cast<const float *>(src),
                            lds_, static_cast<float *>(dst), ldd, rows, cols, accumulate);
-    else if (src_is_f32)
-        hipLaunchKernelGGL((convert_kernel<float, bf16>), dim3(blocks), dim3(256), 0, s, static_cast<const float *>(src),
-                           lds_, static_cast<bf16 *>(dst), ldd, rows, cols, accumulate);
-    else if (dst_is_f32)
-        hipLaunchKernelGGL((convert_kernel<bf16, float>), dim3(blocks), dim3(256), 0, s, static_cast<const bf16 *>(src),
-                           lds_, static_cast<float *>(dst), ldd, rows, cols, accumulate);
+    else if (dtype16 == MIVIT_F16)
+        convert_h<f16>(src_is_f32, src, lds_, dst_is_f32, dst, ldd, rows, cols, accumulate, blocks, s);
     else
-        hipLaunchKernelGGL((convert_kernel<bf16, bf16>), dim3(blocks), dim3(256), 0, s, static_cast<const bf16 *>(src),
-                           lds_, static_cast<bf16 *>(dst), ldd, rows, cols, accumulate);
+        convert_h<bf16>(src_is_f32, src, lds_, dst_is_f32, dst, ldd, rows, cols, accumulate, blocks, s);
     MIVIT_LAUNCH_CHECK();
     return 0;
 }

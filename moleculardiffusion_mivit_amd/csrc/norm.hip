@@ -368,7 +368,7 @@ int launch_layernorm_fwd(const LayerNormFwdArgs &a, hipStream_t s) {
     MIVIT_CHECK(a.M > 0 && a.E > 0 && a.E <= 1024, "layernorm_fwd: unsupported shape M=%d E=%d (E <= 1024)", a.M, a.E);
     LnFwd k = {a.z, a.ldz, a.gamma, a.beta, a.M, a.E, a.y, a.ldy, a.rows_per_seq, a.out_seq_stride, a.out_row_off,
                a.pos, a.mean, a.rstd, a.in_rows, a.in_stride, a.in_off};
-    return a.dtype == MIVIT_F32 ? ln_fwd_dispatch<float>(k, s) : ln_fwd_dispatch<bf16>(k, s);
+    return a.dtype == MIVIT_F32 ? ln_fwd_dispatch<float>(k, s) : a.dtype == MIVIT_BF16 ? ln_fwd_dispatch<bf16>(k, s) : ln_fwd_dispatch<f16>(k, s);
 }
 
 size_t layernorm_bwd_ws_bytes(int M, int E) { return align_up((size_t)3 * ln_blocks(M) * E * sizeof(float), 256); }
@@ -381,7 +381,8 @@ int launch_layernorm_bwd(const LayerNormBwdArgs &a, hipStream_t s) {
     LnBwd k = {a.dy, a.lddy, a.z, a.ldz, a.gamma, a.mean, a.rstd, a.M, a.E, a.rows_per_seq, a.in_seq_stride,
                a.in_row_off, a.z_rows, a.z_stride, a.z_off, a.dz, a.lddz, pg, pb, a.dzsum ? pz : nullptr};
     bool did_z = false;
-    int rc = a.dtype == MIVIT_F32 ? ln_bwd_dispatch<float>(k, blocks, &did_z, s) : ln_bwd_dispatch<bf16>(k, blocks, &did_z, s);
+    int rc = a.dtype == MIVIT_F32 ? ln_bwd_dispatch<float>(k, blocks, &did_z, s)
+           : a.dtype == MIVIT_BF16 ? ln_bwd_dispatch<bf16>(k, blocks, &did_z, s) : ln_bwd_dispatch<f16>(k, blocks, &did_z, s);
     if (rc) return rc;
     if (a.dgamma && a.dbeta) {
         const bool z = a.dzsum && did_z;
@@ -400,7 +401,7 @@ int launch_layernorm_bwd(const LayerNormBwdArgs &a, hipStream_t s) {
 extern "C" int mivit_layernorm_fwd(int dtype, const void *z, int64_t ldz, const float *gamma, const float *beta, int M,
                                    int E, void *y, int64_t ldy, int rows_per_seq, int out_seq_stride, int out_row_off,
                                    const float *pos, float *mean, float *rstd, void *stream) {
-    MIVIT_CHECK(dtype == MIVIT_F32 || dtype == MIVIT_BF16, "bad dtype %d", dtype);
+    MIVIT_CHECK(dtype == MIVIT_F32 || dtype == MIVIT_BF16 || dtype == MIVIT_F16, "bad dtype %d", dtype);
     MIVIT_CHECK(z && gamma && beta && y, "layernorm_fwd: null pointer");
     LayerNormFwdArgs a = {};
     a.dtype = dtype; a.z = z; a.ldz = ldz; a.gamma = gamma; a.beta = beta; a.M = M; a.E = E; a.y = y; a.ldy = ldy;
@@ -416,7 +417,7 @@ extern "C" int mivit_layernorm_bwd(int dtype, const void *dy, int64_t lddy, cons
                                    int rows_per_seq, int in_seq_stride, int in_row_off, void *dz, int64_t lddz,
                                    float *dgamma, float *dbeta, int accumulate, void *workspace,
                                    size_t workspace_bytes, void *stream) {
-    MIVIT_CHECK(dtype == MIVIT_F32 || dtype == MIVIT_BF16, "bad dtype %d", dtype);
+    MIVIT_CHECK(dtype == MIVIT_F32 || dtype == MIVIT_BF16 || dtype == MIVIT_F16, "bad dtype %d", dtype);
     MIVIT_CHECK(dy && z && gamma && mean && rstd && dz && workspace, "layernorm_bwd: null pointer");
     LayerNormBwdArgs a = {};
     a.dtype = dtype; a.dy = dy; a.lddy = lddy; a.z = z; a.ldz = ldz; a.gamma = gamma; a.mean = mean; a.rstd = rstd;

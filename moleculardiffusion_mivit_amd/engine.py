@@ -15,7 +15,8 @@ import torch
 
 from . import _native as N
 
-_PRECISIONS = {"fp32": N.F32, "f32": N.F32, "float32": N.F32, "bf16": N.BF16, "bfloat16": N.BF16}
+_PRECISIONS = {"fp32": N.F32, "f32": N.F32, "float32": N.F32, "bf16": N.BF16, "bfloat16": N.BF16,
+               "fp16": N.F16, "f16": N.F16, "float16": N.F16, "half": N.F16}
 
 
 def _ptr(t: Optional[torch.Tensor]):

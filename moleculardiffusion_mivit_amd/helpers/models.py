@@ -367,7 +367,10 @@ class GeneralTransformer(nn.Module):
 
     # -- plan / arena management ------------------------------------------------------------------------
     def set_precision(self, precision: str):
-        """'fp32': fp32 MFMA, the 1e-4 parity mode.  'bf16': bf16 MFMA operands / stored activations."""
+        """'fp32': fp32 MFMA, the 1e-4 parity mode.  'bf16': bf16 MFMA operands / stored activations (the fast path:
+        LDS-DMA streaming kernels).  'fp16': IEEE-half operands / stored activations on the general kernels; gradients
+        can underflow, so train it under ``torch.amp.GradScaler`` (``scaler.scale(loss).backward()``; parameters and
+        their gradients stay fp32, so ``scaler.step`` / ``unscale_`` work unchanged) -- BASELINE config 5."""
         self.precision = precision
         self.embedding.__dict__["_mivit_precision"] = precision      # picks the fused inference kernel's operand type
         self._plan = MivitPlan(precision=precision, **self._plan_kwargs)

@@ -2,7 +2,8 @@
 
 Each function mirrors one torch op of the reference path (nn.Linear(+activation), nn.LayerNorm, the attention
 core of MultiHeadAttention) and differentiates through the matching hand-written backward kernels.  Tensors must
-be on the GPU; x may be float32 (fp32 MFMA) or bfloat16 (bf16 MFMA); weights / LayerNorm parameters are fp32.
+be on the GPU; x may be float32 (fp32 MFMA), bfloat16 (bf16 MFMA, the fast path) or float16 (fp16 MFMA, general
+kernels); weights / LayerNorm parameters are fp32.
 """
 from __future__ import annotations
 
@@ -18,7 +19,9 @@ def _dt(t: torch.Tensor) -> int:
         return N.F32
     if t.dtype == torch.bfloat16:
         return N.BF16
-    raise TypeError(f"unsupported dtype {t.dtype} (float32 or bfloat16)")
+    if t.dtype == torch.float16:
+        return N.F16
+    raise TypeError(f"unsupported dtype {t.dtype} (float32, bfloat16 or float16)")
 
 
 def _gpu(*ts):

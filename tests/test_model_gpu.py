@@ -387,3 +387,58 @@ def test_hipgraph_replay_is_bitwise_identical(embedding):
             if "bn" in k or "skip.1" in k or "running" in k:
                 continue
             assert torch.equal(grads[k], outs[0][1][k]), k
+
+
+# ---- fp16 mode + dynamic loss scaling (BASELINE config 5: image sequences + feature vector, fp16 with loss scaling) ----
+@pytest.mark.parametrize("name", ["c5_early", "c5_late", "ref_linear", "c1", "meanpool_posenc_leaky"])
+def test_fp16_matches_reference_golden(name):
+    """fp16 operands / stored activations (10-bit mantissa), fp32 accumulation: outputs, loss and gradients of the golden
+    cases within 1e-2 of the reference's fp32 values (gradients 5e-2: at B = 4 one ReLU flip moves a tensor by ~3 %).
+    The backward runs under a loss scale of 2**12 (what GradScaler
+    does) and the gradients are unscaled before the comparison."""
+    fx, meta, cfg = load_golden(name)
+    params, x, labels, feats = golden_inputs(meta, cfg)
+    m = build_product_model(cfg, "fp16", params)
+    m.train(meta["training"])
+    m.zero_grad(set_to_none=True)
+    xs, ls, fs = x.cuda(), labels.cuda(), None if feats is None else feats.cuda()
+    out = m(xs, fs) if fs is not None else m(xs)
+    loss = F.mse_loss(out, ls)
+    scale = 4096.0
+    (loss * scale).backward()
+    torch.cuda.synchronize()
+    grads = {k: p.grad.detach() / scale for k, p in m.named_parameters()}
+    assert all(bool(torch.isfinite(g).all()) for g in grads.values())
+    assert rel_err(out, fx["out"]) < 1e-2
+    assert abs(float(loss) - float(fx["loss"])) / float(fx["loss"]) < 1e-2
+    e, who = _grad_err(grads, fx, meta["full_grads"])
+    assert e < 5e-2, (who, e)
+
+
+def test_fp16_training_with_grad_scaler():
+    """The reference-style loop under torch.amp.GradScaler: parameters / gradients are fp32, so scale -> backward ->
+    unscale_ -> step -> update work unchanged.  An absurd initial scale overflows fp16 gradients: the first steps must be
+    skipped (scale halves, parameters untouched), then training proceeds and the loss falls."""
+    cfg = orc.MiViTConfig(embedding="linear", patch_size=9, embed_dim=64, num_heads=4, hidden_dim=128, num_layers=2,
+                          use_global_features=True, fusion_type="early", global_feature_dim=25)
+    m = build_product_model(cfg, "fp16", orc.random_params(cfg, seed=11)).train()
+    opt = torch.optim.AdamW(m.parameters(), lr=2e-3)
+    scaler = torch.amp.GradScaler("cuda", init_scale=2.0 ** 40, growth_interval=1000)
+    x, labels, feats = orc.closed_form_batch(32, 12, 9, 25, salt=1)
+    x, labels, feats = x.cuda(), labels.cuda(), feats.cuda()
+    before = {k: p.detach().clone() for k, p in m.named_parameters()}
+    losses, scales = [], []
+    for step in range(60):
+        opt.zero_grad(set_to_none=True)
+        loss = F.mse_loss(m(x, feats), labels)
+        scaler.scale(loss).backward()
+        scaler.step(opt)
+        scaler.update()
+        losses.append(float(loss)); scales.append(scaler.get_scale())
+        if step == 0:
+            assert scales[0] < 2.0 ** 40                      # overflow detected ...
+            for k, p in m.named_parameters():
+                assert torch.equal(p.detach(), before[k]), k   # ... and the step skipped
+    assert scales[-1] < 2.0 ** 30 and scales[-1] >= 1.0
+    assert all(map(lambda v: v == v, losses))                 # no NaN ever reaches the loss
+    assert losses[-1] < 0.5 * losses[0], (losses[0], losses[-1])
