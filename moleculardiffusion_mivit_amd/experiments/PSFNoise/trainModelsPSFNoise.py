@@ -14,6 +14,7 @@ import torch
 from torch.utils.data import DataLoader
 
 from ...helpers import generation as gen
+from .._common import backward_and_step, make_scaler
 from .trainSettingsPSFNoise import *       # noqa: F401,F403  (constants + factories, as the reference does :7)
 from . import trainSettingsPSFNoise as S
 
@@ -42,6 +43,7 @@ def run_training(num_cycles=100, N=64, TrainingDs_list=([1, 1], [3, 1], [5, 1], 
     for name in validation_losses:
         validation_losses[name]["val_avg"] = []
     all_gen_labels = np.array([])
+    scalers = {name: make_scaler(model) for name, model in models.items()}
     print("StartTime: ", datetime.datetime.now())
 
     for cycle in range(num_cycles):
@@ -70,8 +72,7 @@ def run_training(num_cycles=100, N=64, TrainingDs_list=([1, 1], [3, 1], [5, 1], 
                 optimizer.zero_grad()
                 predictions = S.make_prediction(model, name, batch_images, eval=False)
                 loss = S.loss_function(predictions, batch_labels)
-                loss.backward()
-                optimizer.step()
+                backward_and_step(loss, optimizer, scalers[name])
             scheduler.step()
 
         for name, model in models.items():

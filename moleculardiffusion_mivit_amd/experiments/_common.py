@@ -54,6 +54,25 @@ def validation_trajectories(length, T, traj_div_factor, generator, n_synthetic=5
     return sets, tio
 
 
+def make_scaler(model):
+    """fp16 mode (BASELINE config 5) trains under dynamic loss scaling: init 2**16, x2 every 2000 good steps, /2 on
+    inf/NaN (skipping that step).  fp32 / bf16 models need none (returns None)."""
+    if getattr(model, "precision", None) != "fp16":
+        return None
+    return torch.amp.GradScaler("cuda", init_scale=2.0 ** 16, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000)
+
+
+def backward_and_step(loss, optimizer, scaler=None):
+    """loss.backward(); optimizer.step()  (trainModelsPSFNoise.py:192-193), through the loss scaler when there is one."""
+    if scaler is None:
+        loss.backward()
+        optimizer.step()
+    else:
+        scaler.scale(loss).backward()
+        scaler.step(optimizer)
+        scaler.update()
+
+
 def run_cycles(S, models, optimizers, schedulers, make_batch_data, predict, num_cycles, val_sets, results_name,
                batch_size=None, device=None, out_dir=".", save=True, shuffle=True, generator=None, verbose=False):
     """The reference's cycle loop.  `make_batch_data(cycle)` -> (tensors..., labels, raw_labels);
@@ -66,6 +85,7 @@ def run_cycles(S, models, optimizers, schedulers, make_batch_data, predict, num_
         batch_size = 1 if S.adaptive_batch_size != -1 else 16
     validation_losses = {name: {**{f"val_{float(D)}": [] for D in D_VALUES}, "val_avg": []} for name in models}
     all_gen_labels = np.array([])
+    scalers = {}
     print("StartTime: ", datetime.datetime.now())
     for cycle in range(num_cycles):
         if S.adaptive_batch_size != -1 and cycle != 0 and cycle % S.adaptive_batch_size == 0:
@@ -81,12 +101,13 @@ def run_cycles(S, models, optimizers, schedulers, make_batch_data, predict, num_
                 continue
             model.train()
             opt, sch = optimizers[name], schedulers[name]
+            if name not in scalers:
+                scalers[name] = make_scaler(model)
             for *bt, bl in loader:
                 bt = [t.to(device) for t in bt]
                 opt.zero_grad()
                 loss = S.loss_function(predict(model, name, *bt), bl.to(device))
-                loss.backward()
-                opt.step()
+                backward_and_step(loss, opt, scalers[name])
             sch.step()
         for name, model in models.items():
             if model is None:

@@ -64,3 +64,15 @@ def test_reduced_embeddings_run_and_rotation_tta(tmp_path):
     tta = IF.predict_with_rotations(zoo[IF.im_tr], x.cuda())
     manual = torch.stack([zoo[IF.im_tr](torch.rot90(x.cuda(), k, (2, 3)).contiguous()) for k in range(4)]).mean(0)
     assert torch.allclose(tta, manual)
+
+
+def test_reduced_psfnoise_run_fp16_with_loss_scaling(tmp_path):
+    """BASELINE config 5's numerics on the training-loop API: fp16 compute under the dynamic loss scaler the loop installs
+    for fp16 models (init 2**16, x2 / 2000 good steps, /2 on inf)."""
+    from moleculardiffusion_mivit_amd.experiments.PSFNoise import trainModelsPSFNoise as TM
+    models, vlosses, _ = TM.run_training(num_cycles=3, N=6, seed=0, out_dir=str(tmp_path), embedding="linear", save=False,
+                                         precision="fp16", psf_indices=[1], noise_indices=[0], include_resnet=False)
+    assert models["tr_1_0"].precision == "fp16"
+    assert np.isfinite(vlosses["tr_1_0"]["val_avg"]).all()
+    for p in models["tr_1_0"].parameters():
+        assert p.dtype == torch.float32 and bool(torch.isfinite(p).all())
