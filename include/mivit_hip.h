@@ -124,6 +124,10 @@ size_t mivit_deepresnet_train_workspace_bytes(int dtype, int N, int P, int E);
 int mivit_deepresnet_train_fwd(int dtype, const mivit_deepresnet_params *params, const float *x, int N, int P, int E,
                                float momentum, float eps, float *tokens, void *workspace, size_t workspace_bytes,
                                void *stream);
+/* Inference with the layer-by-layer kernels (any frame side): BatchNorm uses running_mean / running_var (required,
+ * not modified).  Workspace as for train_fwd. */
+int mivit_deepresnet_infer(int dtype, const mivit_deepresnet_params *params, const float *x, int N, int P, int E,
+                           float eps, float *tokens, void *workspace, size_t workspace_bytes, void *stream);
 int mivit_deepresnet_train_bwd(int dtype, const mivit_deepresnet_params *params, const float *x, const float *dtokens,
                                int N, int P, int E, float eps, const mivit_deepresnet_grads *grads, void *workspace,
                                size_t workspace_bytes, void *stream);

@@ -68,6 +68,8 @@ SYMBOLS = {
     "mivit_deepresnet_train_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "mivit_deepresnet_train_fwd": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p,
                                            c_void_p, c_size_t, c_void_p]),
+    "mivit_deepresnet_infer": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_size_t,
+                                       c_void_p]),
     "mivit_deepresnet_train_bwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p,
                                            c_void_p, c_size_t, c_void_p]),
     "mivit_graph_stats": (None, [c_void_p, c_void_p, c_void_p]),

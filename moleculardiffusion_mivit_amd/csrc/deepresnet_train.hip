@@ -392,6 +392,15 @@ __global__ __launch_bounds__(NT) void drn_bn_finalize_kernel(const float *part, 
     }
 }
 
+// inference: forward table from the running statistics
+__global__ void drn_bn_running_kernel(int C, const float *gamma, const float *beta, const float *rmean, const float *rvar, float eps,
+                                      float *coef) {
+    const int c = threadIdx.x;
+    if (c >= C) return;
+    const float rstd = 1.f / sqrtf(rvar[c] + eps), scale = gamma[c] * rstd;
+    coef[c] = rmean[c]; coef[CSTR + c] = rstd; coef[2 * CSTR + c] = scale; coef[3 * CSTR + c] = beta[c] - rmean[c] * scale;
+}
+
 // partial [nb][W] -> [nb2][W]  (out[b2] = sum of the parts b = b2, b2 + nb2, ...), used when a kernel left many partials
 __global__ void drn_part_reduce_kernel(const float *part, int nb, int W, float *out, int nb2) {
     const int w = blockIdx.y * blockDim.x + threadIdx.x, b2 = blockIdx.x;
@@ -725,6 +734,7 @@ struct Ctx {
     float eps, momentum;
     void *ws; DrnWs w; hipStream_t s;
     const mivit_deepresnet_params *prm;
+    bool use_running = false;      // inference: BatchNorm with the running statistics
     float *fco(int i) const { return static_cast<float *>(at(ws, w.fcoef)) + (size_t)i * 4 * CSTR; }
     float *bco(int i) const { return static_cast<float *>(at(ws, w.bcoef)) + (size_t)i * 3 * CSTR; }
     void *y(int i) const { return at(ws, w.y[i]); }
@@ -744,8 +754,14 @@ int squeeze_parts(const Ctx &c, const float *&part, int &nb, int W) {
 
 int bn_finalize(const Ctx &c, int i, const float *part, int nb) {
     const int C = DRN_CO[i];
-    RC(squeeze_parts(c, part, nb, 2 * C));
     const mivit_conv_bn &b = c.prm->conv[i];
+    if (c.use_running) {
+        hipLaunchKernelGGL(drn_bn_running_kernel, dim3(1), dim3(128), 0, c.s, C, b.gamma, b.beta, b.running_mean, b.running_var,
+                           c.eps, c.fco(i));
+        MIVIT_LAUNCH_CHECK();
+        return 0;
+    }
+    RC(squeeze_parts(c, part, nb, 2 * C));
     hipLaunchKernelGGL(drn_bn_finalize_kernel, dim3(1), dim3(NT), 0, c.s, part, nb, C, c.count(), b.gamma, b.beta, b.running_mean,
                        b.running_var, c.momentum, c.eps, c.fco(i));
     MIVIT_LAUNCH_CHECK();
@@ -1020,4 +1036,20 @@ extern "C" int mivit_deepresnet_train_bwd(int dtype, const mivit_deepresnet_para
                        (uint64_t)grads->fc_weight, (uint64_t)grads->fc_bias, (uint64_t)__builtin_bit_cast(uint32_t, eps)})
         key.push_back(v);
     return graph_run(key.data(), (int)key.size(), c.s, body);
+}
+
+extern "C" int mivit_deepresnet_infer(int dtype, const mivit_deepresnet_params *params, const float *x, int N, int P, int E,
+                                      float eps, float *tokens, void *workspace, size_t workspace_bytes, void *stream) {
+    MIVIT_CHECK(dtype == MIVIT_F32 || dtype == MIVIT_BF16, "bad dtype %d", dtype);
+    RC(check_params(params));
+    for (int i = 0; i < 7; ++i)
+        MIVIT_CHECK(params->conv[i].running_mean && params->conv[i].running_var, "deepresnet_infer: running statistics required");
+    MIVIT_CHECK(x && tokens && workspace, "deepresnet_infer: null pointer");
+    MIVIT_CHECK(N > 0 && E > 0, "deepresnet_infer: empty problem");
+    if (!drn_train_supported(dtype, P)) { mivit_set_error("deepresnet_infer: unsupported frame side %d", P); return 3; }
+    Ctx c{dtype, N, P, E, eps, 0.f, workspace, make_ws(dtype, N, P, E), static_cast<hipStream_t>(stream), params};
+    c.use_running = true;
+    MIVIT_CHECK(workspace_bytes >= c.w.total, "deepresnet_infer: workspace too small (%zu < %zu)", workspace_bytes, c.w.total);
+    prof_set_tag(MIVIT_PROF_OP);
+    return dtype == MIVIT_F32 ? forward_t<float>(c, x, tokens) : forward_t<bf16>(c, x, tokens);
 }

@@ -234,13 +234,18 @@ class DeepResNetEmbedding(nn.Module):
             self.__dict__["_fold_pack"], self.__dict__["_fold_key"] = pk, key
         return self._fold_pack
 
-    def _native_eval_ok(self, x):
+    def _native_infer_ok(self, x):
+        """eval() + no gradient wanted: one of the two native inference paths applies."""
         if self.training or x.device.type != "cuda" or x.shape[-1] != x.shape[-2]:
             return False
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
             return False
+        return os.environ.get("MIVIT_NO_DEEPRESNET_EVAL") != "1" and all(bn.track_running_stats for _, bn in self._conv_bn_pairs())
+
+    def _native_eval_ok(self, x):
+        """... and the frame is small enough for the fully fused single-kernel path."""
         dtype = torch.bfloat16 if getattr(self, "_mivit_precision", "fp32") == "bf16" else torch.float32
-        return _ops.deepresnet_eval_supported(dtype, x.shape[-1]) and os.environ.get("MIVIT_NO_DEEPRESNET_EVAL") != "1"
+        return self._native_infer_ok(x) and _ops.deepresnet_eval_supported(dtype, x.shape[-1])
 
     # -- training: batch-statistics BatchNorm, hand-written conv / BN forward + backward (csrc/deepresnet_train.hip) --
     def _conv_bn_pairs(self):
@@ -283,6 +288,12 @@ class DeepResNetEmbedding(nn.Module):
             return _ops.deepresnet_eval(x.reshape(b * n, h, w), self.folded(dtype), self.fc.out_features).view(b, n, -1)
         if self._native_train_ok(x):
             return self._forward_native_train(x.reshape(b * n, h, w)).view(b, n, -1)
+        if self._native_infer_ok(x):          # frame too large for the fused kernel: layer-by-layer kernels, running stats
+            pairs = self._conv_bn_pairs()
+            dtype = torch.bfloat16 if getattr(self, "_mivit_precision", "fp32") == "bf16" else torch.float32
+            params = [t for conv, bn in pairs for t in (conv.weight, bn.weight, bn.bias)] + [self.fc.weight, self.fc.bias]
+            running = [(bn.running_mean, bn.running_var) for _, bn in pairs]
+            return _ops.deepresnet_infer(x.reshape(b * n, h, w), dtype, pairs[0][1].eps, running, params).view(b, n, -1)
         y = x.reshape(b * n, 1, h, w)
         y = self.relu(self.bn1(self.initial_conv(y)))
         y = self.res_block2(self.res_block1(y))

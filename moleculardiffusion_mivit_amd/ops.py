@@ -239,3 +239,29 @@ def deepresnet_train(x, dtype, momentum, eps, running, params):
             raise TypeError("DeepResNet parameters must be contiguous float32 tensors")
     return _DeepResNetTrain.apply(x.contiguous().float(), N.BF16 if dtype == torch.bfloat16 else N.F32, float(momentum),
                                   float(eps), running, *params)
+
+
+@torch.no_grad()
+def deepresnet_infer(x, dtype, eps, running, params, chunk_frames: int = 8192):
+    """Inference-mode DeepResNetEmbedding on the layer-by-layer kernels (any frame side; running statistics).
+    Frames are processed in chunks so the activation workspace stays bounded."""
+    _gpu(x, *params)
+    x = x.contiguous().float()
+    n, p, _ = x.shape
+    e = params[21].shape[0]
+    code = N.BF16 if dtype == torch.bfloat16 else N.F32
+    prm = N.DeepResNetParams()
+    for i in range(7):
+        w, g, b = params[3 * i:3 * i + 3]
+        prm.conv[i] = N.ConvBn(w.data_ptr(), g.data_ptr(), b.data_ptr(), running[i][0].data_ptr(), running[i][1].data_ptr())
+    prm.fc_weight, prm.fc_bias = params[21].data_ptr(), params[22].data_ptr()
+    out = torch.empty(n, e, device=x.device, dtype=torch.float32)
+    ws = None
+    for f0 in range(0, n, chunk_frames):
+        m = min(chunk_frames, n - f0)
+        nbytes = N.lib.mivit_deepresnet_train_workspace_bytes(code, m, p, e)
+        if ws is None or ws.numel() < nbytes:
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        N.check(N.lib.mivit_deepresnet_infer(code, ctypes.addressof(prm), _p(x[f0:f0 + m]), m, p, e, float(eps), _p(out[f0:f0 + m]),
+                                             _p(ws), ws.numel(), _s(x)), "mivit_deepresnet_infer")
+    return out

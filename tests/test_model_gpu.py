@@ -261,13 +261,21 @@ def test_deepresnet_fused_inference_matches_torch_stack(precision, P, N, E):
     assert rel_err(got2, ref + 1.0) < (2e-5 if precision == "fp32" else 2e-2)
 
 
-def test_deepresnet_fused_inference_unsupported_side_uses_torch():
+@pytest.mark.parametrize("precision,P", [("fp32", 13), ("fp32", 32), ("bf16", 20)])
+def test_deepresnet_large_frame_inference_layer_kernels(precision, P):
+    """Frames too large for the fused kernel: inference runs the layer-by-layer kernels on the running statistics."""
     from moleculardiffusion_mivit_amd.helpers.models import DeepResNetEmbedding
-    emb = DeepResNetEmbedding(32, 32).cuda().eval()
-    x = torch.rand(1, 2, 32, 32, device="cuda")
+    torch.manual_seed(P)
+    emb = DeepResNetEmbedding(P, 32)
+    _randomise_bn(emb, P)
+    emb = emb.cuda().eval()
+    emb.__dict__["_mivit_precision"] = precision
+    x = torch.rand(2, 3, P, P, device="cuda")
+    ref = emb(x).detach()                                   # grad enabled -> torch path
     with torch.no_grad():
-        assert not emb._native_eval_ok(x)
-        assert emb(x).shape == (1, 2, 32)
+        assert not emb._native_eval_ok(x) and emb._native_infer_ok(x)
+        got = emb(x)
+    assert rel_err(got, ref) < (2e-4 if precision == "fp32" else 2e-2)
 
 
 # ---- training-mode DeepResNetEmbedding on the hand-written conv / BatchNorm kernels (csrc/deepresnet_train.hip) -------
