@@ -172,6 +172,116 @@ __global__ __launch_bounds__(BM / 64 * 2 * 64) void embed_fwd_dma(const EmbFwdAr
 }
 
 // =================================================================================================================
+// forward, "direct" variant: the fp32 frames never touch LDS.  Each wave owns 32 rows x 128 columns and loads its X
+// fragments straight from global memory into the MFMA operand registers, one 64-k stage ahead (8 x 16-byte loads per
+// lane in flight, no barrier on that path, 12 waves per CU -> ~100 KB of X in flight per CU).  Only the bf16 W tile
+// [128][64] goes through a 3-slot LDS ring by DMA.  The k order inside a 32-k MFMA step is permuted so that the four
+// lane groups of a row read one contiguous 64-byte run per load instruction:
+//      lane group g holds k = 4g..4g+3 and 16+4g..16+4g+3   (X: two float4 loads; W: two 8-byte LDS reads)
+// =================================================================================================================
+struct DirCfg {
+    static constexpr int BM = 128, BN = 128, BK = 64, NW = 4, NS = 3;
+    static constexpr int B_BYTES = BN * BK * 2;                  // 16 KiB per stage
+    static constexpr int B_DMA = B_BYTES / 1024 / NW;            // 4 wave-instructions per wave per stage
+    static constexpr int A_LD = 8;                               // global loads per wave per stage (2 tiles x 2 kk x 2)
+};
+
+__device__ __forceinline__ void dir_issue_b(const EmbFwdArgs &a, unsigned char *slot, int n0, int k0, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < DirCfg::B_DMA; ++i) {
+        const int inst = wave * DirCfg::B_DMA + i;
+        const int n = inst * 8 + (lane >> 3), sl = lane & 7;
+        const int c = sl ^ ((n >> 1) & 7);
+        dma16(a.W + (int64_t)(n0 + n) * a.K + k0 + c * 8, slot + inst * 1024);
+    }
+}
+
+__global__ __launch_bounds__(256) void embed_fwd_direct(const EmbFwdArgs a) {
+    using C = DirCfg;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, cq = lane & 15;
+    const int m0 = blockIdx.y * C::BM, n0 = blockIdx.x * C::BN, nst = a.K / C::BK;
+    const float *ap[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) ap[i] = a.X + (int64_t)min(m0 + wave * 32 + i * 16 + cq, a.M - 1) * a.K + 4 * g;
+
+    f32x4 acc[2][8];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    float4 nx[2][2][2];                                          // [kk][tile][half] of the NEXT stage
+    auto load_a = [&](int k0) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) nx[kk][i][h] = *reinterpret_cast<const float4 *>(ap[i] + k0 + 32 * kk + 16 * h);
+    };
+    dir_issue_b(a, smem, n0, 0, wave, lane);
+    if (nst > 1) dir_issue_b(a, smem + C::B_BYTES, n0, C::BK, wave, lane);
+    load_a(0);
+    for (int s = 0; s < nst; ++s) {
+        float4 cx[2][2][2];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) cx[kk][i][h] = nx[kk][i][h];
+        // in program order the outstanding VM ops are ... A(s), B(s+1), [A(s+1)]: wait for A(s) (and everything older)
+        if (s + 1 < nst) { load_a((s + 1) * C::BK); wait_vm<C::B_DMA + C::A_LD>(); }
+        else wait_vm<0>();
+        barrier();          // every wave's share of W stage s landed; every wave finished reading the slot of stage s-1
+        if (s + 2 < nst) dir_issue_b(a, smem + ((s + 2) % C::NS) * C::B_BYTES, n0, (s + 2) * C::BK, wave, lane);
+        const unsigned char *Bs = smem + (s % C::NS) * C::B_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 af[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = cvt8(cx[kk][i][0], cx[kk][i][1]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int n = j * 16 + cq, sw = (n >> 1) & 7;
+                const unsigned char *row = Bs + n * 128 + 8 * (g & 1);
+                const uint2 lo = *reinterpret_cast<const uint2 *>(row + ((4 * kk + (g >> 1)) ^ sw) * 16);
+                const uint2 hi = *reinterpret_cast<const uint2 *>(row + ((4 * kk + 2 + (g >> 1)) ^ sw) * 16);
+                const bf16x8 bf = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+                acc[0][j] = mma(af[0], bf, acc[0][j]);
+                acc[1][j] = mma(af[1], bf, acc[1][j]);
+            }
+        }
+    }
+    // epilogue: + bias, through LDS as fp32, one 16-row tile per wave per pass, 16-byte bf16 stores
+    constexpr int LDC = C::BN + 4;
+    float *Cs = reinterpret_cast<float *>(smem) + wave * 16 * LDC;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        barrier();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int lc = j * 16 + cq;
+            const float bv = a.bias ? a.bias[n0 + lc] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Cs[(4 * g + r) * LDC + lc] = acc[i][j][r] + bv;
+        }
+        barrier();
+        for (int c = lane; c < 16 * (C::BN / 8); c += 64) {
+            const int lr = c / (C::BN / 8), lc = (c % (C::BN / 8)) * 8;
+            const int row = m0 + wave * 32 + i * 16 + lr;
+            if (row < a.M) {
+                float v[8];
+                *reinterpret_cast<float4 *>(v) = *reinterpret_cast<const float4 *>(Cs + lr * LDC + lc);
+                *reinterpret_cast<float4 *>(v + 4) = *reinterpret_cast<const float4 *>(Cs + lr * LDC + lc + 4);
+                store16(a.Y + (int64_t)row * a.E + n0 + lc, v);
+            }
+        }
+    }
+}
+
+// =================================================================================================================
 // wgrad: tile 128 rows (e) x BKC columns (k of X), stage = 64 reduction rows m of dY (256 B rows) + of X (4*BKC B rows).
 // 2 x BKC/64 waves, each a 64 x 64 sub-tile.  NS ring slots, NS - 1 stages in flight.
 // =================================================================================================================
@@ -345,7 +455,15 @@ int launch_embed_fwd_dma(const float *X, const void *W_bf16, const float *bias, 
     EmbFwdArgs a = {X, static_cast<const bf16 *>(W_bf16), bias, static_cast<bf16 *>(Y), M, K, E};
     static const int variant = getenv("MIVIT_EMBED_FWD_VARIANT") ? atoi(getenv("MIVIT_EMBED_FWD_VARIANT")) : 0;
     if (variant == 2) return fwd_dma_launch<128, 3>(a, s);
-    return fwd_dma_launch<256, 2>(a, s);     // 256-row tiles: the L2-resident W tile is re-streamed half as often
+    if (variant == 1) return fwd_dma_launch<256, 2>(a, s);     // LDS-DMA staging of the frames (first design, kept for A/B runs)
+    {
+        const size_t bytes = (size_t)DirCfg::NS * DirCfg::B_BYTES;
+        MIVIT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(embed_fwd_direct), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        ProfScope prof(s);
+        hipLaunchKernelGGL(embed_fwd_direct, dim3(a.E / 128, ceil_div(a.M, DirCfg::BM)), dim3(256), bytes, s, a);
+        MIVIT_LAUNCH_CHECK();
+        return 0;
+    }
 }
 
 size_t embed_wgrad_dma_ws_bytes(int M, int K, int E) { return (size_t)wg_splits(M, K, E) * E * K * sizeof(float); }
