@@ -379,7 +379,7 @@ int attention_max_seq(int dtype, int Dh) {
     int best = 0;
     for (int S = 1; S <= 128; ++S) {
         const AttnDims d = dtype == MIVIT_F32 ? make_dims<float>(1, S, 1, Dh, true) : make_dims<bf16>(1, S, 1, Dh, true);
-        if ((size_t)d.per_wave * dtype_size(dtype) <= LDS_LIMIT) best = S;
+        if ((size_t)d.per_wave * dtype_size(dtype) <= LDS_LIMIT || attention_fast_supported(dtype, S, Dh)) best = S;
     }
     return best;
 }

@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void attn_fwd_fast(const bf16 *qkv, bf16 *ctx,
     constexpr int KD = (ND + 1) / 2;          // 32-wide k steps over the head dimension
     constexpr int NP = (NT + 1) / 2;          // token tile pairs (32-wide k steps over tokens)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int pair = blockIdx.x * 4 + wave;
+    const int pair = blockIdx.x * (blockDim.x >> 6) + wave;
     if (pair >= d.B * d.H) return;
     const int b = pair / d.H, h = pair % d.H;
     const int g = lane >> 4, cq = lane & 15;
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void attn_bwd_fast(const bf16 *qkv, const bf16
     constexpr int KD = (ND + 1) / 2;
     constexpr int NP = (NT + 1) / 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int pair = blockIdx.x * 4 + wave;
+    const int pair = blockIdx.x * (blockDim.x >> 6) + wave;
     if (pair >= d.B * d.H) return;
     const int b = pair / d.H, h = pair % d.H;
     const int g = lane >> 4, cq = lane & 15;
@@ -370,19 +370,33 @@ FastDims make_fast(int B, int S, int H, int Dh) {
     return d;
 }
 
+// waves per workgroup: 4, fewer when the per-wave LDS images would not fit 160 KB
+static int waves_per_block(size_t per_wave_bytes) {
+    const int w = (int)((size_t)160 * 1024 / per_wave_bytes);
+    return w < 1 ? 1 : (w > 4 ? 4 : w);
+}
+
 template <int NT, int ND>
 int fwd_launch(const bf16 *qkv, bf16 *ctx, const FastDims &d, hipStream_t s) {
-    const size_t bytes = (size_t)4 * d.img * sizeof(bf16);
+    const size_t per_wave = (size_t)d.img * sizeof(bf16);
+    const int wpb = waves_per_block(per_wave);
+    auto kern = attn_fwd_fast<NT, ND>;
+    if (per_wave * wpb > 64 * 1024)
+        MIVIT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(per_wave * wpb)));
     ProfScope prof(s);
-    hipLaunchKernelGGL((attn_fwd_fast<NT, ND>), dim3(ceil_div(d.B * d.H, 4)), dim3(256), bytes, s, qkv, ctx, d);
+    hipLaunchKernelGGL(kern, dim3(ceil_div(d.B * d.H, wpb)), dim3(64 * wpb), per_wave * wpb, s, qkv, ctx, d);
     MIVIT_LAUNCH_CHECK();
     return 0;
 }
 template <int NT, int ND>
 int bwd_launch(const bf16 *qkv, const bf16 *dctx, bf16 *dqkv, const FastDims &d, hipStream_t s) {
-    const size_t bytes = (size_t)4 * 3 * d.img * sizeof(bf16);
+    const size_t per_wave = (size_t)3 * d.img * sizeof(bf16);
+    const int wpb = waves_per_block(per_wave);
+    auto kern = attn_bwd_fast<NT, ND>;
+    if (per_wave * wpb > 64 * 1024)
+        MIVIT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(per_wave * wpb)));
     ProfScope prof(s);
-    hipLaunchKernelGGL((attn_bwd_fast<NT, ND>), dim3(ceil_div(d.B * d.H, 4)), dim3(256), bytes, s, qkv, dctx, dqkv, d);
+    hipLaunchKernelGGL(kern, dim3(ceil_div(d.B * d.H, wpb)), dim3(64 * wpb), per_wave * wpb, s, qkv, dctx, dqkv, d);
     MIVIT_LAUNCH_CHECK();
     return 0;
 }
@@ -390,7 +404,13 @@ int bwd_launch(const bf16 *qkv, const bf16 *dctx, bf16 *dqkv, const FastDims &d,
 }  // namespace
 
 bool attention_fast_supported(int dtype, int S, int Dh) {
-    return dtype == MIVIT_BF16 && S >= 1 && S <= 64 && (Dh == 16 || Dh == 32);
+    // one wavefront holds the whole (batch, head) problem in registers: the backward's register budget sets the limit
+    if (dtype != MIVIT_BF16 || S < 1) return false;
+    const int NT = (S + 15) / 16;
+    if (Dh == 16) return NT <= 8;
+    if (Dh == 32) return NT <= 7;
+    if (Dh == 64) return NT <= 5;
+    return false;
 }
 
 #define FAST_DISPATCH(FN, ...)                                                 \
@@ -403,6 +423,18 @@ bool attention_fast_supported(int dtype, int S, int Dh) {
         case 22: return FN<2, 2>(__VA_ARGS__);                                 \
         case 32: return FN<3, 2>(__VA_ARGS__);                                 \
         case 42: return FN<4, 2>(__VA_ARGS__);                                 \
+        case 14: return FN<1, 4>(__VA_ARGS__);                                 \
+        case 24: return FN<2, 4>(__VA_ARGS__);                                 \
+        case 34: return FN<3, 4>(__VA_ARGS__);                                 \
+        case 44: return FN<4, 4>(__VA_ARGS__);                                 \
+        case 51: return FN<5, 1>(__VA_ARGS__);                                 \
+        case 52: return FN<5, 2>(__VA_ARGS__);                                 \
+        case 54: return FN<5, 4>(__VA_ARGS__);                                 \
+        case 61: return FN<6, 1>(__VA_ARGS__);                                 \
+        case 62: return FN<6, 2>(__VA_ARGS__);                                 \
+        case 71: return FN<7, 1>(__VA_ARGS__);                                 \
+        case 72: return FN<7, 2>(__VA_ARGS__);                                 \
+        case 81: return FN<8, 1>(__VA_ARGS__);                                 \
         default: MIVIT_FAIL("attention fast path: unsupported tile shape");    \
     }
 
