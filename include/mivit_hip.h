@@ -88,6 +88,15 @@ int mivit_rowstream_fwd(const void *x, int64_t ldx, const void *W_bf16, const fl
 int mivit_rowstream_dgrad(const void *dy, int64_t lddy, const void *W_bf16, int M, int N, int K, int act,
                           const void *saved, int64_t lds, const void *dres, int64_t lddr, void *dx, int64_t lddx,
                           void *stream);
+/* Wide layers (K, N of 512-class models), bf16: LDS-DMA ring GEMMs with 256 x 128 workgroup tiles.
+ * fwd:   y = act(x W^T + bias) (+ resid), optional pre-activation copy;   dgrad: dx = (dy W) * act'(saved) (+ dres).
+ * N (fwd) / K (dgrad) multiple of 128, contraction length multiple of 64, M >= 256; returns 3 otherwise. */
+int mivit_gemm_dma_supported(int M, int N, int K, int dgrad);
+int mivit_gemm_dma_fwd(const void *x, int64_t ldx, const void *W_bf16, const float *bias, int M, int N, int K, int act,
+                       const void *resid, int64_t ldr, void *y, int64_t ldy, void *y_preact, void *stream);
+int mivit_gemm_dma_dgrad(const void *dy, int64_t lddy, const void *W_bf16, int M, int N, int K, int act,
+                         const void *saved, int64_t lds, const void *dres, int64_t lddr, void *dx, int64_t lddx,
+                         void *stream);
 size_t mivit_wgrad_bf16_workspace_bytes(int M, int N, int K);
 int mivit_wgrad_bf16(const void *dy, int64_t lddy, const void *x, int64_t ldx, int M, int N, int K, float *dW, float *db,
                      void *workspace, size_t workspace_bytes, void *stream);

@@ -59,6 +59,11 @@ SYMBOLS = {
                                     c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mivit_rowstream_dgrad": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int64, c_void_p,
                                       c_int64, c_void_p, c_int64, c_void_p]),
+    "mivit_gemm_dma_supported": (c_int, [c_int, c_int, c_int, c_int]),
+    "mivit_gemm_dma_fwd": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int64,
+                                   c_void_p, c_int64, c_void_p, c_void_p]),
+    "mivit_gemm_dma_dgrad": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int64, c_void_p,
+                                     c_int64, c_void_p, c_int64, c_void_p]),
     "mivit_wgrad_bf16_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "mivit_wgrad_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                  c_size_t, c_void_p]),

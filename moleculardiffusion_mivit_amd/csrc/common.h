@@ -283,6 +283,13 @@ int launch_rowstream(bool dgrad, const void *A, int64_t lda, const void *W_bf16,
                      int64_t ldr, void *Cout, int64_t ldc, void *C2, const float *gamma, const float *beta, void *Y,
                      int64_t ldy, float *mean, float *rstd, hipStream_t s);
 
+// bf16 LDS-DMA GEMMs of wide layers (gemm_dma.hip): K / N beyond the row-stream kernels' resident-weight budget
+bool gemm_dma_supported(int M, int NC, int KC, bool dgrad);
+int launch_gemm_dma_fwd(const void *x, int64_t ldx, const void *W_bf16, const float *bias, int M, int N, int K, int act,
+                        const void *resid, int64_t ldr, void *y, int64_t ldy, void *y_preact, hipStream_t s);
+int launch_gemm_dma_dgrad(const void *dy, int64_t lddy, const void *W_bf16, int M, int N, int K, int act, const void *saved,
+                          int64_t lds, const void *dres, int64_t lddr, void *dx, int64_t lddx, hipStream_t s);
+
 // bf16 LDS-DMA weight gradient of the layer projections (wgrad_dma.hip)
 bool wgrad_dma_supported(int M, int N, int K, int64_t lddy, int64_t ldx, const void *dy, const void *x);
 size_t wgrad_dma_ws_bytes(int M, int N, int K);

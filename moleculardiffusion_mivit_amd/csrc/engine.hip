@@ -137,6 +137,12 @@ int lin_fwd(int dtype, const void *x, int x_f32, int64_t ldx, const void *W, con
         return launch_rowstream(false, x, ldx, W, K, M, N, K, b, act, nullptr, 0, 0, resid, ldr, y, ldy, pre, nullptr,
                                 nullptr, nullptr, 0, nullptr, nullptr, s);
     }
+    if (dtype == MIVIT_BF16 && !x_f32 && !y_f32 && gemm_dma_supported(M, N, K, false) && ldx % 8 == 0 && ldy % 8 == 0 &&
+        (!resid || ldr % 8 == 0) && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(y) |
+                                      reinterpret_cast<uintptr_t>(resid) | reinterpret_cast<uintptr_t>(pre)) & 15) == 0) {
+        prof_set_tag(MIVIT_PROF_LINEAR_FWD);
+        return launch_gemm_dma_fwd(x, ldx, W, b, M, N, K, act, resid, ldr, y, ldy, pre, s);
+    }
     LinearFwdArgs a = {};
     a.dtype = dtype; a.x = x; a.x_is_f32 = x_f32 || dtype == MIVIT_F32; a.ldx = ldx; a.W = W;
     a.w_is_bf16 = dtype != MIVIT_F32; a.bias = b;
@@ -152,6 +158,13 @@ int lin_dgrad(int dtype, const void *dy, int64_t lddy, const void *W, int M, int
         prof_set_tag(MIVIT_PROF_LINEAR_DGRAD);
         return launch_rowstream(true, dy, lddy, W, K, M, K, N, nullptr, MIVIT_ACT_NONE, act != MIVIT_ACT_NONE ? saved : nullptr,
                                 lds, act, dres, lddr, dx, lddx, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, s);
+    }
+    if (dtype == MIVIT_BF16 && !dx_f32 && gemm_dma_supported(M, K, N, true) && lddy % 8 == 0 && lddx % 8 == 0 &&
+        (!dres || lddr % 8 == 0) && (act == MIVIT_ACT_NONE || lds % 8 == 0) &&
+        ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(dx) |
+          reinterpret_cast<uintptr_t>(dres) | reinterpret_cast<uintptr_t>(act != MIVIT_ACT_NONE ? saved : nullptr)) & 15) == 0) {
+        prof_set_tag(MIVIT_PROF_LINEAR_DGRAD);
+        return launch_gemm_dma_dgrad(dy, lddy, W, M, N, K, act, saved, lds, dres, lddr, dx, lddx, s);
     }
     LinearDgradArgs a = {};
     a.dtype = dtype; a.dy = dy; a.dy_is_f32 = dtype == MIVIT_F32; a.lddy = lddy; a.W = W;

@@ -1,0 +1,289 @@
+// bf16 GEMMs of WIDE layers (embed_dim 512-class models: K, N beyond what the resident-weight row-stream kernels
+// hold in LDS).  These shapes are MFMA/LDS-bound, not HBM-bound, so the design goal is MFMAs per LDS byte:
+//   * workgroup tile (4 * BMW) x 128, four waves stacked along M, each wave a BMW x 128 sub-tile.  BMW = 64 has the better
+//     MFMA : LDS ratio (12 fragment reads per 32 MFMAs = 96 B/clk at full MFMA rate, LDS limit 128) but needs 268
+//     registers = one wave per SIMD, and nothing then hides the LDS-read -> MFMA dependency; BMW = 32 (141 registers,
+//     three workgroups per CU) measures 1.5x faster and is the default (sweep: DESIGN.md);
+//   * both operands global -> LDS by LDS-DMA (16 B per lane) into an NS-slot ring, NS - 1 stages in flight behind counted
+//     s_waitcnt vmcnt + one raw s_barrier per stage; XOR swizzle of the 16-byte chunks on the SOURCE address;
+//   * forward:  Y = act(A W^T + b) (+ residual), optional pre-activation copy      A [M,K], W [N,K]: both k-contiguous
+//     dgrad  :  dX = (dY W) * act'(saved) (+ d residual)                           contraction over n: W tile natural
+//               [n][k] image read with ds_read_b64_tr_b16
+//   * epilogue through per-wave LDS scratch (fp32), 16-byte loads of residual / saved activation, 16-byte bf16 stores.
+// Template parameters (BMW, BK, NS) are the "MFMA tile + LDS sizing" knobs of BASELINE config 4; the sweep is in
+// scripts/sweep_gemm_dma.py and DESIGN.md.
+#include "common.h"
+#include <stdlib.h>
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((address_space(1))) const void gptr_t;
+typedef __attribute__((address_space(3))) void lptr_t;
+
+__device__ __forceinline__ void dma16(const void *g, void *l) {
+    __builtin_amdgcn_global_load_lds((gptr_t *)g, (lptr_t *)l, 16, 0, 0);
+}
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+__device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ f32x4 mma(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+struct GdArgs {
+    const bf16 *A; int64_t lda;        // [M, Kc]  (forward: x, Kc = K;  dgrad: dy, Kc = N_out)
+    const bf16 *W; int64_t ldw;        // [N_out, K_in] bf16 shadow weights
+    const float *bias;                 // forward only
+    int M, NC, KC;                     // output columns, contraction length
+    int act;                           // forward: activation; dgrad: activation whose derivative multiplies (uses `aux`)
+    const bf16 *aux; int64_t ldaux;    // forward: residual;  dgrad: saved activation (post-activation value)
+    const bf16 *aux2; int64_t ldaux2;  // dgrad: gradient arriving through the residual branch
+    bf16 *C; int64_t ldc;
+    bf16 *C2;                          // forward: optional pre-activation copy (same ld as C)
+};
+
+template <int BMW, int BK, int NS>
+struct Cfg {
+    static constexpr int NW = 4, BM = NW * BMW, BN = 128;
+    static constexpr int CH = BK / 8;                        // 16-byte chunks per k-contiguous row
+    static constexpr int RPI = 1024 / (BK * 2);              // rows per 1 KiB wave-instruction
+    static constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
+    static constexpr int STAGE = A_BYTES + B_BYTES;
+    static constexpr int A_DMA = A_BYTES / 1024 / NW, B_DMA = B_BYTES / 1024 / NW;
+    static constexpr int PER_STAGE = A_DMA + B_DMA;
+    static_assert(BK == 32 || BK == 64, "stage depth");
+    static_assert(A_DMA * NW * 1024 == A_BYTES && B_DMA * NW * 1024 == B_BYTES, "stage must split evenly over the waves");
+    static_assert(PER_STAGE * (NS - 1) < 64, "vmcnt is a 6-bit counter");
+};
+
+// k-contiguous image [rows][BK]: chunk c of row r lands in slot c ^ swz(r)
+template <int BK>
+__device__ __forceinline__ int swz(int r) { return BK == 32 ? ((r >> 2) & 3) : ((r >> 1) & 7); }
+
+template <int BMW, int BK, int NS, bool DGRAD>
+__device__ __forceinline__ void issue_stage(const GdArgs &a, unsigned char *slot, int m0, int n0, int k0, int wave, int lane) {
+    using C = Cfg<BMW, BK, NS>;
+#pragma unroll
+    for (int i = 0; i < C::A_DMA; ++i) {
+        const int inst = wave * C::A_DMA + i;
+        const int r = inst * C::RPI + lane / C::CH, s = lane % C::CH;
+        const int c = s ^ swz<BK>(r);
+        dma16(a.A + (int64_t)min(m0 + r, a.M - 1) * a.lda + k0 + c * 8, slot + inst * 1024);
+    }
+    unsigned char *bs = slot + C::A_BYTES;
+    if (!DGRAD) {       // W rows n0.. (output columns), k-contiguous: same image shape as A
+#pragma unroll
+        for (int i = 0; i < C::B_DMA; ++i) {
+            const int inst = wave * C::B_DMA + i;
+            const int n = inst * C::RPI + lane / C::CH, s = lane % C::CH;
+            const int c = s ^ swz<BK>(n);
+            dma16(a.W + (int64_t)(n0 + n) * a.ldw + k0 + c * 8, bs + inst * 1024);
+        }
+    } else {            // natural [BK rows n][128 cols k_in] image, 256-byte rows; chunk c of row r lands in slot c ^ (2 * (r & 7))
+#pragma unroll
+        for (int i = 0; i < C::B_DMA; ++i) {
+            const int inst = wave * C::B_DMA + i;
+            const int r = inst * 4 + (lane >> 4), s = lane & 15;
+            const int c = s ^ (2 * (r & 7));
+            dma16(a.W + (int64_t)(k0 + r) * a.ldw + n0 + c * 8, bs + inst * 1024);
+        }
+    }
+}
+
+// B fragment of the dgrad: k = rows (mr + q | mr + 4 + q supplied per lane), lane index = column colbase + (lane & 15)
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char *img, int mr, int colbase, int q, int p) {
+    const int col = colbase + 4 * p;
+    typedef __attribute__((address_space(3))) s16x4 lds_v4;
+    const int r0 = mr + q, r1 = mr + 4 + q;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4 *)(img + r0 * 256 + (((col >> 3) ^ (2 * (r0 & 7))) * 16) + (col & 7) * 2));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4 *)(img + r1 * 256 + (((col >> 3) ^ (2 * (r1 & 7))) * 16) + (col & 7) * 2));
+    struct { s16x4 a, b; } pr = {lo, hi};
+    return __builtin_bit_cast(bf16x8, pr);
+}
+
+template <int BMW, int BK, int NS, bool DGRAD>
+__global__ __launch_bounds__(256) void gemm_dma_kernel(const GdArgs a) {
+    using C = Cfg<BMW, BK, NS>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int TM = BMW / 16, TN = 8, D = NS - 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, cq = lane & 15, q = cq >> 2, p = cq & 3;
+    // consecutive workgroups walk down M for one 128-column block (they share the W tile through L2)
+    const int m0 = blockIdx.x * C::BM, n0 = blockIdx.y * C::BN;
+    const int nst = a.KC / BK;
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int s = 0; s < D; ++s)
+        if (s < nst) issue_stage<BMW, BK, NS, DGRAD>(a, smem + s * C::STAGE, m0, n0, s * BK, wave, lane);
+    for (int s = 0; s < nst; ++s) {
+        if (s + D - 1 < nst) wait_vm<C::PER_STAGE * (D - 1)>();
+        else wait_vm<0>();
+        barrier();
+        if (s + D < nst) issue_stage<BMW, BK, NS, DGRAD>(a, smem + ((s + D) % NS) * C::STAGE, m0, n0, (s + D) * BK, wave, lane);
+        const unsigned char *As = smem + (s % NS) * C::STAGE, *Bs = As + C::A_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < BK / 32; ++kk) {
+            bf16x8 af[TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int r = wave * BMW + i * 16 + cq;
+                af[i] = *reinterpret_cast<const bf16x8 *>(As + r * (BK * 2) + (((kk * 4 + g) ^ swz<BK>(r)) * 16));
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                bf16x8 bf;
+                if (!DGRAD) {
+                    const int n = j * 16 + cq;
+                    bf = *reinterpret_cast<const bf16x8 *>(Bs + n * (BK * 2) + (((kk * 4 + g) ^ swz<BK>(n)) * 16));
+                } else {
+                    bf = tr_frag(Bs, kk * 32 + 8 * g, j * 16, q, p);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i) acc[i][j] = mma(af[i], bf, acc[i][j]);
+            }
+        }
+    }
+    // ---- epilogue: 16 rows x 128 columns per pass through this wave's fp32 scratch ----
+    barrier();                                     // every wave is done with the operand ring
+    constexpr int LDC = C::BN + 4;
+    float *Cs = reinterpret_cast<float *>(smem) + wave * 16 * LDC;
+    const bool has_bias = !DGRAD && a.bias != nullptr;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        wave_lds_fence();
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int lc = j * 16 + cq;
+            const float bv = has_bias ? a.bias[n0 + lc] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Cs[(4 * g + r) * LDC + lc] = acc[i][j][r] + bv;
+        }
+        wave_lds_fence();
+        for (int c = lane; c < 16 * (C::BN / 8); c += 64) {
+            const int lr = c / (C::BN / 8), lc = (c % (C::BN / 8)) * 8;
+            const int row = m0 + wave * BMW + i * 16 + lr;
+            if (row >= a.M) continue;
+            float v[8];
+            *reinterpret_cast<float4 *>(v) = *reinterpret_cast<const float4 *>(Cs + lr * LDC + lc);
+            *reinterpret_cast<float4 *>(v + 4) = *reinterpret_cast<const float4 *>(Cs + lr * LDC + lc + 4);
+            const int64_t col = n0 + lc;
+            if (!DGRAD) {
+                if (a.C2) store16(a.C2 + (int64_t)row * a.ldc + col, v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = act_fwd(a.act, v[e]);
+                if (a.aux) {
+                    float d[8];
+                    load16(a.aux + (int64_t)row * a.ldaux + col, d);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += d[e];
+                }
+            } else {
+                if (a.aux) {
+                    float d[8];
+                    load16(a.aux + (int64_t)row * a.ldaux + col, d);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] *= act_bwd(a.act, d[e]);
+                }
+                if (a.aux2) {
+                    float d[8];
+                    load16(a.aux2 + (int64_t)row * a.ldaux2 + col, d);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += d[e];
+                }
+            }
+            store16(a.C + (int64_t)row * a.ldc + col, v);
+        }
+    }
+}
+
+template <int BMW, int BK, int NS, bool DGRAD>
+int launch_t(const GdArgs &a, hipStream_t s) {
+    using C = Cfg<BMW, BK, NS>;
+    const size_t ring = (size_t)NS * C::STAGE, scratch = (size_t)4 * 16 * (C::BN + 4) * 4;
+    const size_t bytes = ring > scratch ? ring : scratch;
+    auto kern = gemm_dma_kernel<BMW, BK, NS, DGRAD>;
+    MIVIT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    ProfScope prof(s);
+    hipLaunchKernelGGL(kern, dim3(ceil_div(a.M, C::BM), a.NC / C::BN), dim3(256), bytes, s, a);
+    MIVIT_LAUNCH_CHECK();
+    return 0;
+}
+
+// tile variants, selectable for the sizing sweep: MIVIT_GEMM_DMA_VARIANT = 0 (default) .. 4
+template <bool DGRAD>
+int launch_variant(const GdArgs &a, hipStream_t s) {
+    static const int variant = getenv("MIVIT_GEMM_DMA_VARIANT") ? atoi(getenv("MIVIT_GEMM_DMA_VARIANT")) : 0;
+    switch (variant) {
+        case 1: return launch_t<64, 32, 3, DGRAD>(a, s);     // 256 x 128 tile, 72 KB ring: 1 wave / SIMD (268 registers)
+        case 2: return launch_t<64, 32, 4, DGRAD>(a, s);
+        case 3: return launch_t<64, 64, 2, DGRAD>(a, s);
+        case 4: return launch_t<32, 64, 3, DGRAD>(a, s);     // 128 x 128 tile, 96 KB ring: 1 workgroup / CU
+        default: return launch_t<32, 32, 3, DGRAD>(a, s);    // 128 x 128 tile, 48 KB ring: 3 workgroups / CU (measured best)
+    }
+}
+
+bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+// wide-layer shapes only: the row-stream kernels own K in {128, 256, 384}
+bool gemm_dma_supported(int M, int NC, int KC, bool dgrad) {
+    static const bool off = getenv("MIVIT_NO_GEMM_DMA") != nullptr;
+    if (off || M < 256 || NC % 128 != 0 || KC % 64 != 0 || KC < 128) return false;
+    return true;
+}
+
+int launch_gemm_dma_fwd(const void *x, int64_t ldx, const void *W_bf16, const float *bias, int M, int N, int K, int act,
+                        const void *resid, int64_t ldr, void *y, int64_t ldy, void *y_preact, hipStream_t s) {
+    MIVIT_CHECK(aligned16(x) && aligned16(W_bf16) && aligned16(y) && aligned16(resid) && aligned16(y_preact) && ldx % 8 == 0 &&
+                ldy % 8 == 0 && (!resid || ldr % 8 == 0), "gemm_dma_fwd: operands must be 16-byte aligned");
+    GdArgs a = {};
+    a.A = static_cast<const bf16 *>(x); a.lda = ldx; a.W = static_cast<const bf16 *>(W_bf16); a.ldw = K; a.bias = bias;
+    a.M = M; a.NC = N; a.KC = K; a.act = act; a.aux = static_cast<const bf16 *>(resid); a.ldaux = ldr;
+    a.C = static_cast<bf16 *>(y); a.ldc = ldy; a.C2 = static_cast<bf16 *>(y_preact);
+    return launch_variant<false>(a, s);
+}
+
+// dx [M,K] = (dy [M,N] . W [N,K]) * act'(saved) + dres
+int launch_gemm_dma_dgrad(const void *dy, int64_t lddy, const void *W_bf16, int M, int N, int K, int act, const void *saved,
+                          int64_t lds, const void *dres, int64_t lddr, void *dx, int64_t lddx, hipStream_t s) {
+    MIVIT_CHECK(aligned16(dy) && aligned16(W_bf16) && aligned16(dx) && aligned16(saved) && aligned16(dres) && lddy % 8 == 0 &&
+                lddx % 8 == 0 && (!saved || lds % 8 == 0) && (!dres || lddr % 8 == 0), "gemm_dma_dgrad: operands must be 16-byte aligned");
+    GdArgs a = {};
+    a.A = static_cast<const bf16 *>(dy); a.lda = lddy; a.W = static_cast<const bf16 *>(W_bf16); a.ldw = K;
+    a.M = M; a.NC = K; a.KC = N; a.act = act; a.aux = act != MIVIT_ACT_NONE ? static_cast<const bf16 *>(saved) : nullptr; a.ldaux = lds;
+    a.aux2 = static_cast<const bf16 *>(dres); a.ldaux2 = lddr;
+    a.C = static_cast<bf16 *>(dx); a.ldc = lddx;
+    return launch_variant<true>(a, s);
+}
+
+extern "C" int mivit_gemm_dma_supported(int M, int N, int K, int dgrad) {
+    return dgrad ? gemm_dma_supported(M, K, N, true) : gemm_dma_supported(M, N, K, false);
+}
+extern "C" int mivit_gemm_dma_fwd(const void *x, int64_t ldx, const void *W_bf16, const float *bias, int M, int N, int K, int act,
+                                  const void *resid, int64_t ldr, void *y, int64_t ldy, void *y_preact, void *stream) {
+    MIVIT_CHECK(x && W_bf16 && y, "gemm_dma_fwd: null pointer");
+    if (!gemm_dma_supported(M, N, K, false)) { mivit_set_error("gemm_dma_fwd: unsupported shape M=%d N=%d K=%d", M, N, K); return 3; }
+    prof_set_tag(MIVIT_PROF_OP);
+    return launch_gemm_dma_fwd(x, ldx, W_bf16, bias, M, N, K, act, resid, ldr, y, ldy, y_preact, static_cast<hipStream_t>(stream));
+}
+extern "C" int mivit_gemm_dma_dgrad(const void *dy, int64_t lddy, const void *W_bf16, int M, int N, int K, int act,
+                                    const void *saved, int64_t lds, const void *dres, int64_t lddr, void *dx, int64_t lddx,
+                                    void *stream) {
+    MIVIT_CHECK(dy && W_bf16 && dx, "gemm_dma_dgrad: null pointer");
+    if (!gemm_dma_supported(M, K, N, true)) { mivit_set_error("gemm_dma_dgrad: unsupported shape M=%d N=%d K=%d", M, N, K); return 3; }
+    prof_set_tag(MIVIT_PROF_OP);
+    return launch_gemm_dma_dgrad(dy, lddy, W_bf16, M, N, K, act, saved, lds, dres, lddr, dx, lddx, static_cast<hipStream_t>(stream));
+}

@@ -257,3 +257,52 @@ def test_wgrad_dma_exact(M, N, K):
     N_.check(N_.lib.mivit_wgrad_bf16(p(dyg), N, p(xg), K, M, N, K, p(dW), p(db), p(ws), ws.numel(), st), "wgrad_bf16")
     assert torch.equal(dW.cpu(), (dy.double().t() @ x.double()).float())
     assert torch.equal(db.cpu(), dy.double().sum(0).float())
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 128, 128), (1000, 512, 512), (4130, 1536, 512), (777, 512, 1024), (300, 1024, 576)])
+@pytest.mark.parametrize("variant", ["plain", "relu_preact", "resid"])
+def test_gemm_dma_forward_exact(M, N, K, variant):
+    """Wide-layer LDS-DMA GEMM (csrc/gemm_dma.hip), forward, on small integers: exact up to the final bf16 rounding."""
+    import ctypes
+    from moleculardiffusion_mivit_amd import _native as N_
+    assert N_.lib.mivit_gemm_dma_supported(M, N, K, 0)
+    x, W, b = _ints((M, K), -2, 2, 1), _ints((N, K), -2, 2, 2), _ints((N,), -3, 3, 3)
+    r = _ints((M, N), -4, 4, 4)
+    p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())   # noqa: E731
+    xg, Wg, bg, rg = x.bfloat16().cuda(), W.bfloat16().cuda(), b.cuda(), r.bfloat16().cuda()
+    y = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    pre = torch.empty_like(y) if variant == "relu_preact" else None
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    N_.check(N_.lib.mivit_gemm_dma_fwd(p(xg), K, p(Wg), p(bg), M, N, K, 1 if variant == "relu_preact" else 0,
+                                       p(rg) if variant == "resid" else None, N, p(y), N, p(pre), st), "gemm_dma_fwd")
+    u = x.double() @ W.double().t() + b.double()
+    ref = torch.relu(u) if variant == "relu_preact" else u
+    if variant == "resid":
+        ref = ref + r.double()
+    assert torch.equal(y.float().cpu(), ref.float().bfloat16().float())
+    if pre is not None:
+        assert torch.equal(pre.float().cpu(), u.float().bfloat16().float())
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 128, 128), (1000, 512, 512), (4130, 1536, 512), (777, 1024, 512), (300, 576, 1024)])
+@pytest.mark.parametrize("variant", ["plain", "dact_relu", "dres"])
+def test_gemm_dma_dgrad_exact(M, N, K, variant):
+    """dx[M,K] = dy[M,N] @ W[N,K] (* relu'(saved)) (+ dres): W tile consumed through transposed LDS reads."""
+    import ctypes
+    from moleculardiffusion_mivit_amd import _native as N_
+    assert N_.lib.mivit_gemm_dma_supported(M, N, K, 1)
+    dy, W = _ints((M, N), -2, 2, 7), _ints((N, K), -2, 2, 8)
+    saved, dres = _ints((M, K), -1, 2, 9), _ints((M, K), -4, 4, 10)
+    p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())   # noqa: E731
+    dyg, Wg, sg, rg = dy.bfloat16().cuda(), W.bfloat16().cuda(), saved.bfloat16().cuda(), dres.bfloat16().cuda()
+    dx = torch.empty(M, K, dtype=torch.bfloat16, device="cuda")
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    N_.check(N_.lib.mivit_gemm_dma_dgrad(p(dyg), N, p(Wg), M, N, K, 1 if variant == "dact_relu" else 0,
+                                         p(sg) if variant == "dact_relu" else None, K,
+                                         p(rg) if variant == "dres" else None, K, p(dx), K, st), "gemm_dma_dgrad")
+    ref = dy.double() @ W.double()
+    if variant == "dact_relu":
+        ref = ref * (saved > 0).double()
+    if variant == "dres":
+        ref = ref + dres.double()
+    assert torch.equal(dx.float().cpu(), ref.float().bfloat16().float())
