@@ -88,6 +88,16 @@ int mivit_rowstream_fwd(const void *x, int64_t ldx, const void *W_bf16, const fl
 int mivit_rowstream_dgrad(const void *dy, int64_t lddy, const void *W_bf16, int M, int N, int K, int act,
                           const void *saved, int64_t lds, const void *dres, int64_t lddr, void *dx, int64_t lddx,
                           void *stream);
+/* Same contracts as mivit_rowstream_fwd / _dgrad, "wave-stream" data movement (weight slice copied to LDS once, every
+ * wave streams its own 16-row tiles straight from global memory into MFMA operands, wave-private epilogue, no barriers);
+ * contraction length 128 or 256.  The engine picks per launch whichever of the two measured faster. */
+int mivit_wavestream_fwd(const void *x, int64_t ldx, const void *W_bf16, const float *bias, int M, int N, int K, int act,
+                         const void *resid, int64_t ldr, void *y, int64_t ldy, void *y_preact, const float *ln_gamma,
+                         const float *ln_beta, void *ln_out, float *mean, float *rstd, void *stream);
+int mivit_wavestream_dgrad(const void *dy, int64_t lddy, const void *W_bf16, int M, int N, int K, int act,
+                           const void *saved, int64_t lds, const void *dres, int64_t lddr, void *dx, int64_t lddx,
+                           void *stream);
+
 /* Wide layers (K, N of 512-class models), bf16: LDS-DMA ring GEMMs with 256 x 128 workgroup tiles.
  * fwd:   y = act(x W^T + bias) (+ resid), optional pre-activation copy;   dgrad: dx = (dy W) * act'(saved) (+ dres).
  * N (fwd) / K (dgrad) multiple of 128, contraction length multiple of 64, M >= 256; returns 3 otherwise. */

@@ -283,6 +283,13 @@ int launch_rowstream(bool dgrad, const void *A, int64_t lda, const void *W_bf16,
                      int64_t ldr, void *Cout, int64_t ldc, void *C2, const float *gamma, const float *beta, void *Y,
                      int64_t ldy, float *mean, float *rstd, hipStream_t s);
 
+// bf16 wave-stream GEMM (wavestream.hip): same contract as launch_rowstream, K in {128, 256}
+bool wavestream_supported(int M, int N, int K, bool dgrad, int64_t lda, int64_t ldw, const void *A, const void *W);
+int launch_wavestream(bool dgrad, const void *A, int64_t lda, const void *W_bf16, int64_t ldw, int M, int N, int K,
+                      const float *bias, int act, const void *dact, int64_t ldd, int dact_kind, const void *resid,
+                      int64_t ldr, void *Cout, int64_t ldc, void *C2, const float *gamma, const float *beta, void *Y,
+                      int64_t ldy, float *mean, float *rstd, hipStream_t s);
+
 // bf16 LDS-DMA GEMMs of wide layers (gemm_dma.hip): K / N beyond the row-stream kernels' resident-weight budget
 bool gemm_dma_supported(int M, int NC, int KC, bool dgrad);
 int launch_gemm_dma_fwd(const void *x, int64_t ldx, const void *W_bf16, const float *bias, int M, int N, int K, int act,

@@ -1,0 +1,259 @@
+// bf16 "wave-stream" GEMMs of the encoder-layer projections (K = 128 / 256 contraction, 128-column slices):
+//      forward : C = act(A W^T + b) (+ residual) (+ fused post-norm LayerNorm when the slice is the whole row)
+//      dgrad   : C = (A W) * act'(saved)  |  + residual gradient
+// Same arithmetic and interface as the row-stream kernels (rowstream.hip), different data movement: these launches are
+// HBM-bound on the activation rows, so the goal is bytes in flight with nothing to stall on.
+//   * the 128-column weight slice is copied into LDS ONCE per workgroup (the only __syncthreads of the kernel);
+//   * every wave then walks its own 16-row tiles: the A fragments go straight from global memory into the MFMA operand
+//     registers (16 bytes per lane, one contiguous 64-byte run per row and instruction), prefetched 8 loads deep;
+//   * the epilogue is wave-private (fp32 scratch of 16 x 128 per wave, row statistics of the LayerNorm by 2 shuffles),
+//     so waves never wait for each other: no ring, no barrier, no DMA bookkeeping on the streaming path;
+//   * dgrad reads the natural [n][k] weight image with ds_read_b64_tr_b16.
+#include "common.h"
+#include <stdlib.h>
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+__device__ __forceinline__ f32x4 mma(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+struct WsArgs {
+    const bf16 *A; int64_t lda;
+    const bf16 *W; int64_t ldw;
+    int M, N, K;
+    const float *bias; int act;
+    const bf16 *dact; int64_t ldd; int dact_kind;
+    const bf16 *resid; int64_t ldr;
+    bf16 *C; int64_t ldc;          // forward: the pre-LayerNorm sum z when `gamma` is set
+    bf16 *C2;                      // optional pre-activation copy (same ld as C)
+    const float *gamma, *beta;     // fused LayerNorm (N == 128 only)
+    bf16 *Y; int64_t ldy; float *mean, *rstd;
+};
+
+constexpr int BN = 128, LDC = BN + 4;
+
+template <int K, bool DGRAD>
+struct WsCfg {
+    static constexpr int NWV = K == 128 ? 12 : 8;                       // waves per workgroup (one workgroup per CU)
+    static constexpr int PF = K == 128 ? 2 : 1;                         // tiles of A fragments in flight per wave
+    static constexpr int KS = K / 32;
+    static constexpr int W_LD = DGRAD ? BN + 16 : K + 8;                // elements per LDS row of the weight image
+    static constexpr int W_ROWS = DGRAD ? K : BN;
+    static constexpr int W_BYTES = W_ROWS * W_LD * 2;
+    static constexpr int SCRATCH = 16 * LDC * 4;
+    static constexpr int LDS = W_BYTES + NWV * SCRATCH;
+    static_assert(LDS <= 160 * 1024, "LDS budget");
+};
+
+__device__ __forceinline__ bf16x8 tr_pair(const bf16 *lo, const bf16 *hi) {
+    typedef __attribute__((address_space(3))) s16x4 lds_v4;
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4 *)(lo));
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4 *)(hi));
+    struct { s16x4 a, b; } pr = {a, b};
+    return __builtin_bit_cast(bf16x8, pr);
+}
+
+// E_KIND: 0 none, 1 residual add (forward), 2 activation-derivative multiply (dgrad), 3 residual add of a gradient
+template <int K, bool DGRAD, bool LN, int E_KIND>
+__global__ __launch_bounds__((K == 128 ? 12 : 8) * 64) void wavestream_kernel(const WsArgs a) {
+    using C = WsCfg<K, DGRAD>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int KS = C::KS, PF = C::PF, NT = C::NWV * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, cq = lane & 15, q = cq >> 2, p = cq & 3;
+    const int n0 = blockIdx.x * BN;
+    bf16 *Wimg = reinterpret_cast<bf16 *>(smem);
+    float *Cs = reinterpret_cast<float *>(smem + C::W_BYTES) + wave * 16 * LDC;
+
+    // ---- weight slice -> LDS, once ----
+    if (!DGRAD) {       // rows n0 .. n0+127 of W [N, K]: k-contiguous
+        for (int i = tid; i < BN * (K / 8); i += NT) {
+            const int n = i / (K / 8), c = i - n * (K / 8);
+            *reinterpret_cast<uint4 *>(Wimg + n * C::W_LD + c * 8) = *reinterpret_cast<const uint4 *>(a.W + (int64_t)(n0 + n) * a.ldw + c * 8);
+        }
+    } else {            // rows 0 .. K-1 (contraction index), columns n0 .. n0+127 of W [K, N_total]
+        for (int i = tid; i < K * (BN / 8); i += NT) {
+            const int r = i / (BN / 8), c = i - r * (BN / 8);
+            *reinterpret_cast<uint4 *>(Wimg + r * C::W_LD + c * 8) = *reinterpret_cast<const uint4 *>(a.W + (int64_t)r * a.ldw + n0 + c * 8);
+        }
+    }
+    __syncthreads();
+
+    const int ntiles = (a.M + 15) / 16, stride = gridDim.y * C::NWV;
+    int tile = blockIdx.y * C::NWV + wave;
+    const bf16 *E = E_KIND == 2 ? a.dact : a.resid;
+    const int64_t lde = E_KIND == 2 ? a.ldd : a.ldr;
+
+    bf16x8 nx[PF][KS];
+    auto load_tile = [&](int t, bf16x8 (&dst)[KS]) {
+        const bf16 *ap = a.A + (int64_t)min(t * 16 + cq, a.M - 1) * a.lda + 8 * g;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) dst[ks] = *reinterpret_cast<const bf16x8 *>(ap + ks * 32);
+    };
+#pragma unroll
+    for (int i = 0; i < PF; ++i) load_tile(min(tile + i * stride, ntiles - 1), nx[i]);
+
+    for (; tile < ntiles; tile += stride) {
+        bf16x8 cur[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) cur[ks] = nx[0][ks];
+#pragma unroll
+        for (int i = 0; i + 1 < PF; ++i)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) nx[i][ks] = nx[i + 1][ks];
+        load_tile(min(tile + PF * stride, ntiles - 1), nx[PF - 1]);
+
+        f32x4 acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                bf16x8 bf;
+                if (!DGRAD) bf = *reinterpret_cast<const bf16x8 *>(Wimg + (j * 16 + cq) * C::W_LD + ks * 32 + 8 * g);
+                else bf = tr_pair(Wimg + (ks * 32 + 8 * g + q) * C::W_LD + j * 16 + 4 * p,
+                                  Wimg + (ks * 32 + 8 * g + 4 + q) * C::W_LD + j * 16 + 4 * p);
+                acc[j] = mma(cur[ks], bf, acc[j]);
+            }
+        }
+        // ---- wave-private epilogue: accumulators (+ bias) -> fp32 scratch -> rows of 128, four lanes per row ----
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int lc = j * 16 + cq;
+            const float bv = a.bias ? a.bias[n0 + lc] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Cs[(4 * g + r) * LDC + lc] = acc[j][r] + bv;
+        }
+        wave_lds_fence();
+        const int lr = lane >> 2, row = tile * 16 + lr;
+        const bool live = row < a.M;
+        float v[4][8];
+        float s1 = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int lc = c * 32 + (lane & 3) * 8, col = n0 + lc;
+            *reinterpret_cast<float4 *>(v[c]) = *reinterpret_cast<const float4 *>(Cs + lr * LDC + lc);
+            *reinterpret_cast<float4 *>(v[c] + 4) = *reinterpret_cast<const float4 *>(Cs + lr * LDC + lc + 4);
+            if (live && a.C2) store16(a.C2 + (int64_t)row * a.ldc + col, v[c]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[c][e] = act_fwd(a.act, v[c][e]);
+            if (E_KIND != 0) {
+                float d[8];
+                load16(E + (int64_t)(live ? row : 0) * lde + col, d);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[c][e] = E_KIND == 2 ? v[c][e] * act_bwd(a.dact_kind, d[e]) : v[c][e] + d[e];
+            }
+            if (live) store16(a.C + (int64_t)row * a.ldc + col, v[c]);
+            if (LN) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {       // LayerNorm acts on the values as STORED (bf16-rounded z)
+                    v[c][e] = live ? to_f32(from_f32<bf16>(v[c][e])) : 0.f;
+                    s1 += v[c][e];
+                }
+            }
+        }
+        if (LN) {
+            s1 += __shfl_xor(s1, 1, 64); s1 += __shfl_xor(s1, 2, 64);
+            const float mu = s1 * (1.f / BN);
+            float s2 = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float dlt = v[c][e] - mu; s2 += dlt * dlt; }
+            s2 += __shfl_xor(s2, 1, 64); s2 += __shfl_xor(s2, 2, 64);
+            const float rs = rsqrtf(s2 * (1.f / BN) + 1e-5f);
+            if (live) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int lc = c * 32 + (lane & 3) * 8;
+                    float o8[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o8[e] = (v[c][e] - mu) * rs * a.gamma[lc + e] + a.beta[lc + e];
+                    store16(a.Y + (int64_t)row * a.ldy + lc, o8);
+                }
+                if ((lane & 3) == 0) { a.mean[row] = mu; a.rstd[row] = rs; }
+            }
+        }
+    }
+}
+
+template <int K, bool DGRAD, bool LN, int E_KIND>
+int ws_launch(const WsArgs &a, hipStream_t s) {
+    using C = WsCfg<K, DGRAD>;
+    auto kern = wavestream_kernel<K, DGRAD, LN, E_KIND>;
+    MIVIT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
+    const int ntn = a.N / BN, ntiles = ceil_div(a.M, 16);
+    int gy = 256 / ntn;                                       // one resident workgroup per CU, no tail round
+    if (gy < 1) gy = 1;
+    if (gy > ceil_div(ntiles, C::NWV)) gy = ceil_div(ntiles, C::NWV);
+    ProfScope prof(s);
+    hipLaunchKernelGGL(kern, dim3(ntn, gy), dim3(C::NWV * 64), C::LDS, s, a);
+    MIVIT_LAUNCH_CHECK();
+    return 0;
+}
+
+bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+bool wavestream_supported(int M, int N, int K, bool dgrad, int64_t lda, int64_t ldw, const void *A, const void *W) {
+    static const bool off = getenv("MIVIT_NO_WAVESTREAM") != nullptr;
+    if (off) return false;
+    if (!(K == 128 || K == 256) || N % 128 != 0 || M < 256) return false;
+    if (lda % 8 || ldw % 8 || !aligned16(A) || !aligned16(W)) return false;
+    return true;
+}
+
+// same contract as launch_rowstream (rowstream.hip)
+int launch_wavestream(bool dgrad, const void *A, int64_t lda, const void *W_bf16, int64_t ldw, int M, int N, int K,
+                      const float *bias, int act, const void *dact, int64_t ldd, int dact_kind, const void *resid,
+                      int64_t ldr, void *Cout, int64_t ldc, void *C2, const float *gamma, const float *beta, void *Y,
+                      int64_t ldy, float *mean, float *rstd, hipStream_t s) {
+    WsArgs a = {static_cast<const bf16 *>(A), lda, static_cast<const bf16 *>(W_bf16), ldw, M, N, K, bias, act,
+                static_cast<const bf16 *>(dact), ldd, dact_kind, static_cast<const bf16 *>(resid), ldr,
+                static_cast<bf16 *>(Cout), ldc, static_cast<bf16 *>(C2), gamma, beta, static_cast<bf16 *>(Y), ldy, mean, rstd};
+    const bool ln = gamma != nullptr;
+    MIVIT_CHECK(!ln || (N == 128 && !dgrad && resid), "wavestream: fused LayerNorm needs N == 128, forward, with a residual");
+    MIVIT_CHECK(!(dact && resid), "wavestream: at most one epilogue operand");
+    MIVIT_CHECK(ldc % 8 == 0 && (!ln || ldy % 8 == 0) && aligned16(Cout) && (!C2 || aligned16(C2)) && (!Y || aligned16(Y)),
+                "wavestream: outputs must be 16-byte aligned with ld % 8 == 0");
+    MIVIT_CHECK((!resid || (ldr % 8 == 0 && aligned16(resid))) && (!dact || (ldd % 8 == 0 && aligned16(dact))),
+                "wavestream: epilogue operand must be 16-byte aligned with ld % 8 == 0");
+#define WS_GO(KK, DG, LNF, EK) return ws_launch<KK, DG, LNF, EK>(a, s)
+    if (K == 128) {
+        if (dgrad) { if (dact) WS_GO(128, true, false, 2); if (resid) WS_GO(128, true, false, 3); WS_GO(128, true, false, 0); }
+        if (ln) WS_GO(128, false, true, 1);
+        if (resid) WS_GO(128, false, false, 1);
+        WS_GO(128, false, false, 0);
+    }
+    if (dgrad) { if (dact) WS_GO(256, true, false, 2); if (resid) WS_GO(256, true, false, 3); WS_GO(256, true, false, 0); }
+    if (ln) WS_GO(256, false, true, 1);
+    if (resid) WS_GO(256, false, false, 1);
+    WS_GO(256, false, false, 0);
+#undef WS_GO
+}
+
+extern "C" int mivit_wavestream_fwd(const void *x, int64_t ldx, const void *W_bf16, const float *bias, int M, int N, int K,
+                                    int act, const void *resid, int64_t ldr, void *y, int64_t ldy, void *y_preact,
+                                    const float *ln_gamma, const float *ln_beta, void *ln_out, float *mean, float *rstd,
+                                    void *stream) {
+    MIVIT_CHECK(x && W_bf16 && y, "wavestream_fwd: null pointer");
+    if (!wavestream_supported(M, N, K, false, ldx, K, x, W_bf16)) { mivit_set_error("wavestream_fwd: unsupported shape"); return 3; }
+    prof_set_tag(MIVIT_PROF_OP);
+    return launch_wavestream(false, x, ldx, W_bf16, K, M, N, K, bias, act, nullptr, 0, 0, resid, ldr, y, ldy, y_preact, ln_gamma,
+                             ln_beta, ln_out, N, mean, rstd, static_cast<hipStream_t>(stream));
+}
+extern "C" int mivit_wavestream_dgrad(const void *dy, int64_t lddy, const void *W_bf16, int M, int N, int K, int act,
+                                      const void *saved, int64_t lds, const void *dres, int64_t lddr, void *dx, int64_t lddx,
+                                      void *stream) {
+    MIVIT_CHECK(dy && W_bf16 && dx, "wavestream_dgrad: null pointer");
+    if (!wavestream_supported(M, K, N, true, lddy, K, dy, W_bf16)) { mivit_set_error("wavestream_dgrad: unsupported shape"); return 3; }
+    prof_set_tag(MIVIT_PROF_OP);
+    return launch_wavestream(true, dy, lddy, W_bf16, K, M, K, N, nullptr, MIVIT_ACT_NONE, act != MIVIT_ACT_NONE ? saved : nullptr,
+                             lds, act, dres, lddr, dx, lddx, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr,
+                             static_cast<hipStream_t>(stream));
+}

@@ -182,10 +182,13 @@ def _ints(shape, lo, hi, seed):
 
 @pytest.mark.parametrize("M,N,K", [(264, 128, 128), (1000, 384, 128), (4130, 256, 128), (777, 128, 256)])
 @pytest.mark.parametrize("variant", ["plain", "relu_preact", "resid", "resid_ln"])
-def test_rowstream_forward_exact(M, N, K, variant):
-    """Row-stream GEMM (csrc/rowstream.hip), forward, on small integers: exact up to the final bf16 rounding."""
+@pytest.mark.parametrize("family", ["rowstream", "wavestream"])
+def test_rowstream_forward_exact(M, N, K, variant, family):
+    """Row-stream / wave-stream GEMMs (csrc/rowstream.hip, wavestream.hip), forward, on small integers: exact up to the
+    final bf16 rounding."""
     import ctypes
     from moleculardiffusion_mivit_amd import _native as N_
+    entry = getattr(N_.lib, f"mivit_{family}_fwd")
     if variant == "resid_ln" and N != 128:
         pytest.skip("fused LayerNorm needs N == 128")
     x, W, b = _ints((M, K), -2, 2, 1), _ints((N, K), -2, 2, 2), _ints((N,), -3, 3, 3)
@@ -202,9 +205,8 @@ def test_rowstream_forward_exact(M, N, K, variant):
     mean = torch.empty(M, device="cuda") if ln else None
     rstd = torch.empty(M, device="cuda") if ln else None
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    N_.check(N_.lib.mivit_rowstream_fwd(p(xg), K, p(Wg), p(bg), M, N, K, 1 if variant == "relu_preact" else 0,
-                                        p(rg) if has_r else None, N, p(y), N, p(pre), p(gam), p(bet), p(lno), p(mean), p(rstd),
-                                        st), "rowstream_fwd")
+    N_.check(entry(p(xg), K, p(Wg), p(bg), M, N, K, 1 if variant == "relu_preact" else 0,
+                   p(rg) if has_r else None, N, p(y), N, p(pre), p(gam), p(bet), p(lno), p(mean), p(rstd), st), family + "_fwd")
     u = x.double() @ W.double().t() + b.double()
     ref = torch.relu(u) if variant == "relu_preact" else u
     if has_r:
@@ -222,19 +224,22 @@ def test_rowstream_forward_exact(M, N, K, variant):
 
 @pytest.mark.parametrize("M,N,K", [(264, 128, 128), (1000, 128, 256), (4130, 256, 128), (900, 384, 128)])
 @pytest.mark.parametrize("variant", ["plain", "dact_relu", "dres"])
-def test_rowstream_dgrad_exact(M, N, K, variant):
+@pytest.mark.parametrize("family", ["rowstream", "wavestream"])
+def test_rowstream_dgrad_exact(M, N, K, variant, family):
     """dx[M,K] = dy[M,N] @ W[N,K] (* relu'(saved)) (+ dres): W consumed through transposed LDS reads."""
     import ctypes
     from moleculardiffusion_mivit_amd import _native as N_
+    if family == "wavestream" and N == 384:
+        pytest.skip("contraction 384 stays on the row-stream kernel")
+    entry = getattr(N_.lib, f"mivit_{family}_dgrad")
     dy, W = _ints((M, N), -2, 2, 7), _ints((N, K), -2, 2, 8)
     saved, dres = _ints((M, K), -1, 2, 9), _ints((M, K), -4, 4, 10)
     p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())   # noqa: E731
     dyg, Wg, sg, rg = dy.bfloat16().cuda(), W.bfloat16().cuda(), saved.bfloat16().cuda(), dres.bfloat16().cuda()
     dx = torch.empty(M, K, dtype=torch.bfloat16, device="cuda")
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    N_.check(N_.lib.mivit_rowstream_dgrad(p(dyg), N, p(Wg), M, N, K, 1 if variant == "dact_relu" else 0,
-                                          p(sg) if variant == "dact_relu" else None, K,
-                                          p(rg) if variant == "dres" else None, K, p(dx), K, st), "rowstream_dgrad")
+    N_.check(entry(p(dyg), N, p(Wg), M, N, K, 1 if variant == "dact_relu" else 0, p(sg) if variant == "dact_relu" else None, K,
+                   p(rg) if variant == "dres" else None, K, p(dx), K, st), family + "_dgrad")
     ref = dy.double() @ W.double()
     if variant == "dact_relu":
         ref = ref * (saved > 0).double()
