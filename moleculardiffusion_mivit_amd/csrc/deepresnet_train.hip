@@ -120,13 +120,13 @@ __device__ __forceinline__ void fill_halo(T *tile, const TileSrc &s, const Geom 
     }
 }
 
-// plain row-ordered image [nrows][C] (dead rows zero)
-template <typename T, int C, int PRO>
-__device__ __forceinline__ void fill_rows(T *tile, const TileSrc &s, const int *rowg, int nrows, int tid) {
-    constexpr int V = vec_el<T>(), CV = C / V, CS = C + pad_el<T>();
+// plain row-ordered image [nrows][CB] of the channel window c_off .. c_off + CB of a CTOT-channel tensor (dead rows zero)
+template <typename T, int CB, int CTOT, int PRO>
+__device__ __forceinline__ void fill_rows(T *tile, const TileSrc &s, const int *rowg, int nrows, int c_off, int tid) {
+    constexpr int V = vec_el<T>(), CV = CB / V, CS = CB + pad_el<T>();
     for (int i = tid; i < nrows * CV; i += NT) {
         const int r = i / CV, c = (i - r * CV) * V;
-        transform_store<T, C, PRO>(tile + r * CS + c, s, rowg[r], c);
+        transform_store<T, CTOT, PRO>(tile + r * CS + c, s, rowg[r], c_off + c);
     }
 }
 
@@ -530,22 +530,30 @@ __device__ __forceinline__ bf16x8 tr_pair(const bf16 *lo, const bf16 *hi) {
     return __builtin_bit_cast(bf16x8, pr);
 }
 
-template <typename T, int CIN, int COUT, int TAPS, int PROA>
+// grid (G, CSPLIT): a workgroup walks frame groups blockIdx.x, +G, ... holding ALL taps of its c_out window
+// (COUT / CSPLIT channels) x all c_in in accumulators, so every activation is read once per c_out window.
+template <typename T, int CIN, int COUT, int TAPS, int PROA, int CSPLIT>
 __global__ __launch_bounds__(NT) void drn_wgrad_kernel(const WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int TPP = TAPS == 9 ? 3 : 1, WM = COUT / 64, WN = CIN / 32;
-    constexpr int CSA = CIN + pad_el<T>(), CSD = COUT + pad_el<T>();
+    // 8 waves = WGM (c_out) x WGN (c_in).  The dy fragments do not depend on the tap, so tall wave tiles (more c_out tiles
+    // per wave) need fewer LDS reads per MFMA
+    constexpr int COB = COUT / CSPLIT;
+    constexpr int WGM = CIN >= 64 ? 2 : 4, WGN = 8 / WGM;
+    constexpr int WM = COB / 16 / WGM, WN = CIN / 16 / WGN;
+    static_assert(WM >= 1 && WN >= 1 && TAPS * WM * WN <= 36, "wave tile / accumulator budget");
+    constexpr int CSA = CIN + pad_el<T>(), CSD = COB + pad_el<T>();
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, cq = lane & 15, q = cq >> 2, p = cq & 3;
-    const int wm = wave & 3, wn = wave >> 2;
+    const int wm = wave % WGM, wn = wave / WGM;
+    const int co_off = blockIdx.y * COB;
     const Geom &gm = a.g;
     const int W2 = gm.tw + 2, RP = (gm.RT + 31) / 32 * 32;
     T *tileA = reinterpret_cast<T *>(smem);                     // [F*HPt][CSA]  zero-haloed input activation
-    T *tileD = tileA + gm.F * gm.HPt * CSA;                     // [RP][CSD]     dy, plain row order, dead rows zero
+    T *tileD = tileA + gm.F * gm.HPt * CSA;                     // [RP][CSD]     dy window, plain row order, dead rows zero
     int *rowg = reinterpret_cast<int *>(tileD + RP * CSD), *hmap = rowg + RP, *cellsrc = hmap + RP;   // [RP], [RP], [F*HPt]
-    f32x4 acc[TPP][WM][WN];
+    f32x4 acc[TAPS][WM][WN];
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int t = 0; t < TPP; ++t)
+    for (int t = 0; t < TAPS; ++t)
 #pragma unroll
         for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -556,7 +564,7 @@ __global__ __launch_bounds__(NT) void drn_wgrad_kernel(const WgradArgs a) {
         build_cell_table(gm, grp, cellsrc, tid);
         __syncthreads();
         fill_halo<T, CIN, PROA>(tileA, a.A, gm, cellsrc, tid);
-        fill_rows<T, COUT, PRO_DY>(tileD, a.D, rowg, RP, tid);
+        fill_rows<T, COB, COUT, PRO_DY>(tileD, a.D, rowg, RP, co_off, tid);
         __syncthreads();
         const int ksteps = RP / 32;
 #pragma unroll 1
@@ -572,9 +580,8 @@ __global__ __launch_bounds__(NT) void drn_wgrad_kernel(const WgradArgs a) {
                 }
                 const int hl = hmap[rlo], hh = hmap[rhi];
 #pragma unroll
-                for (int t = 0; t < TPP; ++t) {
-                    const int tap = blockIdx.y * TPP + t;
-                    const int off = TAPS == 9 ? ((tap / 3 - 1) * W2 + (tap % 3 - 1)) : 0;
+                for (int t = 0; t < TAPS; ++t) {
+                    const int off = TAPS == 9 ? ((t / 3 - 1) * W2 + (t % 3 - 1)) : 0;
 #pragma unroll
                     for (int j = 0; j < WN; ++j) {
                         const int ci0 = (wn * WN + j) * 16 + 4 * p;
@@ -593,9 +600,8 @@ __global__ __launch_bounds__(NT) void drn_wgrad_kernel(const WgradArgs a) {
                     for (int i = 0; i < WM; ++i) af[i] = reinterpret_cast<const float *>(tileD)[r * CSD + (wm * WM + i) * 16 + cq];
                     const int h = hmap[r];
 #pragma unroll
-                    for (int t = 0; t < TPP; ++t) {
-                        const int tap = blockIdx.y * TPP + t;
-                        const int off = TAPS == 9 ? ((tap / 3 - 1) * W2 + (tap % 3 - 1)) : 0;
+                    for (int t = 0; t < TAPS; ++t) {
+                        const int off = TAPS == 9 ? ((t / 3 - 1) * W2 + (t % 3 - 1)) : 0;
 #pragma unroll
                         for (int j = 0; j < WN; ++j) {
                             const float bfr = reinterpret_cast<const float *>(tileA)[(h + off) * CSA + (wn * WN + j) * 16 + cq];
@@ -609,16 +615,15 @@ __global__ __launch_bounds__(NT) void drn_wgrad_kernel(const WgradArgs a) {
     }
     float *slab = a.slab + (size_t)blockIdx.x * COUT * TAPS * CIN;
 #pragma unroll
-    for (int t = 0; t < TPP; ++t) {
-        const int tap = blockIdx.y * TPP + t;
+    for (int t = 0; t < TAPS; ++t) {
 #pragma unroll
         for (int i = 0; i < WM; ++i)
 #pragma unroll
             for (int j = 0; j < WN; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int co = (wm * WM + i) * 16 + 4 * g + r, ci = (wn * WN + j) * 16 + cq;
-                    slab[((size_t)co * TAPS + tap) * CIN + ci] = acc[t][i][j][r];
+                    const int co = co_off + (wm * WM + i) * 16 + 4 * g + r, ci = (wn * WN + j) * 16 + cq;
+                    slab[((size_t)co * TAPS + t) * CIN + ci] = acc[t][i][j][r];
                 }
     }
 }
@@ -682,7 +687,7 @@ size_t conv_lds(int dtype, int t, int F, int CIN, int CIN2) {
     return image_bytes(dtype, t, F, CIN) + (CIN2 ? image_bytes(dtype, t, F, CIN2) : 0) + 8 * 2 * 32 * 4 + 2 * ROWS_PAD * 4 +
            (size_t)F * (t + 2) * (t + 2) * 4;
 }
-size_t wgrad_lds(int dtype, int t, int F, int CIN, int COUT) {
+size_t wgrad_lds(int dtype, int t, int F, int CIN, int COUT /* c_out window held in LDS */) {
     const int RP = (F * t * t + 31) / 32 * 32;
     return image_bytes(dtype, t, F, CIN) + (size_t)RP * (COUT * dtype_size(dtype) + PADB) + (size_t)RP * 8 +
            (size_t)F * (t + 2) * (t + 2) * 4;
@@ -694,7 +699,7 @@ bool drn_train_supported(int dtype, int P) {
     int t, nt;
     choose_tile(dtype, P, &t, &nt);
     return slots_fit(t, [&](int F) { return conv_lds(dtype, t, F, 128, 128); }) >= 1 &&
-           slots_fit(t, [&](int F) { return wgrad_lds(dtype, t, F, 128, 128); }) >= 1;
+           slots_fit(t, [&](int F) { return wgrad_lds(dtype, t, F, 128, 64); }) >= 1;
 }
 
 DrnWs make_ws(int dtype, int N, int P, int E) {
@@ -714,7 +719,7 @@ DrnWs make_ws(int dtype, int N, int P, int E) {
     w.part = take((size_t)w.parts_cap * 3 * 128 * 4 * 2);
     w.part2 = take((size_t)PART_MAX * 3 * 128 * 4);
     for (int i = 0; i < 3; ++i) w.X[i] = take(R * 128 * es);
-    w.slab = take((size_t)85 * 128 * 9 * 128 * 4);      // >= 256 * 128 * 128 * 4 of the 1x1 convolutions
+    w.slab = take((size_t)WG_GROUPS / 2 * 128 * 9 * 128 * 4);   // 128 parts of the 128x128x9 gradient = 256 of a 64x128x9 one
     w.lin = take(linear_wgrad_ws_bytes(N, E, 128));
     w.total = off;
     return w;
@@ -874,18 +879,20 @@ int bn_bwd_finalize(const Ctx &c, int i, int which, int nb, const mivit_deepresn
 
 template <typename T, int CIN, int COUT, int TAPS, int PROA>
 int run_wgrad(const Ctx &c, const TileSrc &A, const TileSrc &D, float *dW) {
+    // all taps in one pass; the 128 x 128 convolution splits c_out in two windows to fit the accumulators
+    constexpr int CSPLIT = (TAPS * (COUT / 16) * (CIN / 16) / 8 > 36) ? 2 : 1;
     WgradArgs a{};
     int t, nt;
     choose_tile(c.dtype, c.P, &t, &nt);
-    const int F = slots_fit(t, [&](int f) { return wgrad_lds(c.dtype, t, f, CIN, COUT); });
+    const int F = slots_fit(t, [&](int f) { return wgrad_lds(c.dtype, t, f, CIN, COUT / CSPLIT); });
     a.g = make_geom(c.dtype, c.N, c.P, F);
     a.ngroups = ceil_div(a.g.units, F);
     a.A = A; a.D = D; a.slab = static_cast<float *>(at(c.ws, c.w.slab));
-    const int G = std::min(a.ngroups, TAPS == 9 ? 85 : WG_GROUPS);
-    const size_t lds = wgrad_lds(c.dtype, t, F, CIN, COUT);
-    auto kern = drn_wgrad_kernel<T, CIN, COUT, TAPS, PROA>;
+    const int G = std::min(a.ngroups, WG_GROUPS / CSPLIT);        // one resident workgroup per CU
+    const size_t lds = wgrad_lds(c.dtype, t, F, CIN, COUT / CSPLIT);
+    auto kern = drn_wgrad_kernel<T, CIN, COUT, TAPS, PROA, CSPLIT>;
     RC(set_lds(kern, lds));
-    hipLaunchKernelGGL(kern, dim3(G, TAPS == 9 ? 3 : 1), dim3(NT), lds, c.s, a);
+    hipLaunchKernelGGL(kern, dim3(G, CSPLIT), dim3(NT), lds, c.s, a);
     MIVIT_LAUNCH_CHECK();
     const int n = COUT * TAPS * CIN;
     hipLaunchKernelGGL(drn_wgrad_reduce_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, c.s, a.slab, G, COUT, TAPS, CIN, dW);
