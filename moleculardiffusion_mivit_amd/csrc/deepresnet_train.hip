@@ -20,7 +20,7 @@
 
 namespace {
 
-constexpr int NT = 512, MAXM = 11;          // 8 waves; <= 176 output pixels (11 MFMA row tiles) per workgroup
+constexpr int NT = 512, MAXM = 22;          // 8 waves; <= 352 output pixels (22 MFMA row tiles) per workgroup
 constexpr int PADB = 16;                    // bytes of padding per pixel row in LDS (bank spread)
 constexpr int CSTR = 128;                   // stride of the per-channel coefficient tables
 template <typename T> constexpr int pad_el() { return PADB / (int)sizeof(T); }
