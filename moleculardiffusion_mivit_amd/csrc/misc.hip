@@ -205,21 +205,21 @@ struct Reduce3 {
     const float *part[3];
     float *out[3];
 };
-__global__ __launch_bounds__(256) void slab_reduce3_kernel(const Reduce3 r, int nparts, int n, int accumulate) {
-    __shared__ float red[8][33];
+__global__ __launch_bounds__(1024) void slab_reduce3_kernel(const Reduce3 r, int nparts, int n, int accumulate) {
+    __shared__ float red[32][33];
     const float *part = r.part[blockIdx.y];
     float *out = r.out[blockIdx.y];
-    const int ex = threadIdx.x & 31, pl = threadIdx.x >> 5;
+    const int ex = threadIdx.x & 31, pl = threadIdx.x >> 5;       // 32 columns x 32 part lanes (fixed summation order)
     const int e = blockIdx.x * 32 + ex;
     float acc = 0.f;
     if (e < n)
-        for (int p = pl; p < nparts; p += 8) acc += part[(int64_t)p * n + e];
+        for (int p = pl; p < nparts; p += 32) acc += part[(int64_t)p * n + e];
     red[pl][ex] = acc;
     __syncthreads();
     if (pl == 0 && e < n) {
         float t = red[0][ex];
 #pragma unroll
-        for (int y = 1; y < 8; ++y) t += red[y][ex];
+        for (int y = 1; y < 32; ++y) t += red[y][ex];
         out[e] = accumulate ? out[e] + t : t;
     }
 }
@@ -321,7 +321,7 @@ int launch_slab_reduce3(const float *p0, float *o0, const float *p1, float *o1, 
                         int n, int accumulate, hipStream_t s) {
     Reduce3 r = {{p0, p1, p2}, {o0, o1, o2}};
     const int cnt = o2 ? 3 : (o1 ? 2 : 1);
-    hipLaunchKernelGGL(slab_reduce3_kernel, dim3((n + 31) / 32, cnt), dim3(256), 0, s, r, nparts, n, accumulate);
+    hipLaunchKernelGGL(slab_reduce3_kernel, dim3((n + 31) / 32, cnt), dim3(1024), 0, s, r, nparts, n, accumulate);
     MIVIT_LAUNCH_CHECK();
     return 0;
 }

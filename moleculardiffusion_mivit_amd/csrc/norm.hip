@@ -311,7 +311,7 @@ VecPlan vec_plan(int E, int64_t ld_a, int64_t ld_b, const void *p0, const void *
 
 int ln_blocks(int M) {
     int b = ceil_div(M, 16);
-    return b < 1 ? 1 : (b > 512 ? 512 : b);   // = per-block dgamma/dbeta partials to reduce afterwards
+    return b < 1 ? 1 : (b > 2048 ? 2048 : b);   // = per-block dgamma/dbeta partials to reduce afterwards (8 workgroups per CU)
 }
 
 template <typename T>
