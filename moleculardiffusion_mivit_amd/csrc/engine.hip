@@ -129,9 +129,14 @@ inline void *col_ptr(void *p, size_t cols, int dtype) { return static_cast<char 
 
 #define RC(call) do { int rc_ = (call); if (rc_) return rc_; } while (0)
 
+// row-stream (DMA ring) or wave-stream kernels: launch_rowstream picks between the two families
+static bool stream_gemm_supported(int M, int N, int K, bool dgrad, int64_t lda, int64_t ldw, const void *A, const void *W) {
+    return rowstream_supported(M, N, K, dgrad, lda, ldw, A, W) || wavestream_supported(M, N, K, dgrad, lda, ldw, A, W);
+}
+
 int lin_fwd(int dtype, const void *x, int x_f32, int64_t ldx, const void *W, const float *b, int M, int N, int K,
             int act, const void *resid, int64_t ldr, void *y, int64_t ldy, void *pre, int y_f32, hipStream_t s) {
-    if (dtype == MIVIT_BF16 && !x_f32 && !y_f32 && rowstream_supported(M, N, K, false, ldx, K, x, W) &&
+    if (dtype == MIVIT_BF16 && !x_f32 && !y_f32 && stream_gemm_supported(M, N, K, false, ldx, K, x, W) &&
         (!resid || ldr % 8 == 0) && ldy % 8 == 0) {
         prof_set_tag(MIVIT_PROF_LINEAR_FWD);
         return launch_rowstream(false, x, ldx, W, K, M, N, K, b, act, nullptr, 0, 0, resid, ldr, y, ldy, pre, nullptr,
@@ -153,7 +158,7 @@ int lin_fwd(int dtype, const void *x, int x_f32, int64_t ldx, const void *W, con
 }
 int lin_dgrad(int dtype, const void *dy, int64_t lddy, const void *W, int M, int N, int K, int act, const void *saved,
               int64_t lds, const void *dres, int64_t lddr, void *dx, int64_t lddx, int dx_f32, hipStream_t s) {
-    if (dtype == MIVIT_BF16 && !dx_f32 && rowstream_supported(M, K, N, true, lddy, K, dy, W) && lddx % 8 == 0 &&
+    if (dtype == MIVIT_BF16 && !dx_f32 && stream_gemm_supported(M, K, N, true, lddy, K, dy, W) && lddx % 8 == 0 &&
         (!dres || lddr % 8 == 0) && (act == MIVIT_ACT_NONE || lds % 8 == 0)) {
         prof_set_tag(MIVIT_PROF_LINEAR_DGRAD);
         return launch_rowstream(true, dy, lddy, W, K, M, K, N, nullptr, MIVIT_ACT_NONE, act != MIVIT_ACT_NONE ? saved : nullptr,
@@ -192,7 +197,7 @@ int lin_wgrad(int dtype, const void *dy, int64_t lddy, const void *x, int x_f32,
 // block owns whole rows, otherwise GEMM + LayerNorm kernel.
 int lin_res_ln(int dtype, const void *x, int64_t ldx, const void *W, const float *b, int M, int N, int K, const void *resid,
                void *z, const float *gamma, const float *beta, void *y, float *mean, float *rstd, hipStream_t s) {
-    if (dtype == MIVIT_BF16 && N == 128 && rowstream_supported(M, N, K, false, ldx, K, x, W)) {
+    if (dtype == MIVIT_BF16 && (N == 128 || N == 64) && stream_gemm_supported(M, N, K, false, ldx, K, x, W)) {
         prof_set_tag(MIVIT_PROF_LINEAR_FWD);
         return launch_rowstream(false, x, ldx, W, K, M, N, K, b, MIVIT_ACT_NONE, nullptr, 0, 0, resid, N, z, N, nullptr, gamma,
                                 beta, y, N, mean, rstd, s);

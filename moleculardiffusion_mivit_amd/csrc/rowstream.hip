@@ -308,11 +308,13 @@ int launch_rowstream(bool dgrad, const void *A, int64_t lda, const void *W_bf16,
     // it measured faster at the headline shape (out-proj + LayerNorm 81 -> 74 us, FC2 dgrad with act' 124 -> 93 us,
     // K = 256 dgrad 71 -> 68 us; the plain forward slices and FC2 + LayerNorm stay on the DMA ring: 61 vs 70, 88 vs 94 us)
     static const int use_ws = getenv("MIVIT_WAVESTREAM") ? atoi(getenv("MIVIT_WAVESTREAM")) : 2;
-    const bool ws_pick = use_ws == 1 || (use_ws == 2 && ((K == 128 && !dgrad && gamma) || (K == 128 && dgrad && dact) ||
-                                                         (K == 256 && dgrad)));
+    const bool rs_shape = (K == 128 || K == 256 || (K == 384 && dgrad)) && N % 128 == 0;     // what the DMA-ring kernels cover
+    const bool ws_pick = !rs_shape || use_ws == 1 || (use_ws == 2 && ((K == 128 && !dgrad && gamma) || (K == 128 && dgrad && dact) ||
+                                                                      (K == 256 && dgrad)));
     if (ws_pick && wavestream_supported(M, N, K, dgrad, lda, ldw, A, W_bf16))
         return launch_wavestream(dgrad, A, lda, W_bf16, ldw, M, N, K, bias, act, dact, ldd, dact_kind, resid, ldr, Cout, ldc, C2,
                                  gamma, beta, Y, ldy, mean, rstd, s);
+    MIVIT_CHECK(rs_shape, "rowstream: unsupported shape M=%d N=%d K=%d", M, N, K);
     RsArgs a = {static_cast<const bf16 *>(A), lda, static_cast<const bf16 *>(W_bf16), ldw, M, N, K, bias, act,
                 static_cast<const bf16 *>(dact), ldd, dact_kind, static_cast<const bf16 *>(resid), ldr,
                 static_cast<bf16 *>(Cout), ldc, static_cast<bf16 *>(C2), gamma, beta, static_cast<bf16 *>(Y), ldy, mean, rstd};

@@ -1,4 +1,4 @@
-// bf16 "wave-stream" GEMMs of the encoder-layer projections (K = 128 / 256 contraction, 128-column slices):
+// bf16 "wave-stream" GEMMs of the encoder-layer projections (K = 64 / 128 / 256 contraction, 128- or 64-column slices):
 //      forward : C = act(A W^T + b) (+ residual) (+ fused post-norm LayerNorm when the slice is the whole row)
 //      dgrad   : C = (A W) * act'(saved)  |  + residual gradient
 // Same arithmetic and interface as the row-stream kernels (rowstream.hip), different data movement: these launches are
@@ -34,13 +34,13 @@ struct WsArgs {
     bf16 *Y; int64_t ldy; float *mean, *rstd;
 };
 
-constexpr int BN = 128, LDC = BN + 4;
 
-template <int K, bool DGRAD>
+template <int K, int BN, bool DGRAD>
 struct WsCfg {
-    static constexpr int NWV = K == 128 ? 12 : 8;                       // waves per workgroup (one workgroup per CU)
-    static constexpr int PF = K == 128 ? 2 : 1;                         // tiles of A fragments in flight per wave
+    static constexpr int NWV = K == 64 ? 16 : (K == 128 ? 12 : 8);     // waves per workgroup (one workgroup per CU)
+    static constexpr int PF = K == 64 ? 4 : (K == 128 ? 2 : 1);         // tiles of A fragments in flight per wave (8 loads)
     static constexpr int KS = K / 32;
+    static constexpr int LDC = BN + 4;
     static constexpr int W_LD = DGRAD ? BN + 16 : K + 8;                // elements per LDS row of the weight image
     static constexpr int W_ROWS = DGRAD ? K : BN;
     static constexpr int W_BYTES = W_ROWS * W_LD * 2;
@@ -58,9 +58,10 @@ __device__ __forceinline__ bf16x8 tr_pair(const bf16 *lo, const bf16 *hi) {
 }
 
 // E_KIND: 0 none, 1 residual add (forward), 2 activation-derivative multiply (dgrad), 3 residual add of a gradient
-template <int K, bool DGRAD, bool LN, int E_KIND>
-__global__ __launch_bounds__((K == 128 ? 12 : 8) * 64) void wavestream_kernel(const WsArgs a) {
-    using C = WsCfg<K, DGRAD>;
+template <int K, int BN, bool DGRAD, bool LN, int E_KIND>
+__global__ __launch_bounds__((K == 64 ? 16 : (K == 128 ? 12 : 8)) * 64) void wavestream_kernel(const WsArgs a) {
+    using C = WsCfg<K, BN, DGRAD>;
+    constexpr int LDC = C::LDC, TN = BN / 16, NCH = BN / 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int KS = C::KS, PF = C::PF, NT = C::NWV * 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, cq = lane & 15, q = cq >> 2, p = cq & 3;
@@ -106,13 +107,13 @@ __global__ __launch_bounds__((K == 128 ? 12 : 8) * 64) void wavestream_kernel(co
             for (int ks = 0; ks < KS; ++ks) nx[i][ks] = nx[i + 1][ks];
         load_tile(min(tile + PF * stride, ntiles - 1), nx[PF - 1]);
 
-        f32x4 acc[8];
+        f32x4 acc[TN];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < TN; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < TN; ++j) {
                 bf16x8 bf;
                 if (!DGRAD) bf = *reinterpret_cast<const bf16x8 *>(Wimg + (j * 16 + cq) * C::W_LD + ks * 32 + 8 * g);
                 else bf = tr_pair(Wimg + (ks * 32 + 8 * g + q) * C::W_LD + j * 16 + 4 * p,
@@ -120,9 +121,9 @@ __global__ __launch_bounds__((K == 128 ? 12 : 8) * 64) void wavestream_kernel(co
                 acc[j] = mma(cur[ks], bf, acc[j]);
             }
         }
-        // ---- wave-private epilogue: accumulators (+ bias) -> fp32 scratch -> rows of 128, four lanes per row ----
+        // ---- wave-private epilogue: accumulators (+ bias) -> fp32 scratch -> rows of BN, four lanes per row ----
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < TN; ++j) {
             const int lc = j * 16 + cq;
             const float bv = a.bias ? a.bias[n0 + lc] : 0.f;
 #pragma unroll
@@ -131,10 +132,10 @@ __global__ __launch_bounds__((K == 128 ? 12 : 8) * 64) void wavestream_kernel(co
         wave_lds_fence();
         const int lr = lane >> 2, row = tile * 16 + lr;
         const bool live = row < a.M;
-        float v[4][8];
+        float v[NCH][8];
         float s1 = 0.f;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
+        for (int c = 0; c < NCH; ++c) {
             const int lc = c * 32 + (lane & 3) * 8, col = n0 + lc;
             *reinterpret_cast<float4 *>(v[c]) = *reinterpret_cast<const float4 *>(Cs + lr * LDC + lc);
             *reinterpret_cast<float4 *>(v[c] + 4) = *reinterpret_cast<const float4 *>(Cs + lr * LDC + lc + 4);
@@ -161,14 +162,14 @@ __global__ __launch_bounds__((K == 128 ? 12 : 8) * 64) void wavestream_kernel(co
             const float mu = s1 * (1.f / BN);
             float s2 = 0.f;
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
+            for (int c = 0; c < NCH; ++c)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { const float dlt = v[c][e] - mu; s2 += dlt * dlt; }
             s2 += __shfl_xor(s2, 1, 64); s2 += __shfl_xor(s2, 2, 64);
             const float rs = rsqrtf(s2 * (1.f / BN) + 1e-5f);
             if (live) {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
+                for (int c = 0; c < NCH; ++c) {
                     const int lc = c * 32 + (lane & 3) * 8;
                     float o8[8];
 #pragma unroll
@@ -181,10 +182,10 @@ __global__ __launch_bounds__((K == 128 ? 12 : 8) * 64) void wavestream_kernel(co
     }
 }
 
-template <int K, bool DGRAD, bool LN, int E_KIND>
+template <int K, int BN, bool DGRAD, bool LN, int E_KIND>
 int ws_launch(const WsArgs &a, hipStream_t s) {
-    using C = WsCfg<K, DGRAD>;
-    auto kern = wavestream_kernel<K, DGRAD, LN, E_KIND>;
+    using C = WsCfg<K, BN, DGRAD>;
+    auto kern = wavestream_kernel<K, BN, DGRAD, LN, E_KIND>;
     MIVIT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
     const int ntn = a.N / BN, ntiles = ceil_div(a.M, 16);
     int gy = 256 / ntn;                                       // one resident workgroup per CU, no tail round
@@ -196,6 +197,19 @@ int ws_launch(const WsArgs &a, hipStream_t s) {
     return 0;
 }
 
+// epilogue variants of one (K, BN) shape
+template <int K, int BN>
+int ws_dispatch(const WsArgs &a, bool dgrad, bool ln, hipStream_t s) {
+    if (dgrad) {
+        if (a.dact) return ws_launch<K, BN, true, false, 2>(a, s);
+        if (a.resid) return ws_launch<K, BN, true, false, 3>(a, s);
+        return ws_launch<K, BN, true, false, 0>(a, s);
+    }
+    if (ln) return ws_launch<K, BN, false, true, 1>(a, s);
+    if (a.resid) return ws_launch<K, BN, false, false, 1>(a, s);
+    return ws_launch<K, BN, false, false, 0>(a, s);
+}
+
 bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
@@ -203,7 +217,8 @@ bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 
 bool wavestream_supported(int M, int N, int K, bool dgrad, int64_t lda, int64_t ldw, const void *A, const void *W) {
     static const bool off = getenv("MIVIT_NO_WAVESTREAM") != nullptr;
     if (off) return false;
-    if (!(K == 128 || K == 256) || N % 128 != 0 || M < 256) return false;
+    if (!(K == 64 || K == 128 || K == 256) || N % 64 != 0 || M < 256) return false;
+    if (K == 256 && N % 128 != 0) return false;
     if (lda % 8 || ldw % 8 || !aligned16(A) || !aligned16(W)) return false;
     return true;
 }
@@ -217,24 +232,20 @@ int launch_wavestream(bool dgrad, const void *A, int64_t lda, const void *W_bf16
                 static_cast<const bf16 *>(dact), ldd, dact_kind, static_cast<const bf16 *>(resid), ldr,
                 static_cast<bf16 *>(Cout), ldc, static_cast<bf16 *>(C2), gamma, beta, static_cast<bf16 *>(Y), ldy, mean, rstd};
     const bool ln = gamma != nullptr;
-    MIVIT_CHECK(!ln || (N == 128 && !dgrad && resid), "wavestream: fused LayerNorm needs N == 128, forward, with a residual");
+    const int BNsel = N % 128 == 0 ? 128 : 64;
+    MIVIT_CHECK(!ln || (N == BNsel && !dgrad && resid), "wavestream: fused LayerNorm needs the slice to be the whole row (N = 64 or 128), forward, with a residual");
     MIVIT_CHECK(!(dact && resid), "wavestream: at most one epilogue operand");
     MIVIT_CHECK(ldc % 8 == 0 && (!ln || ldy % 8 == 0) && aligned16(Cout) && (!C2 || aligned16(C2)) && (!Y || aligned16(Y)),
                 "wavestream: outputs must be 16-byte aligned with ld % 8 == 0");
     MIVIT_CHECK((!resid || (ldr % 8 == 0 && aligned16(resid))) && (!dact || (ldd % 8 == 0 && aligned16(dact))),
                 "wavestream: epilogue operand must be 16-byte aligned with ld % 8 == 0");
-#define WS_GO(KK, DG, LNF, EK) return ws_launch<KK, DG, LNF, EK>(a, s)
-    if (K == 128) {
-        if (dgrad) { if (dact) WS_GO(128, true, false, 2); if (resid) WS_GO(128, true, false, 3); WS_GO(128, true, false, 0); }
-        if (ln) WS_GO(128, false, true, 1);
-        if (resid) WS_GO(128, false, false, 1);
-        WS_GO(128, false, false, 0);
+    if (BNsel == 128) {
+        if (K == 64) return ws_dispatch<64, 128>(a, dgrad, ln, s);
+        if (K == 128) return ws_dispatch<128, 128>(a, dgrad, ln, s);
+        return ws_dispatch<256, 128>(a, dgrad, ln, s);
     }
-    if (dgrad) { if (dact) WS_GO(256, true, false, 2); if (resid) WS_GO(256, true, false, 3); WS_GO(256, true, false, 0); }
-    if (ln) WS_GO(256, false, true, 1);
-    if (resid) WS_GO(256, false, false, 1);
-    WS_GO(256, false, false, 0);
-#undef WS_GO
+    if (K == 64) return ws_dispatch<64, 64>(a, dgrad, ln, s);
+    return ws_dispatch<128, 64>(a, dgrad, ln, s);
 }
 
 extern "C" int mivit_wavestream_fwd(const void *x, int64_t ldx, const void *W_bf16, const float *bias, int M, int N, int K,
