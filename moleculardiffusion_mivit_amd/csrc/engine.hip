@@ -4,6 +4,7 @@
 // the kernels in gemm.hip / norm.hip / attention.hip / misc.hip.  The engine owns no device memory: the caller
 // passes the parameter arena, the gradient arena and one workspace whose layout is computed here.
 #include "common.h"
+#include <algorithm>
 
 #include <string>
 #include <vector>
@@ -102,6 +103,7 @@ Ws make_ws(const mivit_plan *p, int B, int T, bool bwd) {
         auto mx = [&](int m, int n, int k) {
             size_t b = linear_wgrad_ws_bytes(m, n, k);
             if (c.dtype == MIVIT_BF16 && n % 128 == 0 && k % 128 == 0 && m >= 256) b += wgrad_dma_ws_bytes(m, n, k);
+            if (c.dtype == MIVIT_BF16 && m >= 256) b = std::max(b, wgrad_small_ws_bytes(m, n, k));
             if (b > wg) wg = b;
         };
         mx((int)M, 3 * E, E); mx((int)M, E, E); mx((int)M, F, E); mx((int)M, E, F);
@@ -184,6 +186,15 @@ int lin_wgrad(int dtype, const void *dy, int64_t lddy, const void *x, int x_f32,
         wsb >= wgrad_dma_ws_bytes(M, N, K) + linear_wgrad_ws_bytes(M, N, K)) {
         prof_set_tag(MIVIT_PROF_LINEAR_WGRAD);
         return launch_wgrad_dma(dy, lddy, x, ldx, M, N, K, dW, db, ws, wsb, s);      // db (optional) from the same pass
+    }
+    if (dtype == MIVIT_BF16 && !x_f32 && dW && wgrad_small_supported(M, N, K, lddy, ldx, dy, x) &&
+        wsb >= wgrad_small_ws_bytes(M, N, K) && wsb >= linear_wgrad_ws_bytes(M, N, K)) {
+        prof_set_tag(MIVIT_PROF_LINEAR_WGRAD);
+        RC(launch_wgrad_small(dy, lddy, x, ldx, M, N, K, dW, ws, wsb, s));
+        if (!db) return 0;
+        LinearWgradArgs b = {};          // bias gradient only (column sums of dy), after the slabs were consumed
+        b.dtype = dtype; b.dy = dy; b.lddy = lddy; b.x = x; b.ldx = ldx; b.M = M; b.N = N; b.K = K; b.db = db; b.ws = ws; b.ws_bytes = wsb;
+        return launch_linear_wgrad(b, s);
     }
     LinearWgradArgs a = {};
     a.dtype = dtype; a.dy = dy; a.dy_is_f32 = dtype == MIVIT_F32; a.lddy = lddy; a.x = x;

@@ -1,0 +1,182 @@
+// Weight gradients of NARROW layers (64-wide models: N, K in {64, 96, 128}), bf16:  dW[N, K] = dY[M, N]^T . X[M, K].
+// The whole [NB x KB] gradient block (<= 32 MFMA tiles) lives in one wave's accumulators; every wave walks its own
+// 32-row chunks of dY and X: 16-byte global loads one chunk ahead -> wave-private natural [row][col] LDS images ->
+// both MFMA operands by ds_read_b64_tr_b16 (the contraction runs over rows).  No barrier while streaming; the eight
+// waves of a workgroup are summed through LDS in a fixed order at the end, workgroups through a slab + slab_reduce
+// (deterministic).  Wide layers use wgrad_dma.hip (128 x 128 tiles).
+#include "common.h"
+#include <stdlib.h>
+#include <algorithm>
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+constexpr int NWV = 8, NT = NWV * 64, CH = 32;        // waves per workgroup, rows per chunk (one 32-deep MFMA k step)
+
+__device__ __forceinline__ f32x4 mma(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ bf16x8 tr_pair(const bf16 *lo, const bf16 *hi) {
+    typedef __attribute__((address_space(3))) s16x4 lds_v4;
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4 *)(lo));
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4 *)(hi));
+    struct { s16x4 a, b; } pr = {a, b};
+    return __builtin_bit_cast(bf16x8, pr);
+}
+
+struct WsmArgs {
+    const bf16 *dY; int64_t lddy; const bf16 *X; int64_t ldx;
+    float *slabs;        // [gridDim.x][N][K]
+    int M, N, K;
+};
+
+template <int W> constexpr int img_ld() { return W + (W % 128 == 0 ? 16 : 8); }   // row stride (elements): conflict-free tr reads
+
+// NB = dY columns of this workgroup (blockIdx.y selects the window), KB = all X columns
+template <int NB, int KB>
+__global__ __launch_bounds__(NT) void wgrad_small_kernel(const WsmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int TMN = NB / 16, TKN = KB / 16, LDA = img_ld<NB>(), LDB = img_ld<KB>();
+    constexpr int VA = CH * NB / 8 / 64, VB = CH * KB / 8 / 64;          // 16-byte vectors per lane per chunk
+    static_assert(TMN * TKN <= 32, "accumulator budget");
+    static_assert(CH * NB / 8 % 64 == 0 && CH * KB / 8 % 64 == 0, "chunk must split evenly over the lanes");
+    constexpr int WAVE_LDS = (CH * LDA + CH * LDB) * 2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, cq = lane & 15, q = cq >> 2, p = cq & 3;
+    const int n0 = blockIdx.y * NB;
+    bf16 *Aimg = reinterpret_cast<bf16 *>(smem + wave * WAVE_LDS), *Bimg = Aimg + CH * LDA;
+
+    f32x4 acc[TMN][TKN];
+#pragma unroll
+    for (int i = 0; i < TMN; ++i)
+#pragma unroll
+        for (int j = 0; j < TKN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nchunks = (a.M + CH - 1) / CH, stride = gridDim.x * NWV;
+    uint4 ra[VA], rb[VB];
+    auto load_chunk = [&](int c) {
+#pragma unroll
+        for (int v = 0; v < VA; ++v) {
+            const int idx = v * 64 + lane, r = idx / (NB / 8), col = (idx % (NB / 8)) * 8, row = c * CH + r;
+            ra[v] = row < a.M ? *reinterpret_cast<const uint4 *>(a.dY + (int64_t)row * a.lddy + n0 + col) : make_uint4(0u, 0u, 0u, 0u);
+        }
+#pragma unroll
+        for (int v = 0; v < VB; ++v) {
+            const int idx = v * 64 + lane, r = idx / (KB / 8), col = (idx % (KB / 8)) * 8, row = c * CH + r;
+            rb[v] = row < a.M ? *reinterpret_cast<const uint4 *>(a.X + (int64_t)row * a.ldx + col) : make_uint4(0u, 0u, 0u, 0u);
+        }
+    };
+    int chunk = blockIdx.x * NWV + wave;
+    if (chunk < nchunks) load_chunk(chunk);
+    for (; chunk < nchunks; chunk += stride) {
+        // registers (this chunk) -> wave-private LDS images; then prefetch the next chunk while the MFMAs run
+#pragma unroll
+        for (int v = 0; v < VA; ++v) {
+            const int idx = v * 64 + lane, r = idx / (NB / 8), col = (idx % (NB / 8)) * 8;
+            *reinterpret_cast<uint4 *>(Aimg + r * LDA + col) = ra[v];
+        }
+#pragma unroll
+        for (int v = 0; v < VB; ++v) {
+            const int idx = v * 64 + lane, r = idx / (KB / 8), col = (idx % (KB / 8)) * 8;
+            *reinterpret_cast<uint4 *>(Bimg + r * LDB + col) = rb[v];
+        }
+        wave_lds_fence();
+        if (chunk + stride < nchunks) load_chunk(chunk + stride);
+        const int rlo = 4 * g + q, rhi = rlo + 16;
+        bf16x8 bf[TKN];
+#pragma unroll
+        for (int j = 0; j < TKN; ++j) bf[j] = tr_pair(Bimg + rlo * LDB + j * 16 + 4 * p, Bimg + rhi * LDB + j * 16 + 4 * p);
+#pragma unroll
+        for (int i = 0; i < TMN; ++i) {
+            const bf16x8 af = tr_pair(Aimg + rlo * LDA + i * 16 + 4 * p, Aimg + rhi * LDA + i * 16 + 4 * p);
+#pragma unroll
+            for (int j = 0; j < TKN; ++j) acc[i][j] = mma(af, bf[j], acc[i][j]);
+        }
+        wave_lds_fence();         // the images are overwritten at the top of the next iteration
+    }
+    // ---- workgroup reduction in a fixed wave order, then one slab row per workgroup ----
+    __syncthreads();
+    float *red = reinterpret_cast<float *>(smem);           // [NB][KB] fp32 (fits: NB * KB * 4 <= 32 KiB)
+    for (int w = 0; w < NWV; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int i = 0; i < TMN; ++i)
+#pragma unroll
+                for (int j = 0; j < TKN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float *dst = red + (i * 16 + 4 * g + r) * KB + j * 16 + cq;
+                        *dst = w == 0 ? acc[i][j][r] : *dst + acc[i][j][r];
+                    }
+        }
+        __syncthreads();
+    }
+    float *out = a.slabs + (int64_t)blockIdx.x * a.N * a.K;
+    for (int i = tid; i < NB * KB; i += NT) {
+        const int n = i / KB, k = i - n * KB;
+        out[(int64_t)(n0 + n) * a.K + k] = red[i];
+    }
+}
+
+constexpr int SLAB_PARTS = 256;           // one resident workgroup per CU
+
+template <int NB, int KB>
+int launch_t(const WsmArgs &a, int nsplit, int *parts, hipStream_t s) {
+    constexpr int WAVE_LDS = (CH * img_ld<NB>() + CH * img_ld<KB>()) * 2;
+    const size_t bytes = std::max((size_t)NWV * WAVE_LDS, (size_t)NB * KB * 4);
+    auto kern = wgrad_small_kernel<NB, KB>;
+    MIVIT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    const int nchunks = ceil_div(a.M, CH);
+    const int gx = std::max(1, std::min(SLAB_PARTS / nsplit, ceil_div(nchunks, NWV)));
+    ProfScope prof(s);
+    hipLaunchKernelGGL(kern, dim3(gx, nsplit), dim3(NT), bytes, s, a);
+    MIVIT_LAUNCH_CHECK();
+    *parts = gx;
+    return 0;
+}
+
+// (N window, K) shapes instantiated: the 64-wide models' projections
+int window_of(int N, int K) {
+    if (K == 64 && (N == 64 || N == 128)) return N;
+    if (K == 64 && N == 192) return 96;
+    if (K == 128 && N == 64) return 64;
+    return 0;
+}
+
+}  // namespace
+
+bool wgrad_small_supported(int M, int N, int K, int64_t lddy, int64_t ldx, const void *dy, const void *x) {
+    static const bool off = getenv("MIVIT_NO_WGRAD_SMALL") != nullptr;
+    return !off && window_of(N, K) != 0 && M >= 256 && lddy % 8 == 0 && ldx % 8 == 0 &&
+           ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(x)) & 15) == 0;
+}
+
+size_t wgrad_small_ws_bytes(int M, int N, int K) {
+    return window_of(N, K) ? align_up((size_t)SLAB_PARTS * N * K * sizeof(float), 256) : 0;
+}
+
+int launch_wgrad_small(const void *dy, int64_t lddy, const void *x, int64_t ldx, int M, int N, int K, float *dW, void *ws,
+                       size_t ws_bytes, hipStream_t s) {
+    MIVIT_CHECK(ws_bytes >= wgrad_small_ws_bytes(M, N, K), "wgrad_small: workspace too small");
+    WsmArgs a = {static_cast<const bf16 *>(dy), lddy, static_cast<const bf16 *>(x), ldx, static_cast<float *>(ws), M, N, K};
+    const int nb = window_of(N, K), nsplit = N / nb;
+    int parts = 0, rc;
+    if (nb == 64 && K == 64) rc = launch_t<64, 64>(a, nsplit, &parts, s);
+    else if (nb == 128 && K == 64) rc = launch_t<128, 64>(a, nsplit, &parts, s);
+    else if (nb == 96 && K == 64) rc = launch_t<96, 64>(a, nsplit, &parts, s);
+    else if (nb == 64 && K == 128) rc = launch_t<64, 128>(a, nsplit, &parts, s);
+    else MIVIT_FAIL("wgrad_small: unsupported shape N=%d K=%d", N, K);
+    if (rc) return rc;
+    return launch_slab_reduce(static_cast<const float *>(ws), parts, (int64_t)N * K, dW, 0, s);
+}
+
+extern "C" size_t mivit_wgrad_small_workspace_bytes(int M, int N, int K) {
+    return window_of(N, K) ? wgrad_small_ws_bytes(M, N, K) : 0;
+}
+extern "C" int mivit_wgrad_small(const void *dy, int64_t lddy, const void *x, int64_t ldx, int M, int N, int K, float *dW,
+                                 void *workspace, size_t workspace_bytes, void *stream) {
+    MIVIT_CHECK(dy && x && dW && workspace, "wgrad_small: null pointer");
+    if (!wgrad_small_supported(M, N, K, lddy, ldx, dy, x)) { mivit_set_error("wgrad_small: unsupported shape"); return 3; }
+    prof_set_tag(MIVIT_PROF_OP);
+    return launch_wgrad_small(dy, lddy, x, ldx, M, N, K, dW, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+}

@@ -318,3 +318,18 @@ def test_gemm_dma_dgrad_exact(M, N, K, variant):
     if variant == "dres":
         ref = ref + dres.double()
     assert torch.equal(dx.float().cpu(), ref.float().bfloat16().float())
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 64, 64), (1000, 128, 64), (4131, 192, 64), (70000, 64, 128), (300, 192, 64)])
+def test_wgrad_small_exact(M, N, K):
+    """Narrow-layer weight gradient (csrc/wgrad_small.hip) on small integers: every partial sum is exact in fp32."""
+    import ctypes
+    from moleculardiffusion_mivit_amd import _native as N_
+    dy, x = _ints((M, N), -2, 2, 21), _ints((M, K), -2, 2, 22)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())   # noqa: E731
+    dyg, xg = dy.bfloat16().cuda(), x.bfloat16().cuda()
+    ws = torch.empty(N_.lib.mivit_wgrad_small_workspace_bytes(M, N, K), dtype=torch.uint8, device="cuda")
+    dW = torch.empty(N, K, device="cuda")
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    N_.check(N_.lib.mivit_wgrad_small(p(dyg), N, p(xg), K, M, N, K, p(dW), p(ws), ws.numel(), st), "wgrad_small")
+    assert torch.equal(dW.cpu(), (dy.double().t() @ x.double()).float())
