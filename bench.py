@@ -90,7 +90,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch-per-gpu", type=int, default=int(os.environ.get("MIVIT_BENCH_BATCH", 8192)))
+    ap.add_argument("--batch-per-gpu", type=int, default=int(os.environ.get("MIVIT_BENCH_BATCH", 16384)))
     ap.add_argument("--precision", default=os.environ.get("MIVIT_BENCH_PRECISION", "bf16"), choices=["bf16", "fp32"])
     ap.add_argument("--resident-batches", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
