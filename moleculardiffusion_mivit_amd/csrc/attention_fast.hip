@@ -406,11 +406,10 @@ int bwd_launch(const bf16 *qkv, const bf16 *dctx, bf16 *dqkv, const FastDims &d,
 bool attention_fast_supported(int dtype, int S, int Dh) {
     // one wavefront holds the whole (batch, head) problem in registers: the backward's register budget sets the limit
     if (dtype != MIVIT_BF16 || S < 1) return false;
+    // (up to 5 token tiles at Dh = 64 / 7 at 32 / 8 at 16 compile without scratch; the longer ones spill a little in the
+    //  backward but keep every sequence the reference's 128-entry positional table allows on this path)
     const int NT = (S + 15) / 16;
-    if (Dh == 16) return NT <= 8;
-    if (Dh == 32) return NT <= 7;
-    if (Dh == 64) return NT <= 5;
-    return false;
+    return (Dh == 16 || Dh == 32 || Dh == 64) && NT <= 8;
 }
 
 #define FAST_DISPATCH(FN, ...)                                                 \
@@ -435,6 +434,10 @@ bool attention_fast_supported(int dtype, int S, int Dh) {
         case 71: return FN<7, 1>(__VA_ARGS__);                                 \
         case 72: return FN<7, 2>(__VA_ARGS__);                                 \
         case 81: return FN<8, 1>(__VA_ARGS__);                                 \
+        case 82: return FN<8, 2>(__VA_ARGS__);                                 \
+        case 64: return FN<6, 4>(__VA_ARGS__);                                 \
+        case 74: return FN<7, 4>(__VA_ARGS__);                                 \
+        case 84: return FN<8, 4>(__VA_ARGS__);                                 \
         default: MIVIT_FAIL("attention fast path: unsupported tile shape");    \
     }
 

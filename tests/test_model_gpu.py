@@ -450,3 +450,20 @@ def test_fp16_training_with_grad_scaler():
     assert scales[-1] < 2.0 ** 30 and scales[-1] >= 1.0
     assert all(map(lambda v: v == v, losses))                 # no NaN ever reaches the loss
     assert losses[-1] < 0.5 * losses[0], (losses[0], losses[-1])
+
+
+def test_maximum_sequence_length_with_positional_table():
+    """The reference's learned positional table holds 128 tokens (models.py:8,120): 127 frames + the regression token is
+    the longest sequence a pos-encoding model accepts.  bf16 runs it on the register-resident attention kernels."""
+    cfg = orc.MiViTConfig(embedding="linear", patch_size=9, embed_dim=64, num_heads=2, hidden_dim=128, num_layers=2,
+                          use_pos_encoding=True)
+    params = orc.closed_form_params(cfg)
+    x, labels, _ = orc.closed_form_batch(6, 127, 9, salt=2)
+    t_out, t_loss, t_g = orc.loss_and_grads(params, cfg, x, labels, None)
+    m = build_product_model(cfg, "bf16", params).train()
+    out, loss, grads = _run(m, x.cuda(), labels.cuda(), None)
+    assert bool(torch.isfinite(out).all()) and all(bool(torch.isfinite(g).all()) for g in grads.values())
+    assert float((out.cpu() - t_out).abs().max()) < 5e-2 * max(float(t_out.abs().max()), 0.25)
+    gscale = max(float(g.norm()) for g in t_g.values())
+    for k, g in t_g.items():
+        assert float((grads[k].cpu() - g).norm()) < 0.3 * (float(g.norm()) + 1e-2 * gscale), k   # small batch, bf16 ReLU flips

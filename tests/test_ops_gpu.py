@@ -111,7 +111,8 @@ def _attn_ref(qkv, H):
 @pytest.mark.parametrize("B,S,H,Dh", [(8, 33, 4, 32), (4, 31, 4, 16), (2, 65, 8, 64), (3, 7, 2, 16), (2, 16, 2, 32),
                                       (2, 17, 4, 16), (1, 1, 1, 16), (2, 61, 4, 16), (2, 48, 8, 16), (1, 80, 2, 64),
                                       (2, 64, 2, 32), (1, 65, 4, 32), (3, 49, 4, 32), (2, 32, 4, 16), (1, 96, 2, 32),
-                                      (1, 112, 2, 32), (2, 128, 2, 16), (1, 100, 3, 16), (5, 65, 8, 64), (1, 113, 2, 32)])
+                                      (1, 112, 2, 32), (2, 128, 2, 16), (1, 100, 3, 16), (5, 65, 8, 64), (1, 113, 2, 32),
+                                      (2, 128, 4, 32), (1, 128, 2, 64), (1, 97, 2, 64)])
 def test_attention(dtype, B, S, H, Dh):
     from moleculardiffusion_mivit_amd import ops, _native as N
     code = {torch.float32: N.F32, torch.bfloat16: N.BF16, torch.float16: N.F16}[dtype]
