@@ -155,7 +155,7 @@ int mivit_deepresnet_train_bwd(int dtype, const mivit_deepresnet_params *params,
  * (192,64), (64,128)}, M >= 256; the whole gradient block lives in each wave's accumulators, deterministic reduction. */
 size_t mivit_wgrad_small_workspace_bytes(int M, int N, int K);
 int mivit_wgrad_small(const void *dy, int64_t lddy, const void *x, int64_t ldx, int M, int N, int K, float *dW,
-                      void *workspace, size_t workspace_bytes, void *stream);
+                      float *db /* optional: column sums of dy */, void *workspace, size_t workspace_bytes, void *stream);
 
 /* Row LayerNorm over E, eps 1e-5, biased variance, affine (nn.LayerNorm: models.py:88-89,134,301).
  * Row r of the output goes to row  (r / rows_per_seq) * out_seq_stride + r % rows_per_seq + out_row_off  when

@@ -83,8 +83,8 @@ SYMBOLS = {
                                            c_void_p, c_size_t, c_void_p]),
     "mivit_graph_stats": (None, [c_void_p, c_void_p, c_void_p]),
     "mivit_wgrad_small_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
-    "mivit_wgrad_small": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t,
-                                  c_void_p]),
+    "mivit_wgrad_small": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                  c_size_t, c_void_p]),
     "mivit_layernorm_fwd": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int64,
                                     c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mivit_layernorm_bwd_workspace_bytes": (c_size_t, [c_int, c_int]),

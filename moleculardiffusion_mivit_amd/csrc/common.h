@@ -306,8 +306,8 @@ int launch_wgrad_dma(const void *dy, int64_t lddy, const void *x, int64_t ldx, i
 // bf16 weight gradient of narrow layers (wgrad_small.hip): (N, K) in {(64,64), (128,64), (192,64), (64,128)}
 bool wgrad_small_supported(int M, int N, int K, int64_t lddy, int64_t ldx, const void *dy, const void *x);
 size_t wgrad_small_ws_bytes(int M, int N, int K);
-int launch_wgrad_small(const void *dy, int64_t lddy, const void *x, int64_t ldx, int M, int N, int K, float *dW, void *ws,
-                       size_t ws_bytes, hipStream_t s);
+int launch_wgrad_small(const void *dy, int64_t lddy, const void *x, int64_t ldx, int M, int N, int K, float *dW, float *db,
+                       void *ws, size_t ws_bytes, hipStream_t s);
 
 // small elementwise / reduction helpers (misc.hip)
 // out[n] (+)= sum_p part[p*n_stride + n]   (deterministic slab reduce)

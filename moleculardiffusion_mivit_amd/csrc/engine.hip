@@ -190,11 +190,7 @@ int lin_wgrad(int dtype, const void *dy, int64_t lddy, const void *x, int x_f32,
     if (dtype == MIVIT_BF16 && !x_f32 && dW && wgrad_small_supported(M, N, K, lddy, ldx, dy, x) &&
         wsb >= wgrad_small_ws_bytes(M, N, K) && wsb >= linear_wgrad_ws_bytes(M, N, K)) {
         prof_set_tag(MIVIT_PROF_LINEAR_WGRAD);
-        RC(launch_wgrad_small(dy, lddy, x, ldx, M, N, K, dW, ws, wsb, s));
-        if (!db) return 0;
-        LinearWgradArgs b = {};          // bias gradient only (column sums of dy), after the slabs were consumed
-        b.dtype = dtype; b.dy = dy; b.lddy = lddy; b.x = x; b.ldx = ldx; b.M = M; b.N = N; b.K = K; b.db = db; b.ws = ws; b.ws_bytes = wsb;
-        return launch_linear_wgrad(b, s);
+        return launch_wgrad_small(dy, lddy, x, ldx, M, N, K, dW, db, ws, wsb, s);      // db (optional) from the same pass
     }
     LinearWgradArgs a = {};
     a.dtype = dtype; a.dy = dy; a.dy_is_f32 = dtype == MIVIT_F32; a.lddy = lddy; a.x = x;

@@ -421,7 +421,7 @@ int wgrad_splits(int M, int N, int K) {
     return (int)s;
 }
 int colsum_chunks(int M) {
-    int c = ceil_div(M, 512);
+    int c = ceil_div(M, M < 8192 ? 64 : 512);       // short problems: more, shorter row chunks (the row loop is a latency chain)
     return c < 1 ? 1 : (c > 256 ? 256 : c);
 }
 

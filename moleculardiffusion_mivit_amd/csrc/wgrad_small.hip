@@ -28,6 +28,7 @@ __device__ __forceinline__ bf16x8 tr_pair(const bf16 *lo, const bf16 *hi) {
 struct WsmArgs {
     const bf16 *dY; int64_t lddy; const bf16 *X; int64_t ldx;
     float *slabs;        // [gridDim.x][N][K]
+    float *bias_slabs;   // optional [gridDim.x][N]: column sums of dY (bias gradient), one extra MFMA per dY fragment
     int M, N, K;
 };
 
@@ -46,11 +47,17 @@ __global__ __launch_bounds__(NT) void wgrad_small_kernel(const WsmArgs a) {
     const int n0 = blockIdx.y * NB;
     bf16 *Aimg = reinterpret_cast<bf16 *>(smem + wave * WAVE_LDS), *Bimg = Aimg + CH * LDA;
 
-    f32x4 acc[TMN][TKN];
+    f32x4 acc[TMN][TKN], accb[TMN];
 #pragma unroll
-    for (int i = 0; i < TMN; ++i)
+    for (int i = 0; i < TMN; ++i) {
+        accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < TKN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const bool do_bias = a.bias_slabs != nullptr;
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
 
     const int nchunks = (a.M + CH - 1) / CH, stride = gridDim.x * NWV;
     uint4 ra[VA], rb[VB];
@@ -91,23 +98,36 @@ __global__ __launch_bounds__(NT) void wgrad_small_kernel(const WsmArgs a) {
             const bf16x8 af = tr_pair(Aimg + rlo * LDA + i * 16 + 4 * p, Aimg + rhi * LDA + i * 16 + 4 * p);
 #pragma unroll
             for (int j = 0; j < TKN; ++j) acc[i][j] = mma(af, bf[j], acc[i][j]);
+            if (do_bias) accb[i] = mma(af, ones, accb[i]);          // every column of the tile = sum over rows of dY[:, n]
         }
         wave_lds_fence();         // the images are overwritten at the top of the next iteration
     }
     // ---- workgroup reduction in a fixed wave order, then one slab row per workgroup ----
     __syncthreads();
-    float *red = reinterpret_cast<float *>(smem);           // [NB][KB] fp32 (fits: NB * KB * 4 <= 32 KiB)
+    float *red = reinterpret_cast<float *>(smem);           // [NB][KB] fp32 (fits: NB * KB * 4 <= 32 KiB) + [NB] bias sums
+    float *redb = red + NB * KB;
     for (int w = 0; w < NWV; ++w) {
         if (wave == w) {
+            // (loads of a whole tile row first, then the stores: interleaved read-modify-writes serialise on LDS latency)
 #pragma unroll
-            for (int i = 0; i < TMN; ++i)
+            for (int i = 0; i < TMN; ++i) {
+                float old[TKN][4];
 #pragma unroll
                 for (int j = 0; j < TKN; ++j)
 #pragma unroll
+                    for (int r = 0; r < 4; ++r) old[j][r] = w == 0 ? 0.f : red[(i * 16 + 4 * g + r) * KB + j * 16 + cq];
+#pragma unroll
+                for (int j = 0; j < TKN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) red[(i * 16 + 4 * g + r) * KB + j * 16 + cq] = old[j][r] + acc[i][j][r];
+                if (do_bias && cq == 0) {
+#pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        float *dst = red + (i * 16 + 4 * g + r) * KB + j * 16 + cq;
-                        *dst = w == 0 ? acc[i][j][r] : *dst + acc[i][j][r];
+                        float *dst = redb + i * 16 + 4 * g + r;
+                        *dst = w == 0 ? accb[i][r] : *dst + accb[i][r];
                     }
+                }
+            }
         }
         __syncthreads();
     }
@@ -116,6 +136,8 @@ __global__ __launch_bounds__(NT) void wgrad_small_kernel(const WsmArgs a) {
         const int n = i / KB, k = i - n * KB;
         out[(int64_t)(n0 + n) * a.K + k] = red[i];
     }
+    if (do_bias)
+        for (int i = tid; i < NB; i += NT) a.bias_slabs[(int64_t)blockIdx.x * a.N + n0 + i] = redb[i];
 }
 
 constexpr int SLAB_PARTS = 256;           // one resident workgroup per CU
@@ -123,7 +145,7 @@ constexpr int SLAB_PARTS = 256;           // one resident workgroup per CU
 template <int NB, int KB>
 int launch_t(const WsmArgs &a, int nsplit, int *parts, hipStream_t s) {
     constexpr int WAVE_LDS = (CH * img_ld<NB>() + CH * img_ld<KB>()) * 2;
-    const size_t bytes = std::max((size_t)NWV * WAVE_LDS, (size_t)NB * KB * 4);
+    const size_t bytes = std::max((size_t)NWV * WAVE_LDS, (size_t)NB * KB * 4 + (size_t)NB * 4);
     auto kern = wgrad_small_kernel<NB, KB>;
     MIVIT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     const int nchunks = ceil_div(a.M, CH);
@@ -152,13 +174,14 @@ bool wgrad_small_supported(int M, int N, int K, int64_t lddy, int64_t ldx, const
 }
 
 size_t wgrad_small_ws_bytes(int M, int N, int K) {
-    return window_of(N, K) ? align_up((size_t)SLAB_PARTS * N * K * sizeof(float), 256) : 0;
+    return window_of(N, K) ? align_up((size_t)SLAB_PARTS * N * (K + 1) * sizeof(float), 256) : 0;
 }
 
-int launch_wgrad_small(const void *dy, int64_t lddy, const void *x, int64_t ldx, int M, int N, int K, float *dW, void *ws,
-                       size_t ws_bytes, hipStream_t s) {
+int launch_wgrad_small(const void *dy, int64_t lddy, const void *x, int64_t ldx, int M, int N, int K, float *dW, float *db,
+                       void *ws, size_t ws_bytes, hipStream_t s) {
     MIVIT_CHECK(ws_bytes >= wgrad_small_ws_bytes(M, N, K), "wgrad_small: workspace too small");
-    WsmArgs a = {static_cast<const bf16 *>(dy), lddy, static_cast<const bf16 *>(x), ldx, static_cast<float *>(ws), M, N, K};
+    float *bias_slabs = db ? static_cast<float *>(ws) + (size_t)SLAB_PARTS * N * K : nullptr;
+    WsmArgs a = {static_cast<const bf16 *>(dy), lddy, static_cast<const bf16 *>(x), ldx, static_cast<float *>(ws), bias_slabs, M, N, K};
     const int nb = window_of(N, K), nsplit = N / nb;
     int parts = 0, rc;
     if (nb == 64 && K == 64) rc = launch_t<64, 64>(a, nsplit, &parts, s);
@@ -167,16 +190,17 @@ int launch_wgrad_small(const void *dy, int64_t lddy, const void *x, int64_t ldx,
     else if (nb == 64 && K == 128) rc = launch_t<64, 128>(a, nsplit, &parts, s);
     else MIVIT_FAIL("wgrad_small: unsupported shape N=%d K=%d", N, K);
     if (rc) return rc;
-    return launch_slab_reduce(static_cast<const float *>(ws), parts, (int64_t)N * K, dW, 0, s);
+    if ((rc = launch_slab_reduce(static_cast<const float *>(ws), parts, (int64_t)N * K, dW, 0, s))) return rc;
+    return db ? launch_slab_reduce(bias_slabs, parts, N, db, 0, s) : 0;
 }
 
 extern "C" size_t mivit_wgrad_small_workspace_bytes(int M, int N, int K) {
     return window_of(N, K) ? wgrad_small_ws_bytes(M, N, K) : 0;
 }
 extern "C" int mivit_wgrad_small(const void *dy, int64_t lddy, const void *x, int64_t ldx, int M, int N, int K, float *dW,
-                                 void *workspace, size_t workspace_bytes, void *stream) {
+                                 float *db, void *workspace, size_t workspace_bytes, void *stream) {
     MIVIT_CHECK(dy && x && dW && workspace, "wgrad_small: null pointer");
     if (!wgrad_small_supported(M, N, K, lddy, ldx, dy, x)) { mivit_set_error("wgrad_small: unsupported shape"); return 3; }
     prof_set_tag(MIVIT_PROF_OP);
-    return launch_wgrad_small(dy, lddy, x, ldx, M, N, K, dW, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+    return launch_wgrad_small(dy, lddy, x, ldx, M, N, K, dW, db, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
 }

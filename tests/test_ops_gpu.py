@@ -331,6 +331,11 @@ def test_wgrad_small_exact(M, N, K):
     dyg, xg = dy.bfloat16().cuda(), x.bfloat16().cuda()
     ws = torch.empty(N_.lib.mivit_wgrad_small_workspace_bytes(M, N, K), dtype=torch.uint8, device="cuda")
     dW = torch.empty(N, K, device="cuda")
+    db = torch.empty(N, device="cuda")
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    N_.check(N_.lib.mivit_wgrad_small(p(dyg), N, p(xg), K, M, N, K, p(dW), p(ws), ws.numel(), st), "wgrad_small")
+    N_.check(N_.lib.mivit_wgrad_small(p(dyg), N, p(xg), K, M, N, K, p(dW), p(db), p(ws), ws.numel(), st), "wgrad_small")
+    assert torch.equal(dW.cpu(), (dy.double().t() @ x.double()).float())
+    assert torch.equal(db.cpu(), dy.double().sum(0).float())
+    dW.zero_()
+    N_.check(N_.lib.mivit_wgrad_small(p(dyg), N, p(xg), K, M, N, K, p(dW), None, p(ws), ws.numel(), st), "wgrad_small")
     assert torch.equal(dW.cpu(), (dy.double().t() @ x.double()).float())
