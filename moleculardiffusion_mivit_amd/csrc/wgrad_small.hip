@@ -102,20 +102,20 @@ __global__ __launch_bounds__(NT) void wgrad_small_kernel(const WsmArgs a) {
         }
         wave_lds_fence();         // the images are overwritten at the top of the next iteration
     }
-    // ---- workgroup reduction in a fixed wave order, then one slab row per workgroup ----
+    // ---- workgroup reduction in a fixed order: waves 0-3 store into four regions, waves 4-7 add into them, then every
+    //      thread sums the four regions element-wise into the workgroup's slab row (three barriers in all) ----
     __syncthreads();
-    float *red = reinterpret_cast<float *>(smem);           // [NB][KB] fp32 (fits: NB * KB * 4 <= 32 KiB) + [NB] bias sums
-    float *redb = red + NB * KB;
-    for (int w = 0; w < NWV; ++w) {
-        if (wave == w) {
-            // (loads of a whole tile row first, then the stores: interleaved read-modify-writes serialise on LDS latency)
+    constexpr int RSZ = NB * KB + NB;                       // one region: [NB][KB] gradient block + [NB] bias sums
+    float *red = reinterpret_cast<float *>(smem) + (wave & 3) * RSZ;
+    for (int half = 0; half < 2; ++half) {
+        if ((wave >> 2) == half) {
 #pragma unroll
             for (int i = 0; i < TMN; ++i) {
                 float old[TKN][4];
 #pragma unroll
                 for (int j = 0; j < TKN; ++j)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) old[j][r] = w == 0 ? 0.f : red[(i * 16 + 4 * g + r) * KB + j * 16 + cq];
+                    for (int r = 0; r < 4; ++r) old[j][r] = half == 0 ? 0.f : red[(i * 16 + 4 * g + r) * KB + j * 16 + cq];
 #pragma unroll
                 for (int j = 0; j < TKN; ++j)
 #pragma unroll
@@ -123,21 +123,25 @@ __global__ __launch_bounds__(NT) void wgrad_small_kernel(const WsmArgs a) {
                 if (do_bias && cq == 0) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        float *dst = redb + i * 16 + 4 * g + r;
-                        *dst = w == 0 ? accb[i][r] : *dst + accb[i][r];
+                        float *dst = red + NB * KB + i * 16 + 4 * g + r;
+                        *dst = half == 0 ? accb[i][r] : *dst + accb[i][r];
                     }
                 }
             }
         }
         __syncthreads();
     }
+    const float *r0 = reinterpret_cast<const float *>(smem);
     float *out = a.slabs + (int64_t)blockIdx.x * a.N * a.K;
     for (int i = tid; i < NB * KB; i += NT) {
         const int n = i / KB, k = i - n * KB;
-        out[(int64_t)(n0 + n) * a.K + k] = red[i];
+        out[(int64_t)(n0 + n) * a.K + k] = ((r0[i] + r0[RSZ + i]) + r0[2 * RSZ + i]) + r0[3 * RSZ + i];
     }
     if (do_bias)
-        for (int i = tid; i < NB; i += NT) a.bias_slabs[(int64_t)blockIdx.x * a.N + n0 + i] = redb[i];
+        for (int i = tid; i < NB; i += NT) {
+            const int o = NB * KB + i;
+            a.bias_slabs[(int64_t)blockIdx.x * a.N + n0 + i] = ((r0[o] + r0[RSZ + o]) + r0[2 * RSZ + o]) + r0[3 * RSZ + o];
+        }
 }
 
 constexpr int SLAB_PARTS = 256;           // one resident workgroup per CU
@@ -145,7 +149,7 @@ constexpr int SLAB_PARTS = 256;           // one resident workgroup per CU
 template <int NB, int KB>
 int launch_t(const WsmArgs &a, int nsplit, int *parts, hipStream_t s) {
     constexpr int WAVE_LDS = (CH * img_ld<NB>() + CH * img_ld<KB>()) * 2;
-    const size_t bytes = std::max((size_t)NWV * WAVE_LDS, (size_t)NB * KB * 4 + (size_t)NB * 4);
+    const size_t bytes = std::max((size_t)NWV * WAVE_LDS, (size_t)4 * (NB * KB + NB) * 4);
     auto kern = wgrad_small_kernel<NB, KB>;
     MIVIT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     const int nchunks = ceil_div(a.M, CH);
