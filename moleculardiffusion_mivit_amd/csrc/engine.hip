@@ -4,6 +4,7 @@
 // the kernels in gemm.hip / norm.hip / attention.hip / misc.hip.  The engine owns no device memory: the caller
 // passes the parameter arena, the gradient arena and one workspace whose layout is computed here.
 #include "common.h"
+#include <atomic>
 #include <algorithm>
 
 #include <string>
@@ -28,6 +29,7 @@ struct mivit_plan {
     std::vector<LayerParams> layers;
     int64_t reg, pos, n0_w, n0_b, emb_w, emb_b;
     int head_in;
+    uint64_t uid;       // unique per created plan: hipGraph keys use it, never the pointer (a freed plan's address can be reused)
 };
 
 namespace {
@@ -267,6 +269,8 @@ extern "C" mivit_plan *mivit_plan_create(const mivit_config *cfg) {
     PLAN_CHECK(c.head_hidden > 0 && c.output_dim > 0, "plan_create: bad head dims");
 #undef PLAN_CHECK
     mivit_plan *p = new mivit_plan();
+    static std::atomic<uint64_t> next_uid{1};
+    p->uid = next_uid.fetch_add(1);
     p->c = c;
     p->arena = 0;
     const int E = c.embed_dim, F = c.hidden_dim;
@@ -633,7 +637,7 @@ extern "C" int mivit_forward(const mivit_plan *plan, const float *params, const 
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (!graph_sized(plan, B, T))
         return forward_impl(plan, params, x, features, B, T, workspace, workspace_bytes, need_backward, out, s);
-    const uint64_t key[] = {1, (uint64_t)plan, (uint64_t)params, (uint64_t)x, (uint64_t)features, (uint64_t)B, (uint64_t)T,
+    const uint64_t key[] = {1, plan->uid, (uint64_t)params, (uint64_t)x, (uint64_t)features, (uint64_t)B, (uint64_t)T,
                             (uint64_t)workspace, (uint64_t)workspace_bytes, (uint64_t)need_backward, (uint64_t)out};
     return graph_run(key, (int)(sizeof(key) / sizeof(key[0])), s, [&](hipStream_t cs) {
         return forward_impl(plan, params, x, features, B, T, workspace, workspace_bytes, need_backward, out, cs);
@@ -647,7 +651,7 @@ extern "C" int mivit_backward(const mivit_plan *plan, const float *params, const
     if (!graph_sized(plan, B, T))
         return backward_impl(plan, params, x, features, B, T, workspace, workspace_bytes, dout, grads, dfeatures, dx_tokens,
                              stage_begin, stage_end, s);
-    const uint64_t key[] = {2, (uint64_t)plan, (uint64_t)params, (uint64_t)x, (uint64_t)features, (uint64_t)B, (uint64_t)T,
+    const uint64_t key[] = {2, plan->uid, (uint64_t)params, (uint64_t)x, (uint64_t)features, (uint64_t)B, (uint64_t)T,
                             (uint64_t)workspace, (uint64_t)workspace_bytes, (uint64_t)dout, (uint64_t)grads,
                             (uint64_t)dfeatures, (uint64_t)dx_tokens, (uint64_t)stage_begin, (uint64_t)stage_end};
     return graph_run(key, (int)(sizeof(key) / sizeof(key[0])), s, [&](hipStream_t cs) {

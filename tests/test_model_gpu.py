@@ -467,3 +467,22 @@ def test_maximum_sequence_length_with_positional_table():
     gscale = max(float(g.norm()) for g in t_g.values())
     for k, g in t_g.items():
         assert float((grads[k].cpu() - g).norm()) < 0.3 * (float(g.norm()) + 1e-2 * gscale), k   # small batch, bf16 ReLU flips
+
+
+def test_hipgraph_not_replayed_across_plans():
+    """A re-created plan (set_precision) must never replay a graph captured for the old one, even when the allocator hands
+    back the same addresses: graph keys carry a per-plan unique id, not the plan pointer."""
+    cfg = orc.MiViTConfig(embedding="linear", patch_size=9, embed_dim=64, num_heads=4, hidden_dim=128, num_layers=2)
+    params = orc.random_params(cfg, seed=4)
+    x = torch.rand(4, 10, 9, 9, device="cuda")
+    m = build_product_model(cfg, "fp32", params).eval()
+    with torch.no_grad():
+        for _ in range(3):
+            o32 = m(x).clone()
+        for prec in ("bf16", "fp32", "bf16"):
+            m.set_precision(prec)
+            for _ in range(3):
+                o = m(x).clone()
+            ref = build_product_model(cfg, prec, params).eval()(x)
+            assert torch.equal(o, ref), prec
+    assert float((o32 - ref).abs().max()) < 5e-2
