@@ -14,10 +14,10 @@
 //    for the probabilities).
 // Everything else (fp32 mode, long sequences, wide heads) uses the general kernels in attention.hip.
 #include "common.h"
+#include "stream_prims.h"
 
 namespace {
 
-typedef __attribute__((ext_vector_type(4))) short s16x4;
 
 struct U128 {
     uint32_t w[4];
@@ -56,9 +56,6 @@ __device__ __forceinline__ bf16x8 pack_frag(const f32x4 a, const f32x4 b) {
     return f;
 }
 
-__device__ __forceinline__ f32x4 mma(bf16x8 a, bf16x8 b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
-}
 
 __device__ __forceinline__ float g16_max(float v) {
 #pragma unroll

@@ -15,6 +15,7 @@
 // ds_read_tr16_b64 (bf16) / scalar reads (fp32); partial sums per workgroup go to a slab that is reduced
 // deterministically (no atomics anywhere).
 #include "common.h"
+#include "stream_prims.h"
 #include <algorithm>
 #include <vector>
 
@@ -521,14 +522,6 @@ struct WgradArgs {
     float *slab;     // [gridDim.x][COUT][TAPS][CIN]
 };
 
-typedef __attribute__((ext_vector_type(4))) short s16x4;
-__device__ __forceinline__ bf16x8 tr_pair(const bf16 *lo, const bf16 *hi) {
-    typedef __attribute__((address_space(3))) s16x4 lds_v4;
-    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4 *)(lo));
-    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4 *)(hi));
-    struct { s16x4 a, b; } pr = {a, b};
-    return __builtin_bit_cast(bf16x8, pr);
-}
 
 // grid (G, CSPLIT): a workgroup walks frame groups blockIdx.x, +G, ... holding ALL taps of its c_out window
 // (COUT / CSPLIT channels) x all c_in in accumulators, so every activation is read once per c_out window.

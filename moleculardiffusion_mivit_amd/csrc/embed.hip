@@ -13,34 +13,18 @@
 //    with 8 scalar reads per fragment (no 32-bit transposing read exists).
 // Shapes outside the constraints below fall back to the general register-staged GEMM (gemm.hip).
 #include "common.h"
+#include "stream_prims.h"
 #include <stdlib.h>
 
 namespace {
 
-typedef __attribute__((ext_vector_type(4))) short s16x4;
-typedef __attribute__((address_space(1))) const void gptr_t;
-typedef __attribute__((address_space(3))) void lptr_t;
 
-__device__ __forceinline__ void dma16(const void *g, void *l) {
-    __builtin_amdgcn_global_load_lds((gptr_t *)g, (lptr_t *)l, 16, 0, 0);
-}
-template <int N>
-__device__ __forceinline__ void wait_vm() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-__device__ __forceinline__ void barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-}
 
 __device__ __forceinline__ bf16x8 cvt8(const float4 a, const float4 b) {
     bf16x8 f;
     f[0] = (__bf16)a.x; f[1] = (__bf16)a.y; f[2] = (__bf16)a.z; f[3] = (__bf16)a.w;
     f[4] = (__bf16)b.x; f[5] = (__bf16)b.y; f[6] = (__bf16)b.z; f[7] = (__bf16)b.w;
     return f;
-}
-__device__ __forceinline__ f32x4 mma(bf16x8 a, bf16x8 b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
 constexpr int NSLOT = 3;

@@ -1,0 +1,39 @@
+// Device primitives shared by the streaming kernels (embed, rowstream, wavestream, gemm_dma, wgrad_dma, wgrad_small,
+// deepresnet_train, attention_fast): LDS-DMA issue, counted vmcnt waits, raw barrier, bf16 MFMA, transposed LDS reads.
+#pragma once
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+// global -> LDS, 16 bytes per lane: the LDS destination is wave-uniform base + lane * 16, the source address is per lane
+__device__ __forceinline__ void dma16(const void *g, void *l) {
+    typedef __attribute__((address_space(1))) const void gptr_t;
+    typedef __attribute__((address_space(3))) void lptr_t;
+    __builtin_amdgcn_global_load_lds((gptr_t *)g, (lptr_t *)l, 16, 0, 0);
+}
+// vector-memory operations retire in order: N = how many of this wave's youngest may still be in flight
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// workgroup barrier without the compiler's blanket vmcnt(0): LDS traffic drained, DMA left in flight
+__device__ __forceinline__ void barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+// ordering of one wave's own LDS writes before its cross-lane reads (wave-private scratch)
+__device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+__device__ __forceinline__ f32x4 mma(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+// MFMA operand whose k index runs over ROWS of a natural [row][col] bf16 LDS image: each lane passes the address of
+// (row base + q, column base + 4p) for the low and the high half of its 8 k slots (q = (lane & 15) >> 2, p = lane & 3)
+// and receives column base + (lane & 15) of those rows (ds_read_b64_tr_b16)
+__device__ __forceinline__ bf16x8 tr_pair(const bf16 *lo, const bf16 *hi) {
+    typedef __attribute__((address_space(3))) s16x4 lds_v4;
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4 *)(lo));
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4 *)(hi));
+    struct { s16x4 a, b; } pr = {a, b};
+    return __builtin_bit_cast(bf16x8, pr);
+}

@@ -10,16 +10,12 @@
 //     so waves never wait for each other: no ring, no barrier, no DMA bookkeeping on the streaming path;
 //   * dgrad reads the natural [n][k] weight image with ds_read_b64_tr_b16.
 #include "common.h"
+#include "stream_prims.h"
 #include <stdlib.h>
 
 namespace {
 
-typedef __attribute__((ext_vector_type(4))) short s16x4;
 
-__device__ __forceinline__ f32x4 mma(bf16x8 a, bf16x8 b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
-}
-__device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 struct WsArgs {
     const bf16 *A; int64_t lda;
@@ -49,13 +45,6 @@ struct WsCfg {
     static_assert(LDS <= 160 * 1024, "LDS budget");
 };
 
-__device__ __forceinline__ bf16x8 tr_pair(const bf16 *lo, const bf16 *hi) {
-    typedef __attribute__((address_space(3))) s16x4 lds_v4;
-    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4 *)(lo));
-    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4 *)(hi));
-    struct { s16x4 a, b; } pr = {a, b};
-    return __builtin_bit_cast(bf16x8, pr);
-}
 
 // E_KIND: 0 none, 1 residual add (forward), 2 activation-derivative multiply (dgrad), 3 residual add of a gradient
 template <int K, int BN, bool DGRAD, bool LN, int E_KIND>

@@ -3,28 +3,12 @@
 // brought in by LDS-DMA into a ring, the contraction over rows m uses ds_read_b64_tr_b16 for BOTH fragments, the
 // reduction is split over row ranges into fp32 slabs that slab_reduce sums in a fixed order (deterministic).
 #include "common.h"
+#include "stream_prims.h"
 #include <stdlib.h>
 
 namespace {
 
-typedef __attribute__((ext_vector_type(4))) short s16x4;
-typedef __attribute__((address_space(1))) const void gptr_t;
-typedef __attribute__((address_space(3))) void lptr_t;
 
-__device__ __forceinline__ void dma16(const void *g, void *l) {
-    __builtin_amdgcn_global_load_lds((gptr_t *)g, (lptr_t *)l, 16, 0, 0);
-}
-template <int N>
-__device__ __forceinline__ void wait_vm() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-__device__ __forceinline__ void barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-}
-__device__ __forceinline__ f32x4 mma(bf16x8 a, bf16x8 b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
-}
 
 struct WgArgs {
     const bf16 *dY; int64_t lddy; const bf16 *X; int64_t ldx; float *slabs;

@@ -5,25 +5,14 @@
 // waves of a workgroup are summed through LDS in a fixed order at the end, workgroups through a slab + slab_reduce
 // (deterministic).  Wide layers use wgrad_dma.hip (128 x 128 tiles).
 #include "common.h"
+#include "stream_prims.h"
 #include <stdlib.h>
 #include <algorithm>
 
 namespace {
 
-typedef __attribute__((ext_vector_type(4))) short s16x4;
 constexpr int NWV = 8, NT = NWV * 64, CH = 32;        // waves per workgroup, rows per chunk (one 32-deep MFMA k step)
 
-__device__ __forceinline__ f32x4 mma(bf16x8 a, bf16x8 b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
-}
-__device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-__device__ __forceinline__ bf16x8 tr_pair(const bf16 *lo, const bf16 *hi) {
-    typedef __attribute__((address_space(3))) s16x4 lds_v4;
-    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4 *)(lo));
-    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4 *)(hi));
-    struct { s16x4 a, b; } pr = {a, b};
-    return __builtin_bit_cast(bf16x8, pr);
-}
 
 struct WsmArgs {
     const bf16 *dY; int64_t lddy; const bf16 *X; int64_t ldx;
