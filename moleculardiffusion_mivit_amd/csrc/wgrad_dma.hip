@@ -14,6 +14,7 @@ struct WgArgs {
     const bf16 *dY; int64_t lddy; const bf16 *X; int64_t ldx; float *slabs;
     int M, N, K, rows_per_split;
     float *bias_part;      // optional [splits][N]: column sums of dY (bias gradient), taken from the LDS image
+    int xcd_remap;
 };
 
 constexpr int BMR = 64, TILE = 128, NS = 3, IMG = BMR * TILE * 2, STAGE = 2 * IMG;   // 16 KiB per image
@@ -64,8 +65,19 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgArgs a) {
     constexpr int TM = 4, TN = 4, D = NS - 1, PER_STAGE = 2 * DMA_PER_WAVE;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int k0 = blockIdx.x * TILE, n0 = blockIdx.y * TILE;
-    const int mb = blockIdx.z * a.rows_per_split, me = min(a.M, mb + a.rows_per_split);
+    // XCD-aware placement (workgroups are dealt round-robin over the 8 XCDs in dispatch order, x fastest): the T output
+    // tiles of one row split read the same dY / X rows, so within 8 * T consecutive workgroups XCD k hosts all tiles of
+    // split 8 * group + k
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    {
+        const int T = gridDim.x * gridDim.y, lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, G = 8 * T;
+        if (a.xcd_remap && T > 1 && lin < (int)(T * gridDim.z) / G * G) {
+            const int t = (lin % G) / 8;
+            bz = (lin / G) * 8 + lin % 8; bx = t % gridDim.x; by = t / gridDim.x;
+        }
+    }
+    const int k0 = bx * TILE, n0 = by * TILE;
+    const int mb = bz * a.rows_per_split, me = min(a.M, mb + a.rows_per_split);
     const int nst = (me - mb + BMR - 1) / BMR;
     const int g = lane >> 4, cq = lane & 15, q = cq >> 2, p = cq & 3;
 
@@ -74,7 +86,7 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgArgs a) {
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const bool do_bias = a.bias_part != nullptr && blockIdx.x == 0;      // one k-tile column of blocks sums dY
+    const bool do_bias = a.bias_part != nullptr && bx == 0;      // one k-tile column of blocks sums dY
     float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
 #pragma unroll
@@ -130,10 +142,10 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgArgs a) {
             float t = 0.f;
 #pragma unroll
             for (int y = 0; y < 16; ++y) t += red[y * 128 + tid];
-            a.bias_part[(int64_t)blockIdx.z * a.N + n0 + tid] = t;
+            a.bias_part[(int64_t)bz * a.N + n0 + tid] = t;
         }
     }
-    float *out = a.slabs + (int64_t)blockIdx.z * a.N * a.K;
+    float *out = a.slabs + (int64_t)bz * a.N * a.K;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -173,8 +185,9 @@ int launch_wgrad_dma(const void *dy, int64_t lddy, const void *x, int64_t ldx, i
     rps = (rps + BMR - 1) / BMR * BMR;
     const int nz = ceil_div(M, rps);
     float *bias_part = db ? static_cast<float *>(ws) + (size_t)nz * N * K : nullptr;
+    static const int remap = getenv("MIVIT_XCD_REMAP") ? atoi(getenv("MIVIT_XCD_REMAP")) : 1;
     WgArgs a = {static_cast<const bf16 *>(dy), lddy, static_cast<const bf16 *>(x), ldx, static_cast<float *>(ws), M, N, K, rps,
-                bias_part};
+                bias_part, remap};
     const size_t bytes = (size_t)NS * STAGE;
     MIVIT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wgrad_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     {
