@@ -288,6 +288,7 @@ struct WgCfg {
 struct EmbWgArgs {
     const bf16 *dY; const float *X; float *slabs;
     int M, K, E, rows_per_split;
+    int xcd_remap;
 };
 
 template <int BKC, int NS>
@@ -322,8 +323,18 @@ __global__ __launch_bounds__(2 * (BKC / 64) * 64) void embed_wgrad_dma(const Emb
     constexpr int WN = BKC / 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int k0 = blockIdx.x * BKC, e0 = blockIdx.y * C::BE;
-    const int mb = blockIdx.z * a.rows_per_split, me = min(a.M, mb + a.rows_per_split);
+    // XCD-aware placement: the K / BKC column tiles of one row split all re-read the same d_emb rows; within 8 * T consecutive
+    // workgroups (dispatch order, x fastest, dealt round-robin over the 8 XCDs) XCD k hosts all T tiles of split 8 * group + k
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    {
+        const int T = gridDim.x * gridDim.y, lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, G = 8 * T;
+        if (a.xcd_remap && T > 1 && lin < (int)(T * gridDim.z) / G * G) {
+            const int t = (lin % G) / 8;
+            bz = (lin / G) * 8 + lin % 8; bx = t % gridDim.x; by = t / gridDim.x;
+        }
+    }
+    const int k0 = bx * BKC, e0 = by * C::BE;
+    const int mb = bz * a.rows_per_split, me = min(a.M, mb + a.rows_per_split);
     const int nst = (me - mb + C::BMR - 1) / C::BMR;
     const int g = lane >> 4, cq = lane & 15, q = cq >> 2, p = cq & 3;
 
@@ -388,7 +399,7 @@ __global__ __launch_bounds__(2 * (BKC / 64) * 64) void embed_wgrad_dma(const Emb
         }
     }
     // slab[z][e][k] fp32 straight from the accumulator layout (column = k, rows = e)
-    float *out = a.slabs + (int64_t)blockIdx.z * a.E * a.K;
+    float *out = a.slabs + (int64_t)bz * a.E * a.K;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -473,7 +484,8 @@ int launch_embed_wgrad_dma(const void *dY_bf16, const float *X, float *dW, int M
     int rps = ceil_div(M, splits);
     rps = (rps + 63) / 64 * 64;
     const int nz = ceil_div(M, rps);
-    EmbWgArgs a = {static_cast<const bf16 *>(dY_bf16), X, static_cast<float *>(ws), M, K, E, rps};
+    static const int remap = getenv("MIVIT_XCD_REMAP") ? atoi(getenv("MIVIT_XCD_REMAP")) : 1;
+    EmbWgArgs a = {static_cast<const bf16 *>(dY_bf16), X, static_cast<float *>(ws), M, K, E, rps, remap};
     const int rc = wg_wide(K) ? wg_dma_launch<256, 2>(a, nz, s) : wg_dma_launch<128, 3>(a, nz, s);
     if (rc) return rc;
     return launch_slab_reduce(static_cast<const float *>(ws), nz, (int64_t)E * K, dW, 0, s);
