@@ -54,7 +54,13 @@ __global__ __launch_bounds__((K == 64 ? 16 : (K == 128 ? 12 : 8)) * 64) void wav
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int KS = C::KS, PF = C::PF, NT = C::NWV * 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, cq = lane & 15, q = cq >> 2, p = cq & 3;
-    const int n0 = blockIdx.x * BN;
+    // XCD-aware placement (see rowstream.hip): the column slices of one row walker on the same XCD
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (gridDim.x > 1) {
+        const int lin = blockIdx.y * gridDim.x + blockIdx.x, G = 8 * gridDim.x;
+        if (lin < (int)(gridDim.x * gridDim.y) / G * G) { bx = (lin % G) / 8; by = (lin / G) * 8 + lin % 8; }
+    }
+    const int n0 = bx * BN;
     bf16 *Wimg = reinterpret_cast<bf16 *>(smem);
     float *Cs = reinterpret_cast<float *>(smem + C::W_BYTES) + wave * 16 * LDC;
 
@@ -73,7 +79,7 @@ __global__ __launch_bounds__((K == 64 ? 16 : (K == 128 ? 12 : 8)) * 64) void wav
     __syncthreads();
 
     const int ntiles = (a.M + 15) / 16, stride = gridDim.y * C::NWV;
-    int tile = blockIdx.y * C::NWV + wave;
+    int tile = by * C::NWV + wave;
     const bf16 *E = E_KIND == 2 ? a.dact : a.resid;
     const int64_t lde = E_KIND == 2 ? a.ldd : a.ldr;
 
