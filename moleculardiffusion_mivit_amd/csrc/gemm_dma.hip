@@ -30,6 +30,7 @@ struct GdArgs {
     const bf16 *aux2; int64_t ldaux2;  // dgrad: gradient arriving through the residual branch
     bf16 *C; int64_t ldc;
     bf16 *C2;                          // forward: optional pre-activation copy (same ld as C)
+    int xcd_remap;
 };
 
 template <int BMW, int BK, int NS>
@@ -97,8 +98,16 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GdArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int TM = BMW / 16, TN = 8, D = NS - 1;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, cq = lane & 15, q = cq >> 2, p = cq & 3;
-    // consecutive workgroups walk down M for one 128-column block (they share the W tile through L2)
-    const int m0 = blockIdx.x * C::BM, n0 = blockIdx.y * C::BN;
+    // XCD-aware placement: all column blocks of one row tile run on the SAME XCD, back to back (the A tile is fetched into
+    // that L2 once instead of once per column block; the W column blocks, 128 KB each at K = 512, stay L2-resident).
+    // Dispatch order is blockIdx.x fastest, dealt round-robin over the 8 XCDs.
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (a.xcd_remap && gridDim.y > 1) {
+        const int T = gridDim.y, gx = gridDim.x, lin = blockIdx.y * gx + blockIdx.x, G = 8 * T, ngrp = gx / 8;
+        if (lin < ngrp * G) { by = (lin % G) / 8; bx = (lin / G) * 8 + lin % 8; }
+        else { const int idx = lin - ngrp * G, rem = gx - 8 * ngrp; bx = 8 * ngrp + idx % rem; by = idx / rem; }
+    }
+    const int m0 = bx * C::BM, n0 = by * C::BN;
     const int nst = a.KC / BK;
 
     f32x4 acc[TM][TN];
@@ -206,7 +215,9 @@ int launch_t(const GdArgs &a, hipStream_t s) {
 
 // tile variants, selectable for the sizing sweep: MIVIT_GEMM_DMA_VARIANT = 0 (default) .. 4
 template <bool DGRAD>
-int launch_variant(const GdArgs &a, hipStream_t s) {
+int launch_variant(GdArgs a, hipStream_t s) {
+    static const int remap = getenv("MIVIT_XCD_REMAP") ? atoi(getenv("MIVIT_XCD_REMAP")) : 1;
+    a.xcd_remap = remap;
     static const int variant = getenv("MIVIT_GEMM_DMA_VARIANT") ? atoi(getenv("MIVIT_GEMM_DMA_VARIANT")) : 0;
     switch (variant) {
         case 1: return launch_t<64, 32, 3, DGRAD>(a, s);     // 256 x 128 tile, 72 KB ring: 1 wave / SIMD (268 registers)
