@@ -17,7 +17,7 @@ struct WgArgs {
     int xcd_remap;
 };
 
-constexpr int BMR = 64, TILE = 128, NS = 3, IMG = BMR * TILE * 2, STAGE = 2 * IMG;   // 16 KiB per image
+constexpr int BMR = 64, TILE = 128, IMG = BMR * TILE * 2, STAGE = 2 * IMG;   // 16 KiB per image; NS ring slots
 constexpr int DMA_PER_WAVE = IMG / 1024 / 4;                                           // per image per wave (4)
 
 // natural [64 rows m][128 cols] bf16 image, 256-byte rows; chunk c of row r lands in slot c ^ (2 * (r & 7))
@@ -60,6 +60,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char *img, int mr, int 
     return __builtin_bit_cast(bf16x8, pr);
 }
 
+template <int NS>
 __global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int TM = 4, TN = 4, D = NS - 1, PER_STAGE = 2 * DMA_PER_WAVE;
@@ -188,11 +189,16 @@ int launch_wgrad_dma(const void *dy, int64_t lddy, const void *x, int64_t ldx, i
     static const int remap = getenv("MIVIT_XCD_REMAP") ? atoi(getenv("MIVIT_XCD_REMAP")) : 1;
     WgArgs a = {static_cast<const bf16 *>(dy), lddy, static_cast<const bf16 *>(x), ldx, static_cast<float *>(ws), M, N, K, rps,
                 bias_part, remap};
-    const size_t bytes = (size_t)NS * STAGE;
-    MIVIT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wgrad_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    // narrow layers are HBM-bound: 3 ring slots (96 KB, one workgroup per CU, two stages in flight).  Wide layers are
+    // MFMA/LDS-bound and want waves: 2 slots (64 KB, two workgroups per CU).
+    static const int force_ns = getenv("MIVIT_WGRAD_DMA_NS") ? atoi(getenv("MIVIT_WGRAD_DMA_NS")) : 0;
+    const int ns = force_ns ? force_ns : (((long)N * K >= 512L * 512L) ? 2 : 3);
+    const size_t bytes = (size_t)ns * STAGE;
+    auto kern = ns == 2 ? wgrad_dma_kernel<2> : wgrad_dma_kernel<3>;
+    MIVIT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     {
         ProfScope prof(s);
-        hipLaunchKernelGGL(wgrad_dma_kernel, dim3(K / TILE, N / TILE, nz), dim3(256), bytes, s, a);
+        hipLaunchKernelGGL(kern, dim3(K / TILE, N / TILE, nz), dim3(256), bytes, s, a);
         MIVIT_LAUNCH_CHECK();
     }
     int rc = launch_slab_reduce(static_cast<const float *>(ws), nz, (int64_t)N * K, dW, 0, s);

@@ -256,7 +256,8 @@ def test_rowstream_dgrad_exact(M, N, K, variant, family):
     assert torch.equal(dx.float().cpu(), ref.float().bfloat16().float())
 
 
-@pytest.mark.parametrize("M,N,K", [(264, 128, 128), (1000, 384, 128), (4130, 128, 256), (70000, 256, 128)])
+@pytest.mark.parametrize("M,N,K", [(264, 128, 128), (1000, 384, 128), (4130, 128, 256), (70000, 256, 128),
+                                   (900, 512, 512), (2100, 1536, 512)])      # wide layers: two ring slots, two workgroups / CU
 def test_wgrad_dma_exact(M, N, K):
     import ctypes
     from moleculardiffusion_mivit_amd import _native as N_
