@@ -17,12 +17,14 @@ struct WgArgs {
     int xcd_remap;
 };
 
-constexpr int BMR = 64, TILE = 128, IMG = BMR * TILE * 2, STAGE = 2 * IMG;   // 16 KiB per image; NS ring slots
-constexpr int DMA_PER_WAVE = IMG / 1024 / 4;                                           // per image per wave (4)
+constexpr int TILE = 128;        // output tile; BMR reduction rows per stage, NS ring slots are template parameters
+constexpr int BMR_MAX = 64;
 
-// natural [64 rows m][128 cols] bf16 image, 256-byte rows; chunk c of row r lands in slot c ^ (2 * (r & 7))
+// natural [BMR rows m][128 cols] bf16 image, 256-byte rows; chunk c of row r lands in slot c ^ (2 * (r & 7))
+template <int BMR>
 __device__ __forceinline__ void issue_img(const bf16 *src, int64_t ld, int col0, int mrow, int mend, unsigned char *img,
                                           int wave, int lane) {
+    constexpr int DMA_PER_WAVE = BMR * TILE * 2 / 1024 / 4;
 #pragma unroll
     for (int i = 0; i < DMA_PER_WAVE; ++i) {
         const int inst = wave * DMA_PER_WAVE + i;
@@ -60,9 +62,10 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char *img, int mr, int 
     return __builtin_bit_cast(bf16x8, pr);
 }
 
-template <int NS>
+template <int NS, int BMR>
 __global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int IMG = BMR * TILE * 2, STAGE = 2 * IMG, DMA_PER_WAVE = IMG / 1024 / 4;
     constexpr int TM = 4, TN = 4, D = NS - 1, PER_STAGE = 2 * DMA_PER_WAVE;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -93,8 +96,8 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgArgs a) {
 #pragma unroll
     for (int s = 0; s < D; ++s)
         if (s < nst) {
-            issue_img(a.dY, a.lddy, n0, mb + s * BMR, me, smem + s * STAGE, wave, lane);
-            issue_img(a.X, a.ldx, k0, mb + s * BMR, me, smem + s * STAGE + IMG, wave, lane);
+            issue_img<BMR>(a.dY, a.lddy, n0, mb + s * BMR, me, smem + s * STAGE, wave, lane);
+            issue_img<BMR>(a.X, a.ldx, k0, mb + s * BMR, me, smem + s * STAGE + IMG, wave, lane);
         }
     for (int s = 0; s < nst; ++s) {
         if (s + D - 1 < nst) wait_vm<PER_STAGE *(D - 1)>();
@@ -102,15 +105,15 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgArgs a) {
         barrier();
         if (s + D < nst) {
             unsigned char *slot = smem + ((s + D) % NS) * STAGE;
-            issue_img(a.dY, a.lddy, n0, mb + (s + D) * BMR, me, slot, wave, lane);
-            issue_img(a.X, a.ldx, k0, mb + (s + D) * BMR, me, slot + IMG, wave, lane);
+            issue_img<BMR>(a.dY, a.lddy, n0, mb + (s + D) * BMR, me, slot, wave, lane);
+            issue_img<BMR>(a.X, a.ldx, k0, mb + (s + D) * BMR, me, slot + IMG, wave, lane);
         }
         const unsigned char *As = smem + (s % NS) * STAGE, *Bs = As + IMG;
         const int valid = min(BMR, me - (mb + s * BMR));
         if (do_bias) {      // thread = (16-byte chunk tid & 15 = 8 columns, row lane tid >> 4): rows lane, lane + 16, ...
             const int ch = tid & 15;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < BMR / 16; ++i) {
                 const int r = (tid >> 4) + 16 * i;
                 float v[8];
                 load16(reinterpret_cast<const bf16 *>(As + r * 256 + ((ch ^ (2 * (r & 7))) << 4)), v);
@@ -120,7 +123,7 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgArgs a) {
             }
         }
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
+        for (int kk = 0; kk < BMR / 32; ++kk) {
             const int mr = kk * 32 + 8 * g;
             bf16x8 af[TM], bf[TN];
 #pragma unroll
@@ -183,18 +186,26 @@ int launch_wgrad_dma(const void *dy, int64_t lddy, const void *x, int64_t ldx, i
     MIVIT_CHECK(ws_bytes >= wgrad_dma_ws_bytes(M, N, K), "wgrad_dma: workspace too small");
     const int splits = dma_splits(M, N, K);
     int rps = ceil_div(M, splits);
-    rps = (rps + BMR - 1) / BMR * BMR;
+    rps = (rps + BMR_MAX - 1) / BMR_MAX * BMR_MAX;
     const int nz = ceil_div(M, rps);
     float *bias_part = db ? static_cast<float *>(ws) + (size_t)nz * N * K : nullptr;
     static const int remap = getenv("MIVIT_XCD_REMAP") ? atoi(getenv("MIVIT_XCD_REMAP")) : 1;
     WgArgs a = {static_cast<const bf16 *>(dy), lddy, static_cast<const bf16 *>(x), ldx, static_cast<float *>(ws), M, N, K, rps,
                 bias_part, remap};
-    // narrow layers are HBM-bound: 3 ring slots (96 KB, one workgroup per CU, two stages in flight).  Wide layers are
-    // MFMA/LDS-bound and want waves: 2 slots (64 KB, two workgroups per CU).
-    static const int force_ns = getenv("MIVIT_WGRAD_DMA_NS") ? atoi(getenv("MIVIT_WGRAD_DMA_NS")) : 0;
-    const int ns = force_ns ? force_ns : (((long)N * K >= 512L * 512L) ? 2 : 3);
-    const size_t bytes = (size_t)ns * STAGE;
-    auto kern = ns == 2 ? wgrad_dma_kernel<2> : wgrad_dma_kernel<3>;
+    // occupancy beats ring depth on this part, narrow (HBM-bound) and wide (MFMA-bound) layers alike: measured on the
+    // headline shape 3 slots x 64 rows (96 KB, one workgroup = 4 waves per CU) 2.35 ms/step, 2 slots (64 KB, two
+    // workgroups) 1.68 ms.  MIVIT_WGRAD_DMA_CFG = 10 * slots + rows / 32 selects another point.
+    // wide (MFMA-bound) layers prefer 32-row stages (32 KB ring, more workgroups per CU): c4 step 21.15 -> 20.2 ms.
+    static const int forced = getenv("MIVIT_WGRAD_DMA_CFG") ? atoi(getenv("MIVIT_WGRAD_DMA_CFG")) : 0;
+    const int cfg = forced ? forced : ((long)N * K >= 512L * 512L ? 21 : 22);
+    size_t bytes;
+    void (*kern)(const WgArgs);
+    switch (cfg) {
+        case 32: kern = wgrad_dma_kernel<3, 64>; bytes = 3 * 2 * 64 * TILE * 2; break;
+        case 21: kern = wgrad_dma_kernel<2, 32>; bytes = 2 * 2 * 32 * TILE * 2; break;
+        case 31: kern = wgrad_dma_kernel<3, 32>; bytes = 3 * 2 * 32 * TILE * 2; break;
+        default: kern = wgrad_dma_kernel<2, 64>; bytes = 2 * 2 * 64 * TILE * 2; break;
+    }
     MIVIT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     {
         ProfScope prof(s);
