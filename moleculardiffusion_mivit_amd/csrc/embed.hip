@@ -269,9 +269,9 @@ __global__ __launch_bounds__(256) void embed_fwd_direct(const EmbFwdArgs a) {
 // wgrad: tile 128 rows (e) x BKC columns (k of X), stage = 64 reduction rows m of dY (256 B rows) + of X (4*BKC B rows).
 // 2 x BKC/64 waves, each a 64 x 64 sub-tile.  NS ring slots, NS - 1 stages in flight.
 // =================================================================================================================
-template <int BKC, int NS>
+template <int BKC, int NS, int BMR_ = 64>
 struct WgCfg {
-    static constexpr int BE = 128, BMR = 64;
+    static constexpr int BE = 128, BMR = BMR_;
     static constexpr int NW = 2 * (BKC / 64);
     static constexpr int A_BYTES = BMR * BE * 2;         // 16 KiB
     static constexpr int B_ROW = BKC * 4;                // bytes per X row in the tile
@@ -291,10 +291,10 @@ struct EmbWgArgs {
     int xcd_remap;
 };
 
-template <int BKC, int NS>
+template <int BKC, int NS, int BMR>
 __device__ __forceinline__ void wg_issue(const EmbWgArgs &a, unsigned char *slot, int e0, int k0, int mrow, int mend,
                                          int wave, int lane) {
-    using C = WgCfg<BKC, NS>;
+    using C = WgCfg<BKC, NS, BMR>;
 #pragma unroll
     for (int i = 0; i < C::A_DMA; ++i) {              // dY: 4 rows of 256 B per wave-instruction
         const int inst = wave * C::A_DMA + i;
@@ -315,9 +315,9 @@ __device__ __forceinline__ void wg_issue(const EmbWgArgs &a, unsigned char *slot
     }
 }
 
-template <int BKC, int NS>
-__global__ __launch_bounds__(2 * (BKC / 64) * 64) void embed_wgrad_dma(const EmbWgArgs a) {
-    using C = WgCfg<BKC, NS>;
+template <int BKC, int NS, int BMR>
+__global__ __launch_bounds__(2 * (BKC / 64) * 64, BMR == 32 ? 4 : 1) void embed_wgrad_dma(const EmbWgArgs a) {
+    using C = WgCfg<BKC, NS, BMR>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int TM = 4, TN = 4, D = NS - 1;
     constexpr int WN = BKC / 64;
@@ -346,16 +346,16 @@ __global__ __launch_bounds__(2 * (BKC / 64) * 64) void embed_wgrad_dma(const Emb
 
 #pragma unroll
     for (int s = 0; s < D; ++s)
-        if (s < nst) wg_issue<BKC, NS>(a, smem + s * C::STAGE, e0, k0, mb + s * C::BMR, me, wave, lane);
+        if (s < nst) wg_issue<BKC, NS, BMR>(a, smem + s * C::STAGE, e0, k0, mb + s * C::BMR, me, wave, lane);
     for (int s = 0; s < nst; ++s) {
         if (s + D - 1 < nst) wait_vm<C::PER_STAGE * (D - 1)>();
         else wait_vm<0>();
         barrier();
-        if (s + D < nst) wg_issue<BKC, NS>(a, smem + ((s + D) % NS) * C::STAGE, e0, k0, mb + (s + D) * C::BMR, me, wave, lane);
+        if (s + D < nst) wg_issue<BKC, NS, BMR>(a, smem + ((s + D) % NS) * C::STAGE, e0, k0, mb + (s + D) * C::BMR, me, wave, lane);
         const unsigned char *As = smem + (s % NS) * C::STAGE, *Bs = As + C::A_BYTES;
         const int valid = min(C::BMR, me - (mb + s * C::BMR));     // rows of this stage inside the split
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
+        for (int kk = 0; kk < BMR / 32; ++kk) {
             // k slots 0..3 = rows kk*32 + 8g + 0..3, slots 4..7 = rows kk*32 + 8g + 4..7 (both operands)
             const int mr = kk * 32 + 8 * g;
             bf16x8 af[TM], bf[TN];
@@ -418,7 +418,8 @@ bool wg_wide(int K) {
 
 int wg_splits(int M, int K, int E) {
     const long tiles = (long)(K / (wg_wide(K) ? 256 : 128)) * (E / 128 > 0 ? E / 128 : 1);
-    long s = (256 + tiles - 1) / tiles;            // ~1 block per CU (one block owns a CU's LDS)
+    static const int target = getenv("MIVIT_EMBED_WGRAD_BLOCKS") ? atoi(getenv("MIVIT_EMBED_WGRAD_BLOCKS")) : 512;
+    long s = (target + tiles - 1) / tiles;         // two resident workgroups per CU
     const long maxs = (M + 511) / 512;
     if (s > maxs) s = maxs;
     if (s < 1) s = 1;
@@ -463,11 +464,11 @@ int launch_embed_fwd_dma(const float *X, const void *W_bf16, const float *bias, 
 
 size_t embed_wgrad_dma_ws_bytes(int M, int K, int E) { return (size_t)wg_splits(M, K, E) * E * K * sizeof(float); }
 
-template <int BKC, int NS>
+template <int BKC, int NS, int BMR>
 static int wg_dma_launch(EmbWgArgs a, int nz, hipStream_t s) {
-    using C = WgCfg<BKC, NS>;
+    using C = WgCfg<BKC, NS, BMR>;
     const size_t bytes = (size_t)NS * C::STAGE;
-    auto kern = embed_wgrad_dma<BKC, NS>;
+    auto kern = embed_wgrad_dma<BKC, NS, BMR>;
     MIVIT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     ProfScope prof(s);
     hipLaunchKernelGGL(kern, dim3(a.K / BKC, a.E / 128, nz), dim3(C::NW * 64), bytes, s, a);
@@ -486,7 +487,13 @@ int launch_embed_wgrad_dma(const void *dY_bf16, const float *X, float *dW, int M
     const int nz = ceil_div(M, rps);
     static const int remap = getenv("MIVIT_XCD_REMAP") ? atoi(getenv("MIVIT_XCD_REMAP")) : 1;
     EmbWgArgs a = {static_cast<const bf16 *>(dY_bf16), X, static_cast<float *>(ws), M, K, E, rps, remap};
-    const int rc = wg_wide(K) ? wg_dma_launch<256, 2>(a, nz, s) : wg_dma_launch<128, 3>(a, nz, s);
+    // 32-row stages: 80 KB ring and <= 128 registers -> two workgroups (16 waves) per CU; measured 1.67 -> 1.39 ms/step
+    // against the 64-row / 160 KB / one-workgroup point (MIVIT_EMBED_WGRAD_CFG=2 selects that one)
+    static const int variant = getenv("MIVIT_EMBED_WGRAD_CFG") ? atoi(getenv("MIVIT_EMBED_WGRAD_CFG")) : 1;
+    int rc;
+    if (!wg_wide(K)) rc = wg_dma_launch<128, 3, 64>(a, nz, s);
+    else if (variant == 2) rc = wg_dma_launch<256, 2, 64>(a, nz, s);
+    else rc = wg_dma_launch<256, 2, 32>(a, nz, s);
     if (rc) return rc;
     return launch_slab_reduce(static_cast<const float *>(ws), nz, (int64_t)E * K, dW, 0, s);
 }
