@@ -163,69 +163,83 @@ __global__ __launch_bounds__(BM / 64 * 2 * 64) void embed_fwd_dma(const EmbFwdAr
 // lane groups of a row read one contiguous 64-byte run per load instruction:
 //      lane group g holds k = 4g..4g+3 and 16+4g..16+4g+3   (X: two float4 loads; W: two 8-byte LDS reads)
 // =================================================================================================================
+// TMW = 16-row tiles per wave (accumulators 32 * TMW registers), NW waves per workgroup, NS ring slots of the W tile
+template <int TMW, int NW_, int NS_>
 struct DirCfg {
-    static constexpr int BM = 128, BN = 128, BK = 64, NW = 4, NS = 3;
+    static constexpr int NW = NW_, NS = NS_, BM = NW * 16 * TMW, BN = 128, BK = 64;
     static constexpr int B_BYTES = BN * BK * 2;                  // 16 KiB per stage
-    static constexpr int B_DMA = B_BYTES / 1024 / NW;            // 4 wave-instructions per wave per stage
-    static constexpr int A_LD = 8;                               // global loads per wave per stage (2 tiles x 2 kk x 2)
+    static constexpr int B_DMA = B_BYTES / 1024 / NW;            // wave-instructions per wave per stage
+    static constexpr int A_LD = 4 * TMW;                         // global loads per wave per stage (TMW tiles x 2 kk x 2)
+    static_assert(B_DMA * NW * 1024 == B_BYTES, "W stage must split evenly over the waves");
 };
 
+template <int NW>
 __device__ __forceinline__ void dir_issue_b(const EmbFwdArgs &a, unsigned char *slot, int n0, int k0, int wave, int lane) {
+    constexpr int B_DMA = 128 * 64 * 2 / 1024 / NW;
 #pragma unroll
-    for (int i = 0; i < DirCfg::B_DMA; ++i) {
-        const int inst = wave * DirCfg::B_DMA + i;
+    for (int i = 0; i < B_DMA; ++i) {
+        const int inst = wave * B_DMA + i;
         const int n = inst * 8 + (lane >> 3), sl = lane & 7;
         const int c = sl ^ ((n >> 1) & 7);
         dma16(a.W + (int64_t)(n0 + n) * a.K + k0 + c * 8, slot + inst * 1024);
     }
 }
 
-__global__ __launch_bounds__(256) void embed_fwd_direct(const EmbFwdArgs a) {
-    using C = DirCfg;
+template <int TMW, int NW, int NS, int PF = 1>
+__global__ __launch_bounds__(NW * 64) void embed_fwd_direct(const EmbFwdArgs a) {
+    using C = DirCfg<TMW, NW, NS>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int D = NS - 1;                                     // W stages in flight
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, cq = lane & 15;
     const int m0 = blockIdx.y * C::BM, n0 = blockIdx.x * C::BN, nst = a.K / C::BK;
-    const float *ap[2];
+    const float *ap[TMW];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) ap[i] = a.X + (int64_t)min(m0 + wave * 32 + i * 16 + cq, a.M - 1) * a.K + 4 * g;
+    for (int i = 0; i < TMW; ++i) ap[i] = a.X + (int64_t)min(m0 + (wave * TMW + i) * 16 + cq, a.M - 1) * a.K + 4 * g;
 
-    f32x4 acc[2][8];
+    f32x4 acc[TMW][8];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TMW; ++i)
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    float4 nx[2][2][2];                                          // [kk][tile][half] of the NEXT stage
-    auto load_a = [&](int k0) {
+    float4 nx[PF][2][TMW][2];                                    // [stage ahead][kk][tile][half]: PF stages in flight
+    auto load_a = [&](int k0, float4 (&dst)[2][TMW][2]) {
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < TMW; ++i)
 #pragma unroll
-                for (int h = 0; h < 2; ++h) nx[kk][i][h] = *reinterpret_cast<const float4 *>(ap[i] + k0 + 32 * kk + 16 * h);
+                for (int h = 0; h < 2; ++h) dst[kk][i][h] = *reinterpret_cast<const float4 *>(ap[i] + k0 + 32 * kk + 16 * h);
     };
-    dir_issue_b(a, smem, n0, 0, wave, lane);
-    if (nst > 1) dir_issue_b(a, smem + C::B_BYTES, n0, C::BK, wave, lane);
-    load_a(0);
+#pragma unroll
+    for (int s = 0; s < D; ++s)
+        if (s < nst) dir_issue_b<NW>(a, smem + s * C::B_BYTES, n0, s * C::BK, wave, lane);
+#pragma unroll
+    for (int f = 0; f < PF; ++f) load_a(min(f, nst - 1) * C::BK, nx[f]);
     for (int s = 0; s < nst; ++s) {
-        float4 cx[2][2][2];
+        float4 cx[2][TMW][2];
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < TMW; ++i)
 #pragma unroll
-                for (int h = 0; h < 2; ++h) cx[kk][i][h] = nx[kk][i][h];
-        // in program order the outstanding VM ops are ... A(s), B(s+1), [A(s+1)]: wait for A(s) (and everything older)
-        if (s + 1 < nst) { load_a((s + 1) * C::BK); wait_vm<C::B_DMA + C::A_LD>(); }
-        else wait_vm<0>();
+                for (int h = 0; h < 2; ++h) {
+                    cx[kk][i][h] = nx[0][kk][i][h];
+#pragma unroll
+                    for (int f = 0; f + 1 < PF; ++f) nx[f][kk][i][h] = nx[f + 1][kk][i][h];
+                }
+        // program order of this wave's VM ops: ... A(s) ... | A(s + PF): everything up to A(s) and W stage s is done once at
+        // most the PF youngest A stages and the D - 1 youngest W stages are outstanding
+        load_a(min(s + PF, nst - 1) * C::BK, nx[PF - 1]);
+        wait_vm<PF * C::A_LD + (D - 1) * C::B_DMA>();
         barrier();          // every wave's share of W stage s landed; every wave finished reading the slot of stage s-1
-        if (s + 2 < nst) dir_issue_b(a, smem + ((s + 2) % C::NS) * C::B_BYTES, n0, (s + 2) * C::BK, wave, lane);
-        const unsigned char *Bs = smem + (s % C::NS) * C::B_BYTES;
+        if (s + D < nst) dir_issue_b<NW>(a, smem + ((s + D) % NS) * C::B_BYTES, n0, (s + D) * C::BK, wave, lane);
+        const unsigned char *Bs = smem + (s % NS) * C::B_BYTES;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 af[2];
+            bf16x8 af[TMW];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) af[i] = cvt8(cx[kk][i][0], cx[kk][i][1]);
+            for (int i = 0; i < TMW; ++i) af[i] = cvt8(cx[kk][i][0], cx[kk][i][1]);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int n = j * 16 + cq, sw = (n >> 1) & 7;
@@ -233,8 +247,8 @@ __global__ __launch_bounds__(256) void embed_fwd_direct(const EmbFwdArgs a) {
                 const uint2 lo = *reinterpret_cast<const uint2 *>(row + ((4 * kk + (g >> 1)) ^ sw) * 16);
                 const uint2 hi = *reinterpret_cast<const uint2 *>(row + ((4 * kk + 2 + (g >> 1)) ^ sw) * 16);
                 const bf16x8 bf = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
-                acc[0][j] = mma(af[0], bf, acc[0][j]);
-                acc[1][j] = mma(af[1], bf, acc[1][j]);
+#pragma unroll
+                for (int i = 0; i < TMW; ++i) acc[i][j] = mma(af[i], bf, acc[i][j]);
             }
         }
     }
@@ -242,7 +256,7 @@ __global__ __launch_bounds__(256) void embed_fwd_direct(const EmbFwdArgs a) {
     constexpr int LDC = C::BN + 4;
     float *Cs = reinterpret_cast<float *>(smem) + wave * 16 * LDC;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < TMW; ++i) {
         barrier();
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -254,7 +268,7 @@ __global__ __launch_bounds__(256) void embed_fwd_direct(const EmbFwdArgs a) {
         barrier();
         for (int c = lane; c < 16 * (C::BN / 8); c += 64) {
             const int lr = c / (C::BN / 8), lc = (c % (C::BN / 8)) * 8;
-            const int row = m0 + wave * 32 + i * 16 + lr;
+            const int row = m0 + (wave * TMW + i) * 16 + lr;
             if (row < a.M) {
                 float v[8];
                 *reinterpret_cast<float4 *>(v) = *reinterpret_cast<const float4 *>(Cs + lr * LDC + lc);
@@ -263,6 +277,19 @@ __global__ __launch_bounds__(256) void embed_fwd_direct(const EmbFwdArgs a) {
             }
         }
     }
+}
+
+template <int TMW, int NW, int NS, int PF = 1>
+int fwd_direct_launch(const EmbFwdArgs &a, hipStream_t s) {
+    using C = DirCfg<TMW, NW, NS>;
+    const size_t ring = (size_t)NS * C::B_BYTES, scratch = (size_t)NW * 16 * (C::BN + 4) * 4;
+    const size_t bytes = ring > scratch ? ring : scratch;
+    auto kern = embed_fwd_direct<TMW, NW, NS, PF>;
+    MIVIT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    ProfScope prof(s);
+    hipLaunchKernelGGL(kern, dim3(a.E / 128, ceil_div(a.M, C::BM)), dim3(NW * 64), bytes, s, a);
+    MIVIT_LAUNCH_CHECK();
+    return 0;
 }
 
 // =================================================================================================================
@@ -452,13 +479,18 @@ int launch_embed_fwd_dma(const float *X, const void *W_bf16, const float *bias, 
     static const int variant = getenv("MIVIT_EMBED_FWD_VARIANT") ? atoi(getenv("MIVIT_EMBED_FWD_VARIANT")) : 0;
     if (variant == 2) return fwd_dma_launch<128, 3>(a, s);
     if (variant == 1) return fwd_dma_launch<256, 2>(a, s);     // LDS-DMA staging of the frames (first design, kept for A/B runs)
-    {
-        const size_t bytes = (size_t)DirCfg::NS * DirCfg::B_BYTES;
-        MIVIT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(embed_fwd_direct), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-        ProfScope prof(s);
-        hipLaunchKernelGGL(embed_fwd_direct, dim3(a.E / 128, ceil_div(a.M, DirCfg::BM)), dim3(256), bytes, s, a);
-        MIVIT_LAUNCH_CHECK();
-        return 0;
+    switch (variant) {
+        case 3: return fwd_direct_launch<2, 4, 3>(a, s);
+        case 4: return fwd_direct_launch<1, 4, 2>(a, s);
+        case 5: return fwd_direct_launch<1, 8, 3>(a, s);
+        case 6: return fwd_direct_launch<1, 8, 2>(a, s);
+        case 7: return fwd_direct_launch<2, 4, 2>(a, s);
+        case 8: return fwd_direct_launch<1, 4, 3>(a, s);
+        case 9: return fwd_direct_launch<1, 4, 3, 2>(a, s);
+        case 10: return fwd_direct_launch<1, 8, 3, 2>(a, s);
+        case 11: return fwd_direct_launch<2, 4, 3, 2>(a, s);
+        case 12: return fwd_direct_launch<1, 8, 3, 3>(a, s);
+        default: return fwd_direct_launch<2, 4, 3>(a, s);
     }
 }
 
