@@ -163,7 +163,8 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgArgs a) {
 
 int dma_splits(int M, int N, int K) {
     const long tiles = (long)(N / TILE) * (K / TILE);
-    long s = (512 + tiles - 1) / tiles;          // 96 KiB of LDS per block: one resident block per CU, two rounds
+    static const int target = getenv("MIVIT_WGRAD_DMA_BLOCKS") ? atoi(getenv("MIVIT_WGRAD_DMA_BLOCKS")) : 512;
+    long s = (target + tiles - 1) / tiles;       // two resident workgroups per CU, one round
     const long maxs = (M + 511) / 512;
     if (s > maxs) s = maxs;
     return s < 1 ? 1 : (int)s;
