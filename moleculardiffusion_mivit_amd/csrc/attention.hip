@@ -52,6 +52,7 @@ struct AttnDims {
     int ldq;    // row length of [token][d] images
     int ldk;    // row length of [.][token] images
     int per_wave;   // LDS elements per wave
+    int two_pass;   // fp32 backward, long sequences: ONE score image (P for dV first, then recomputed dS in place)
     int nw;     // waves per block
 };
 
@@ -82,6 +83,8 @@ AttnDims make_dims(int B, int S, int H, int Dh, bool backward) {
     const int ps = (d.Sp > d.Skp ? d.Sp : d.Skp) * d.ldk;   // one [token][token] image
     if (!backward) d.per_wave = 3 * nat + (BF ? tr : 0) + ps;                 // Q,K,V (+Vt) + P
     else d.per_wave = 4 * nat + (BF ? 3 * tr : 0) + (BF ? 3 : 2) * ps;        // Q,K,V,dO (+Qt,Kt,dOt) + P/dS images
+    d.two_pass = 0;
+    if (backward && !BF && (size_t)d.per_wave * sizeof(T) > (size_t)160 * 1024) { d.two_pass = 1; d.per_wave = 4 * nat + ps; }
     d.per_wave = (d.per_wave + 7) / 8 * 8;
     const size_t bytes = (size_t)d.per_wave * sizeof(T);
     int nw = (int)((size_t)64 * 1024 / bytes);
@@ -229,55 +232,102 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T *qkv, const T *dc
     const float scale = 1.0f / sqrtf((float)d.Dh);
     const int colq = lane & 15, rowq = (lane >> 4) * 4;
 
-    for (int it = 0; it < NT; ++it) {
-        f32x4 sc[NT], dp[NT];
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            sc[j] = tile_mma<T>(Qi, it * 16, Ki, j * 16, d.Dp, lane);
-            dp[j] = tile_mma<T>(Oi, it * 16, Vi, j * 16, d.Dp, lane);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float m = -INFINITY;
+    // mode 0: write P and dS (two images);  mode 1: write P only;  mode 2: write dS into the P image (two-pass fp32)
+    auto score_pass = [&](const int mode) {
+        for (int it = 0; it < NT; ++it) {
+            f32x4 sc[NT], dp[NT];
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
-                const bool ok = j * 16 + colq < d.S;
-                sc[j][r] = ok ? sc[j][r] * scale : -INFINITY;
-                m = fmaxf(m, sc[j][r]);
+                sc[j] = tile_mma<T>(Qi, it * 16, Ki, j * 16, d.Dp, lane);
+                dp[j] = tile_mma<T>(Oi, it * 16, Vi, j * 16, d.Dp, lane);
             }
-            m = group16_max(m);
-            float sum = 0.f;
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const float e = (j * 16 + colq < d.S) ? __expf(sc[j][r] - m) : 0.f;
-                sc[j][r] = e;
-                sum += e;
-            }
-            sum = group16_sum(sum);
-            const float inv = 1.f / sum;
-            float delta = 0.f;
+            for (int r = 0; r < 4; ++r) {
+                float m = -INFINITY;
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                sc[j][r] *= inv;                       // P
-                delta += sc[j][r] * dp[j][r];
-            }
-            delta = group16_sum(delta);
-            const int row = it * 16 + rowq + r;
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const int key = j * 16 + colq;
-                const float p = sc[j][r];
-                const float ds = scale * p * (dp[j][r] - delta);
-                if (BF) {
-                    Pa[key * d.ldk + row] = from_f32<T>(p);
-                    dSt[key * d.ldk + row] = from_f32<T>(ds);
-                } else {
-                    Pa[row * d.ldk + key] = from_f32<T>(p);
+                for (int j = 0; j < NT; ++j) {
+                    const bool ok = j * 16 + colq < d.S;
+                    sc[j][r] = ok ? sc[j][r] * scale : -INFINITY;
+                    m = fmaxf(m, sc[j][r]);
                 }
-                dSn[row * d.ldk + key] = from_f32<T>(ds);
+                m = group16_max(m);
+                float sum = 0.f;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const float e = (j * 16 + colq < d.S) ? __expf(sc[j][r] - m) : 0.f;
+                    sc[j][r] = e;
+                    sum += e;
+                }
+                sum = group16_sum(sum);
+                const float inv = 1.f / sum;
+                float delta = 0.f;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    sc[j][r] *= inv;                       // P
+                    delta += sc[j][r] * dp[j][r];
+                }
+                delta = group16_sum(delta);
+                const int row = it * 16 + rowq + r;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const int key = j * 16 + colq;
+                    const float p = sc[j][r];
+                    const float ds = scale * p * (dp[j][r] - delta);
+                    if (mode == 0) {
+                        if (BF) {
+                            Pa[key * d.ldk + row] = from_f32<T>(p);
+                            dSt[key * d.ldk + row] = from_f32<T>(ds);
+                        } else {
+                            Pa[row * d.ldk + key] = from_f32<T>(p);
+                        }
+                        dSn[row * d.ldk + key] = from_f32<T>(ds);
+                    } else {
+                        Pa[row * d.ldk + key] = from_f32<T>(mode == 1 ? p : ds);
+                    }
+                }
             }
         }
+    };
+    const bool two_pass = !BF && d.two_pass;
+    T *dst = dqkv + (int64_t)b * d.S * ld3 + h * d.Dh;
+    if (two_pass) {
+        // pass 1: P -> dV = P^T dO
+        score_pass(1);
+        wave_lds_sync();
+        const Img<T> PTi1 = {Pa, 1, d.ldk}, Oti1 = {On, 1, d.ldq};
+        for (int it = 0; it < NT; ++it)
+            for (int jd = 0; jd < d.D16 / 16; ++jd) {
+                const f32x4 dv = tile_mma<T>(PTi1, it * 16, Oti1, jd * 16, d.Skp, lane);
+                const int dcol = jd * 16 + colq;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = it * 16 + rowq + r;
+                    if (row < d.S && dcol < d.Dh) dst[(int64_t)row * ld3 + dcol + 2 * d.E] = from_f32<T>(dv[r]);
+                }
+            }
+        wave_lds_sync();
+        // pass 2: scores recomputed, dS written over the P image -> dQ = dS K, dK = dS^T Q
+        score_pass(2);
+        wave_lds_sync();
+        const Img<T> dSi2 = {Pa, d.ldk, 1}, dSTi2 = {Pa, 1, d.ldk}, Qti2 = {Qn, 1, d.ldq}, Kti2 = {Kn, 1, d.ldq};
+        for (int it = 0; it < NT; ++it)
+            for (int jd = 0; jd < d.D16 / 16; ++jd) {
+                const f32x4 dq = tile_mma<T>(dSi2, it * 16, Kti2, jd * 16, d.Skp, lane);
+                const f32x4 dk = tile_mma<T>(dSTi2, it * 16, Qti2, jd * 16, d.Skp, lane);
+                const int dcol = jd * 16 + colq;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = it * 16 + rowq + r;
+                    if (row < d.S && dcol < d.Dh) {
+                        T *o = dst + (int64_t)row * ld3 + dcol;
+                        o[0] = from_f32<T>(dq[r]);
+                        o[d.E] = from_f32<T>(dk[r]);
+                    }
+                }
+            }
+        return;
     }
+    score_pass(0);
     wave_lds_sync();
 
     // operand views for the three output products
@@ -287,7 +337,6 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T *qkv, const T *dc
     const Img<T> Oti = BF ? Img<T>{Ot, d.ldk, 1} : Img<T>{On, 1, d.ldq};        // [d][row]
     const Img<T> Qti = BF ? Img<T>{Qt, d.ldk, 1} : Img<T>{Qn, 1, d.ldq};        // [d][row]
     const Img<T> Kti = BF ? Img<T>{Kt, d.ldk, 1} : Img<T>{Kn, 1, d.ldq};        // [d][key]
-    T *dst = dqkv + (int64_t)b * d.S * ld3 + h * d.Dh;
     for (int it = 0; it < NT; ++it) {
         for (int jd = 0; jd < d.D16 / 16; ++jd) {
             const f32x4 dq = tile_mma<T>(dSi, it * 16, Kti, jd * 16, d.Skp, lane);

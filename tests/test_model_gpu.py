@@ -454,12 +454,19 @@ def test_fp16_training_with_grad_scaler():
 
 def test_maximum_sequence_length_with_positional_table():
     """The reference's learned positional table holds 128 tokens (models.py:8,120): 127 frames + the regression token is
-    the longest sequence a pos-encoding model accepts.  bf16 runs it on the register-resident attention kernels."""
+    the longest sequence a pos-encoding model accepts, in fp32 (parity) and bf16 (register-resident attention)."""
     cfg = orc.MiViTConfig(embedding="linear", patch_size=9, embed_dim=64, num_heads=2, hidden_dim=128, num_layers=2,
                           use_pos_encoding=True)
     params = orc.closed_form_params(cfg)
     x, labels, _ = orc.closed_form_batch(6, 127, 9, salt=2)
     t_out, t_loss, t_g = orc.loss_and_grads(params, cfg, x, labels, None)
+    # fp32 parity mode: the LDS-resident attention keeps one score image at this length (two-pass backward)
+    m32 = build_product_model(cfg, "fp32", params).train()
+    out32, loss32, grads32 = _run(m32, x.cuda(), labels.cuda(), None)
+    assert rel_err(out32, t_out) < FP32_TOL and abs(float(loss32) - float(t_loss)) / float(t_loss) < FP32_TOL
+    gs = max(float(g.abs().max()) for g in t_g.values())
+    for k, g in t_g.items():
+        assert float((grads32[k].cpu() - g).abs().max()) < FP32_TOL * (float(g.abs().max()) + 1e-3 * gs) * 3, k
     m = build_product_model(cfg, "bf16", params).train()
     out, loss, grads = _run(m, x.cuda(), labels.cuda(), None)
     assert bool(torch.isfinite(out).all()) and all(bool(torch.isfinite(g).all()) for g in grads.values())
