@@ -14,6 +14,7 @@
 //    for the probabilities).
 // Everything else (fp32 mode, long sequences, wide heads) uses the general kernels in attention.hip.
 #include "common.h"
+#include <stdlib.h>
 #include "stream_prims.h"
 
 namespace {
@@ -358,6 +359,197 @@ __global__ __launch_bounds__(256) void attn_bwd_fast(const bf16 *qkv, const bf16
             }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// backward, second version: the token contractions (dV += P^T dO, dK += dS^T Q, dQ += dS K) use the 16-deep MFMA
+// (v_mfma_f32_16x16x16_bf16): the accumulator layout of a 16 x 16 score tile (rows 4g + r) IS the k layout of that
+// instruction's operand (k = 4g + i), so one row tile is consumed at a time -- no pairing of row tiles into 32-deep
+// operands, no P / dS tiles parked across two iterations, no padding work for odd tile counts -- and the Q / dO fragments
+// are fetched per row tile instead of being held for the whole sequence.  Fewer live registers = more waves per SIMD;
+// this kernel is latency-bound (1.8 TB/s of traffic), not bandwidth-bound.
+// ---------------------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) short k16_t;
+__device__ __forceinline__ k16_t pack4(const f32x4 a) {
+    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+    bf16x4 f;
+    f[0] = (__bf16)a[0]; f[1] = (__bf16)a[1]; f[2] = (__bf16)a[2]; f[3] = (__bf16)a[3];
+    return __builtin_bit_cast(k16_t, f);
+}
+// operand with k = tokens t0 + 4g + 0..3 (t0 already includes 4g), lane index = column col0 + (lane & 15)
+__device__ __forceinline__ k16_t tr4(const bf16 *img, int ld, int trow, int col0, int lane) {
+    const int i = lane & 15, q = i >> 2, p = i & 3;
+    typedef __attribute__((address_space(3))) s16x4 lds_v4;
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4 *)(img + (trow + q) * ld + col0 + 4 * p));
+}
+__device__ __forceinline__ f32x4 mma16(k16_t a, k16_t b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+}
+
+template <int NT, int ND>
+__global__ __launch_bounds__(256, (NT * ND <= 6 ? 3 : 1)) void attn_bwd_fast2(const bf16 *qkv, const bf16 *dctx, bf16 *dqkv, const FastDims d) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int KD = (ND + 1) / 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pair = blockIdx.x * (blockDim.x >> 6) + wave;
+    if (pair >= d.B * d.H) return;
+    const int b = pair / d.H, h = pair % d.H;
+    const int g = lane >> 4, cq = lane & 15;
+    bf16 *Qimg = reinterpret_cast<bf16 *>(smem_raw) + (size_t)wave * 3 * d.img;
+    bf16 *Kimg = Qimg + d.img, *Oimg = Kimg + d.img;
+    const int64_t ld3 = 3 * (int64_t)d.E;
+    const bf16 *q = qkv + (int64_t)b * d.S * ld3 + h * d.Dh, *k = q + d.E, *v = q + 2 * d.E;
+    const bf16 *dO = dctx + (int64_t)b * d.S * d.E + h * d.Dh;
+    stage_nat(Qimg, d.ld, q, ld3, d.S, NT * 16, d.Dh, lane);
+    stage_nat(Kimg, d.ld, k, ld3, d.S, NT * 16, d.Dh, lane);
+    stage_nat(Oimg, d.ld, dO, d.E, d.S, NT * 16, d.Dh, lane);
+    bf16x8 kf[NT][KD], vf[NT][KD];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int kd = 0; kd < KD; ++kd) {
+            kf[j][kd] = gfrag(k, ld3, j * 16, d.S, kd * 32, d.Dh, lane);
+            vf[j][kd] = gfrag(v, ld3, j * 16, d.S, kd * 32, d.Dh, lane);
+        }
+    lds_sync();
+    const float scale = 1.0f / sqrtf((float)d.Dh);
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    bf16 *dst = dqkv + (int64_t)b * d.S * ld3 + h * d.Dh;
+
+    f32x4 dv[NT][ND], dk[NT][ND];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int jd = 0; jd < ND; ++jd) { dv[j][jd] = zero; dk[j][jd] = zero; }
+
+#pragma unroll 1
+    for (int it = 0; it < NT; ++it) {
+        bf16x8 qf[KD], of[KD];
+#pragma unroll
+        for (int kd = 0; kd < KD; ++kd) {
+            qf[kd] = gfrag(q, ld3, it * 16, d.S, kd * 32, d.Dh, lane);
+            of[kd] = gfrag(dO, d.E, it * 16, d.S, kd * 32, d.Dh, lane);
+        }
+        {   // ---- lane = key orientation: S = Q K^T, dP = dO V^T  ->  P, dS of this row tile  ->  dV, dK ----
+            f32x4 sc[NT], dp[NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                sc[j] = zero; dp[j] = zero;
+#pragma unroll
+                for (int kd = 0; kd < KD; ++kd) {
+                    sc[j] = mma(qf[kd], kf[j][kd], sc[j]);
+                    dp[j] = mma(of[kd], vf[j][kd], dp[j]);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float m = -INFINITY;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const bool ok = j * 16 + cq < d.S;
+                    sc[j][r] = ok ? sc[j][r] * scale : -INFINITY;
+                    m = fmaxf(m, sc[j][r]);
+                }
+                m = g16_max(m);
+                float sum = 0.f;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const float e = (j * 16 + cq < d.S) ? __expf(sc[j][r] - m) : 0.f;
+                    sc[j][r] = e;
+                    sum += e;
+                }
+                const float inv = 1.f / g16_sum(sum);
+                float delta = 0.f;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    sc[j][r] *= inv;
+                    delta += sc[j][r] * dp[j][r];
+                }
+                delta = g16_sum(delta);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) dp[j][r] = scale * sc[j][r] * (dp[j][r] - delta);     // dS
+            }
+            // C layout of P / dS tile j: column = key j*16 + cq, rows = query it*16 + 4g + r  ==  A operand [key][query k]
+            // of the 16-deep MFMA is its TRANSPOSE: A[row = key][k = query] -- which is what lane cq = key, k = 4g + r holds
+#pragma unroll
+            for (int jd = 0; jd < ND; ++jd) {
+                const k16_t bo = tr4(Oimg, d.ld, it * 16 + 4 * g, jd * 16, lane);
+                const k16_t bq = tr4(Qimg, d.ld, it * 16 + 4 * g, jd * 16, lane);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    dv[j][jd] = mma16(pack4(sc[j]), bo, dv[j][jd]);
+                    dk[j][jd] = mma16(pack4(dp[j]), bq, dk[j][jd]);
+                }
+            }
+        }
+        {   // ---- lane = query orientation: S^T = K Q^T, dP^T = V dO^T -> dS^T -> dQ of this row tile ----
+            f32x4 st[NT], dt[NT];
+            float m = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                st[j] = zero; dt[j] = zero;
+#pragma unroll
+                for (int kd = 0; kd < KD; ++kd) {
+                    st[j] = mma(kf[j][kd], qf[kd], st[j]);
+                    dt[j] = mma(vf[j][kd], of[kd], dt[j]);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool ok = j * 16 + 4 * g + r < d.S;
+                    st[j][r] = ok ? st[j][r] * scale : -INFINITY;
+                    m = fmaxf(m, st[j][r]);
+                }
+            }
+            m = x4_max(m);
+            float sum = 0.f;
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = (j * 16 + 4 * g + r < d.S) ? __expf(st[j][r] - m) : 0.f;
+                    st[j][r] = e;
+                    sum += e;
+                }
+            const float inv = 1.f / x4_sum(sum);
+            float delta = 0.f;
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    st[j][r] *= inv;
+                    delta += st[j][r] * dt[j][r];
+                }
+            delta = x4_sum(delta);
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) st[j][r] = scale * st[j][r] * (dt[j][r] - delta);    // dS^T: rows = keys, col = query
+#pragma unroll
+            for (int jd = 0; jd < ND; ++jd) {
+                f32x4 dq = zero;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) dq = mma16(pack4(st[j]), tr4(Kimg, d.ld, j * 16 + 4 * g, jd * 16, lane), dq);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = it * 16 + 4 * g + r;
+                    if (row < d.S) dst[(int64_t)row * ld3 + jd * 16 + cq] = from_f32<bf16>(dq[r]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int jd = 0; jd < ND; ++jd)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = j * 16 + 4 * g + r;
+                if (key < d.S) {
+                    bf16 *o = dst + (int64_t)key * ld3 + jd * 16 + cq;
+                    o[d.E] = from_f32<bf16>(dk[j][jd][r]);
+                    o[2 * d.E] = from_f32<bf16>(dv[j][jd][r]);
+                }
+            }
+}
+
 FastDims make_fast(int B, int S, int H, int Dh) {
     FastDims d;
     d.B = B; d.S = S; d.H = H; d.Dh = Dh; d.E = H * Dh;
@@ -389,7 +581,20 @@ template <int NT, int ND>
 int bwd_launch(const bf16 *qkv, const bf16 *dctx, bf16 *dqkv, const FastDims &d, hipStream_t s) {
     const size_t per_wave = (size_t)3 * d.img * sizeof(bf16);
     const int wpb = waves_per_block(per_wave);
-    auto kern = attn_bwd_fast<NT, ND>;
+    static const int version = getenv("MIVIT_ATTN_BWD") ? atoi(getenv("MIVIT_ATTN_BWD")) : 2;     // 1 = first (pair-tiled) version
+    auto kern = version == 2 ? attn_bwd_fast2<NT, ND> : attn_bwd_fast<NT, ND>;
+    if (version == 2) {        // the 16-deep version needs NT * 16 image rows, not the pair-padded NP * 32: more waves fit a CU
+        FastDims d2 = d;
+        d2.img = NT * 16 * d.ld;
+        const size_t pw = (size_t)3 * d2.img * sizeof(bf16);
+        const int w2 = waves_per_block(pw);
+        if (pw * w2 > 64 * 1024)
+            MIVIT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(pw * w2)));
+        ProfScope prof(s);
+        hipLaunchKernelGGL(kern, dim3(ceil_div(d.B * d.H, w2)), dim3(64 * w2), pw * w2, s, qkv, dctx, dqkv, d2);
+        MIVIT_LAUNCH_CHECK();
+        return 0;
+    }
     if (per_wave * wpb > 64 * 1024)
         MIVIT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(per_wave * wpb)));
     ProfScope prof(s);
