@@ -156,6 +156,102 @@ __global__ __launch_bounds__(BM / 64 * 2 * 64) void embed_fwd_dma(const EmbFwdAr
 }
 
 // =================================================================================================================
+// forward, LDS-DMA with 32-k stages: 256 rows x 128 columns per workgroup (8 waves, 64 x 64 each), stage = 32 fp32 k of X
+// (128-byte rows) + 32 bf16 k of W (64-byte rows) = 40 KB, two slots = 80 KB -> TWO workgroups (16 waves) per CU.
+// =================================================================================================================
+struct F32Cfg {
+    static constexpr int BM = 256, BN = 128, BK = 32, NW = 8, NS = 2;
+    static constexpr int A_BYTES = BM * BK * 4, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
+    static constexpr int A_DMA = A_BYTES / 1024 / NW, B_DMA = B_BYTES / 1024 / NW;     // 4, 1
+};
+
+__device__ __forceinline__ void f32_issue(const EmbFwdArgs &a, unsigned char *slot, int m0, int n0, int k0, int wave, int lane) {
+    using C = F32Cfg;
+    // A: 8 rows (128 B) per wave-instruction; the 32-byte chunk PAIR p of row r lands in pair slot p ^ ((r >> 1) & 3)
+#pragma unroll
+    for (int i = 0; i < C::A_DMA; ++i) {
+        const int inst = wave * C::A_DMA + i;
+        const int r = inst * 8 + (lane >> 3), sl = lane & 7;
+        const int c = (((sl >> 1) ^ ((r >> 1) & 3)) << 1) | (sl & 1);
+        dma16(a.X + (int64_t)min(m0 + r, a.M - 1) * a.K + k0 + c * 4, slot + inst * 1024);
+    }
+    // B: 16 rows (64 B) per wave-instruction; chunk c of row n lands in slot c ^ ((n >> 2) & 3)
+    unsigned char *bs = slot + C::A_BYTES;
+    {
+        const int n = wave * 16 + (lane >> 2), sl = lane & 3;
+        const int c = sl ^ ((n >> 2) & 3);
+        dma16(a.W + (int64_t)(n0 + n) * a.K + k0 + c * 8, bs + wave * 1024);
+    }
+}
+
+__global__ __launch_bounds__(512, 4) void embed_fwd_dma32(const EmbFwdArgs a) {
+    using C = F32Cfg;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int TM = 4, TN = 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * C::BM, n0 = blockIdx.x * C::BN;
+    const int nst = a.K / C::BK;
+    const int g = lane >> 4, cq = lane & 15;
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32_issue(a, smem, m0, n0, 0, wave, lane);
+    for (int s = 0; s < nst; ++s) {
+        wait_vm<0>();
+        barrier();      // stage s landed everywhere; everyone finished reading the other slot
+        if (s + 1 < nst) f32_issue(a, smem + ((s + 1) & 1) * C::STAGE, m0, n0, (s + 1) * C::BK, wave, lane);
+        const unsigned char *As = smem + (s & 1) * C::STAGE, *Bs = As + C::A_BYTES;
+        bf16x8 af[TM], bf[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int r = wm * 64 + i * 16 + cq;
+            const float4 *p = reinterpret_cast<const float4 *>(As + r * 128 + ((g ^ ((r >> 1) & 3)) << 5));
+            af[i] = cvt8(p[0], p[1]);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = wn * 64 + j * 16 + cq;
+            bf[j] = *reinterpret_cast<const bf16x8 *>(Bs + n * 64 + ((g ^ ((n >> 2) & 3)) << 4));
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = mma(af[i], bf[j], acc[i][j]);
+    }
+    // epilogue: + bias, through LDS as fp32 (64 rows per pass), 16-byte bf16 stores
+    constexpr int LDC = C::BN + 4;
+    float *Cs = reinterpret_cast<float *>(smem);
+    for (int h = 0; h < C::BM / 64; ++h) {
+        barrier();
+        if (wm == h) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int lc = wn * 64 + j * 16 + cq;
+                    const float bv = a.bias ? a.bias[n0 + lc] : 0.f;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Cs[(i * 16 + 4 * g + r) * LDC + lc] = acc[i][j][r] + bv;
+                }
+        }
+        barrier();
+        for (int c = tid; c < 64 * (C::BN / 8); c += 512) {
+            const int lr = c / (C::BN / 8), lc = (c % (C::BN / 8)) * 8;
+            const int row = m0 + h * 64 + lr;
+            if (row < a.M) {
+                float v[8];
+                *reinterpret_cast<float4 *>(v) = *reinterpret_cast<const float4 *>(Cs + lr * LDC + lc);
+                *reinterpret_cast<float4 *>(v + 4) = *reinterpret_cast<const float4 *>(Cs + lr * LDC + lc + 4);
+                store16(a.Y + (int64_t)row * a.E + n0 + lc, v);
+            }
+        }
+    }
+}
+
+// =================================================================================================================
 // forward, "direct" variant: the fp32 frames never touch LDS.  Each wave owns 32 rows x 128 columns and loads its X
 // fragments straight from global memory into the MFMA operand registers, one 64-k stage ahead (8 x 16-byte loads per
 // lane in flight, no barrier on that path, 12 waves per CU -> ~100 KB of X in flight per CU).  Only the bf16 W tile
@@ -490,6 +586,14 @@ int launch_embed_fwd_dma(const float *X, const void *W_bf16, const float *bias, 
         case 10: return fwd_direct_launch<1, 8, 3, 2>(a, s);
         case 11: return fwd_direct_launch<2, 4, 3, 2>(a, s);
         case 12: return fwd_direct_launch<1, 8, 3, 3>(a, s);
+        case 13: {
+            const size_t bytes = (size_t)F32Cfg::NS * F32Cfg::STAGE;
+            MIVIT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(embed_fwd_dma32), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+            ProfScope prof(s);
+            hipLaunchKernelGGL(embed_fwd_dma32, dim3(a.E / 128, ceil_div(a.M, F32Cfg::BM)), dim3(512), bytes, s, a);
+            MIVIT_LAUNCH_CHECK();
+            return 0;
+        }
         default: return fwd_direct_launch<2, 4, 3>(a, s);
     }
 }
