@@ -628,7 +628,7 @@ static int backward_impl(const mivit_plan *plan, const float *params, const floa
 // before is captured once into a hipGraph on an internal stream and replayed on the caller's stream afterwards.
 // ------------------------------------------------------------------------------------------------
 static bool graph_sized(const mivit_plan *plan, int B, int T) {
-    return plan && (int64_t)B * (T + 1) <= 8192;
+    return plan && (int64_t)B * (T + 1) <= 65536;
 }
 
 extern "C" int mivit_forward(const mivit_plan *plan, const float *params, const float *x, const float *features, int B,
