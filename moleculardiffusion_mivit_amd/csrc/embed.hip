@@ -594,7 +594,11 @@ int launch_embed_fwd_dma(const float *X, const void *W_bf16, const float *bias, 
             MIVIT_LAUNCH_CHECK();
             return 0;
         }
-        default: return fwd_direct_launch<2, 4, 3>(a, s);
+        default:
+            // small problems: shrink the row tile until the grid covers the chip (a 128-row tile gives M / 128 workgroups)
+            if ((long)ceil_div(a.M, 128) * (a.E / 128) >= 512) return fwd_direct_launch<2, 4, 3>(a, s);
+            if ((long)ceil_div(a.M, 64) * (a.E / 128) >= 512) return fwd_direct_launch<1, 4, 3>(a, s);
+            return fwd_direct_launch<1, 2, 3>(a, s);
     }
 }
 

@@ -165,7 +165,7 @@ int dma_splits(int M, int N, int K) {
     const long tiles = (long)(N / TILE) * (K / TILE);
     static const int target = getenv("MIVIT_WGRAD_DMA_BLOCKS") ? atoi(getenv("MIVIT_WGRAD_DMA_BLOCKS")) : 512;
     long s = (target + tiles - 1) / tiles;       // two resident workgroups per CU, one round
-    const long maxs = (M + 511) / 512;
+    const long maxs = (M + 127) / 128;           // at least two 64-row stages per split
     if (s > maxs) s = maxs;
     return s < 1 ? 1 : (int)s;
 }
