@@ -42,6 +42,9 @@ if __name__ == "__main__":
     if "c4_16" in which: run("c4 P=16 T=64 E=512 L=4", 2048, 64, 16, 512, 8, 1024, 4, pos=True)
     if "c4_64" in which: run("c4 P=64 T=64 E=512 L=4", 1024, 64, 64, 512, 8, 1024, 4, pos=True)
     if "c4_128" in which: run("c4 P=128 T=64 E=512 L=4", 256, 64, 128, 512, 8, 1024, 4, pos=True)
+    if "ref" in which:
+        for B in (16, 64, 256, 1024):
+            run("ref shape P=9 T=30 E=64 L=6", B, 30, 9, 64, 4, 128, 6, steps=30)
     if "c3" in which:
         run("c3 Framerate P=13 T=30 E=64", 4096, 30, 13, 64, 4, 128, 6)
         run("c3 Framerate P=13 T=60 E=64", 4096, 60, 13, 64, 4, 128, 6)

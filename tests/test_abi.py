@@ -116,8 +116,9 @@ def test_workspace_sizing_monotone_and_inference_smaller():
     b = p.workspace_bytes(64, 32, True)
     c = p.workspace_bytes(64, 32, False)
     assert 0 < a < b and c < b
+    # once the activations dominate the weight-gradient slabs, fp32 storage needs more than bf16 storage
     m32 = build_product_model(cfg, "fp32", None, device="cpu")
-    assert m32._plan.workspace_bytes(64, 32, True) > b
+    assert m32._plan.workspace_bytes(2048, 32, True) > p.workspace_bytes(2048, 32, True)
 
 
 def test_error_conventions_host_side():
