@@ -421,6 +421,7 @@ int wgrad_splits(int M, int N, int K) {
     return (int)s;
 }
 int colsum_chunks(int M) {
+    if (M <= 256) return 1;                          // tiny: one chunk, written straight into the result (no reduce launch)
     int c = ceil_div(M, M < 8192 ? 64 : 512);       // short problems: more, shorter row chunks (the row loop is a latency chain)
     return c < 1 ? 1 : (c > 256 ? 256 : c);
 }
@@ -510,6 +511,8 @@ int launch_linear_wgrad(const LinearWgradArgs &a, hipStream_t s) {
     if (a.db) {
         const int chunks = colsum_chunks(a.M);
         const int chunk = ceil_div(a.M, chunks);
+        const bool direct = chunks == 1 && !a.accumulate;       // the single partial row IS the result
+        if (direct) bias_part = a.db;
         const int cols_per_block = (a.dtype == MIVIT_F32 || a.dy_is_f32) ? 32 * 4 : 32 * 8;
         dim3 grid(ceil_div(a.N, cols_per_block), chunks);
         if (a.dtype == MIVIT_F32 || a.dy_is_f32)
@@ -522,8 +525,10 @@ int launch_linear_wgrad(const LinearWgradArgs &a, hipStream_t s) {
             hipLaunchKernelGGL(colsum_kernel<f16>, grid, dim3(256), 0, s, static_cast<const f16 *>(a.dy), a.lddy,
                                a.M, a.N, chunk, bias_part);
         MIVIT_LAUNCH_CHECK();
-        int rc = launch_slab_reduce(bias_part, chunks, a.N, a.db, a.accumulate, s);
-        if (rc) return rc;
+        if (!direct) {
+            int rc = launch_slab_reduce(bias_part, chunks, a.N, a.db, a.accumulate, s);
+            if (rc) return rc;
+        }
     }
     return 0;
 }
