@@ -142,7 +142,8 @@ int launch_t(const WsmArgs &a, int nsplit, int *parts, hipStream_t s) {
     auto kern = wgrad_small_kernel<NB, KB>;
     MIVIT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     const int nchunks = ceil_div(a.M, CH);
-    const int gx = std::max(1, std::min(SLAB_PARTS / nsplit, ceil_div(nchunks, NWV)));
+    // short problems (<= 1024 rows): one workgroup per column window writes the result in place, no slab + reduce launches
+    const int gx = nchunks <= 4 * NWV ? 1 : std::max(1, std::min(SLAB_PARTS / nsplit, ceil_div(nchunks, NWV)));
     ProfScope prof(s);
     hipLaunchKernelGGL(kern, dim3(gx, nsplit), dim3(NT), bytes, s, a);
     MIVIT_LAUNCH_CHECK();
@@ -173,8 +174,10 @@ size_t wgrad_small_ws_bytes(int M, int N, int K) {
 int launch_wgrad_small(const void *dy, int64_t lddy, const void *x, int64_t ldx, int M, int N, int K, float *dW, float *db,
                        void *ws, size_t ws_bytes, hipStream_t s) {
     MIVIT_CHECK(ws_bytes >= wgrad_small_ws_bytes(M, N, K), "wgrad_small: workspace too small");
-    float *bias_slabs = db ? static_cast<float *>(ws) + (size_t)SLAB_PARTS * N * K : nullptr;
-    WsmArgs a = {static_cast<const bf16 *>(dy), lddy, static_cast<const bf16 *>(x), ldx, static_cast<float *>(ws), bias_slabs, M, N, K};
+    const bool in_place = ceil_div(M, CH) <= 4 * NWV;          // must match launch_t's single-workgroup rule
+    float *bias_slabs = db ? (in_place ? db : static_cast<float *>(ws) + (size_t)SLAB_PARTS * N * K) : nullptr;
+    WsmArgs a = {static_cast<const bf16 *>(dy), lddy, static_cast<const bf16 *>(x), ldx, in_place ? dW : static_cast<float *>(ws),
+                 bias_slabs, M, N, K};
     const int nb = window_of(N, K), nsplit = N / nb;
     int parts = 0, rc;
     if (nb == 64 && K == 64) rc = launch_t<64, 64>(a, nsplit, &parts, s);
@@ -183,6 +186,7 @@ int launch_wgrad_small(const void *dy, int64_t lddy, const void *x, int64_t ldx,
     else if (nb == 64 && K == 128) rc = launch_t<64, 128>(a, nsplit, &parts, s);
     else MIVIT_FAIL("wgrad_small: unsupported shape N=%d K=%d", N, K);
     if (rc) return rc;
+    if (in_place) return 0;
     if ((rc = launch_slab_reduce(static_cast<const float *>(ws), parts, (int64_t)N * K, dW, 0, s))) return rc;
     return db ? launch_slab_reduce(bias_slabs, parts, N, db, 0, s) : 0;
 }
