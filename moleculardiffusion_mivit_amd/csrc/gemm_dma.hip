@@ -33,9 +33,9 @@ struct GdArgs {
     int xcd_remap;
 };
 
-template <int BMW, int BK, int NS>
+template <int BMW, int BK, int NS, int NW_ = 4>
 struct Cfg {
-    static constexpr int NW = 4, BM = NW * BMW, BN = 128;
+    static constexpr int NW = NW_, BM = NW * BMW, BN = 128;
     static constexpr int CH = BK / 8;                        // 16-byte chunks per k-contiguous row
     static constexpr int RPI = 1024 / (BK * 2);              // rows per 1 KiB wave-instruction
     static constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
@@ -51,9 +51,9 @@ struct Cfg {
 template <int BK>
 __device__ __forceinline__ int swz(int r) { return BK == 32 ? ((r >> 2) & 3) : ((r >> 1) & 7); }
 
-template <int BMW, int BK, int NS, bool DGRAD>
+template <int BMW, int BK, int NS, bool DGRAD, int NW>
 __device__ __forceinline__ void issue_stage(const GdArgs &a, unsigned char *slot, int m0, int n0, int k0, int wave, int lane) {
-    using C = Cfg<BMW, BK, NS>;
+    using C = Cfg<BMW, BK, NS, NW>;
 #pragma unroll
     for (int i = 0; i < C::A_DMA; ++i) {
         const int inst = wave * C::A_DMA + i;
@@ -92,9 +92,9 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char *img, int mr, int 
     return __builtin_bit_cast(bf16x8, pr);
 }
 
-template <int BMW, int BK, int NS, bool DGRAD>
-__global__ __launch_bounds__(256) void gemm_dma_kernel(const GdArgs a) {
-    using C = Cfg<BMW, BK, NS>;
+template <int BMW, int BK, int NS, bool DGRAD, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void gemm_dma_kernel(const GdArgs a) {
+    using C = Cfg<BMW, BK, NS, NW>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int TM = BMW / 16, TN = 8, D = NS - 1;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, cq = lane & 15, q = cq >> 2, p = cq & 3;
@@ -118,12 +118,12 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GdArgs a) {
 
 #pragma unroll
     for (int s = 0; s < D; ++s)
-        if (s < nst) issue_stage<BMW, BK, NS, DGRAD>(a, smem + s * C::STAGE, m0, n0, s * BK, wave, lane);
+        if (s < nst) issue_stage<BMW, BK, NS, DGRAD, NW>(a, smem + s * C::STAGE, m0, n0, s * BK, wave, lane);
     for (int s = 0; s < nst; ++s) {
         if (s + D - 1 < nst) wait_vm<C::PER_STAGE * (D - 1)>();
         else wait_vm<0>();
         barrier();
-        if (s + D < nst) issue_stage<BMW, BK, NS, DGRAD>(a, smem + ((s + D) % NS) * C::STAGE, m0, n0, (s + D) * BK, wave, lane);
+        if (s + D < nst) issue_stage<BMW, BK, NS, DGRAD, NW>(a, smem + ((s + D) % NS) * C::STAGE, m0, n0, (s + D) * BK, wave, lane);
         const unsigned char *As = smem + (s % NS) * C::STAGE, *Bs = As + C::A_BYTES;
 #pragma unroll
         for (int kk = 0; kk < BK / 32; ++kk) {
@@ -200,15 +200,15 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GdArgs a) {
     }
 }
 
-template <int BMW, int BK, int NS, bool DGRAD>
+template <int BMW, int BK, int NS, bool DGRAD, int NW = 4>
 int launch_t(const GdArgs &a, hipStream_t s) {
-    using C = Cfg<BMW, BK, NS>;
-    const size_t ring = (size_t)NS * C::STAGE, scratch = (size_t)4 * 16 * (C::BN + 4) * 4;
+    using C = Cfg<BMW, BK, NS, NW>;
+    const size_t ring = (size_t)NS * C::STAGE, scratch = (size_t)NW * 16 * (C::BN + 4) * 4;
     const size_t bytes = ring > scratch ? ring : scratch;
-    auto kern = gemm_dma_kernel<BMW, BK, NS, DGRAD>;
+    auto kern = gemm_dma_kernel<BMW, BK, NS, DGRAD, NW>;
     MIVIT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     ProfScope prof(s);
-    hipLaunchKernelGGL(kern, dim3(ceil_div(a.M, C::BM), a.NC / C::BN), dim3(256), bytes, s, a);
+    hipLaunchKernelGGL(kern, dim3(ceil_div(a.M, C::BM), a.NC / C::BN), dim3(NW * 64), bytes, s, a);
     MIVIT_LAUNCH_CHECK();
     return 0;
 }
@@ -224,7 +224,14 @@ int launch_variant(GdArgs a, hipStream_t s) {
         case 2: return launch_t<64, 32, 4, DGRAD>(a, s);
         case 3: return launch_t<64, 64, 2, DGRAD>(a, s);
         case 4: return launch_t<32, 64, 3, DGRAD>(a, s);     // 128 x 128 tile, 96 KB ring: 1 workgroup / CU
-        default: return launch_t<32, 32, 3, DGRAD>(a, s);    // 128 x 128 tile, 48 KB ring: 3 workgroups / CU (measured best)
+        case 5: return launch_t<32, 64, 2, DGRAD>(a, s);     // 64 KB ring: 2 workgroups / CU, 32 MFMAs per barrier
+        case 6: return launch_t<32, 32, 3, DGRAD, 8>(a, s);  // 256 x 128 tile, 8 waves, 72 KB ring
+        case 7: return launch_t<32, 32, 2, DGRAD, 8>(a, s);  // 256 x 128 tile, 8 waves, 48 KB ring
+        case 8: return launch_t<32, 64, 2, DGRAD, 8>(a, s);  // 256 x 128 tile, 8 waves, 96 KB ring
+        case 9: return launch_t<32, 32, 3, DGRAD>(a, s);     // 128 x 128 tile, 4 waves, 48 KB ring: 3 workgroups / CU
+        default:                                             // 256 x 128 tile, 8 waves of 32 x 128 (measured best: c4 forward
+            return DGRAD ? launch_t<32, 32, 2, true, 8>(a, s)    //   4.17 -> 3.75 ms with 3 slots, dgrad 4.05 -> 3.69 ms with 2)
+                         : launch_t<32, 32, 3, false, 8>(a, s);
     }
 }
 
