@@ -151,6 +151,29 @@ int mivit_deepresnet_train_bwd(int dtype, const mivit_deepresnet_params *params,
                                int N, int P, int E, float eps, const mivit_deepresnet_grads *grads, void *workspace,
                                size_t workspace_bytes, void *stream);
 
+/* Introspection (tests, diagnostics): byte offsets of the training workspace regions -- [0..6] raw convolution outputs
+ * y0..y6 ([N*P*P, c_out] in the compute dtype), [7] forward BatchNorm tables (7 x [mean|rstd|scale|shift] x 128 fp32),
+ * [8] gradient tables (7 x [k|c0|c1] x 128), [9] pooled [N,128] fp32, [10] dpooled, [11] partial sums, [12..14] the three
+ * gradient buffers, [15] total bytes. */
+int mivit_deepresnet_train_workspace_layout(int dtype, int N, int P, int E, size_t *offsets /* [16] */);
+
+/* Synchronised BatchNorm for data-parallel training of the DeepResNet embedding (the reference trains on
+ * one device, so its BatchNorm2d at helpers/models.py:206-225,233 always sees the whole minibatch -- this keeps that
+ * true across ranks).  train_fwd / train_bwd cut into MIVIT_DEEPRESNET_STAGES stages each; call stage 0..5 in order.
+ * Every stage leaves this rank's BatchNorm sums in `stats` ([2][3][128] fp64 on the device); between two stages the
+ * caller all-reduces (sum) the whole buffer in the forward pass and only its first [3][128] in the backward pass (the
+ * second half keeps the local sums that d gamma / d beta are made from, exactly as torch.nn.SyncBatchNorm does), then
+ * calls the next stage; *global_count (fp64 on the device, read by the kernels: no host synchronisation) = (frames over
+ * all ranks) * P * P, i.e. the all-reduced local N*P*P.  Not replayed as hipGraphs. */
+#define MIVIT_DEEPRESNET_STAGES 6
+#define MIVIT_DEEPRESNET_STATS_DOUBLES (2 * 3 * 128)
+int mivit_deepresnet_train_fwd_stage(int dtype, const mivit_deepresnet_params *params, const float *x, int N, int P, int E,
+                                     float momentum, float eps, float *tokens, void *workspace, size_t workspace_bytes,
+                                     int stage, const double *global_count, double *stats, void *stream);
+int mivit_deepresnet_train_bwd_stage(int dtype, const mivit_deepresnet_params *params, const float *x, const float *dtokens,
+                                     int N, int P, int E, float eps, const mivit_deepresnet_grads *grads, void *workspace,
+                                     size_t workspace_bytes, int stage, const double *global_count, double *stats, void *stream);
+
 /* Weight gradient of narrow layers (64-wide models), bf16: dW [N,K] = dy^T x for (N, K) in {(64,64), (128,64),
  * (192,64), (64,128)}, M >= 256; the whole gradient block lives in each wave's accumulators, deterministic reduction. */
 size_t mivit_wgrad_small_workspace_bytes(int M, int N, int K);

@@ -81,6 +81,11 @@ SYMBOLS = {
                                        c_void_p]),
     "mivit_deepresnet_train_bwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p,
                                            c_void_p, c_size_t, c_void_p]),
+    "mivit_deepresnet_train_workspace_layout": (c_int, [c_int, c_int, c_int, c_int, c_void_p]),
+    "mivit_deepresnet_train_fwd_stage": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p,
+                                                 c_void_p, c_size_t, c_int, c_void_p, c_void_p, c_void_p]),
+    "mivit_deepresnet_train_bwd_stage": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p,
+                                                 c_void_p, c_size_t, c_int, c_void_p, c_void_p, c_void_p]),
     "mivit_graph_stats": (None, [c_void_p, c_void_p, c_void_p]),
     "mivit_wgrad_small_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "mivit_wgrad_small": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,

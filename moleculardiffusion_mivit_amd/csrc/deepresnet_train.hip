@@ -367,10 +367,12 @@ __global__ __launch_bounds__(NT) void drn_wgrad0_kernel(const float *x, const Ti
 // ---------------------------------------------------------------------------------------------------------------
 // BatchNorm statistics: partial [nb][2][C] -> forward table [mean | rstd | scale | shift] + running-statistics update
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NT) void drn_bn_finalize_kernel(const float *part, int nb, int C, double count, const float *gamma,
+template <typename PT>
+__global__ __launch_bounds__(NT) void drn_bn_finalize_kernel(const PT *part, int nb, int C, double count, const float *gamma,
                                                              const float *beta, float *rmean, float *rvar, float momentum,
-                                                             float eps, float *coef) {
+                                                             float eps, float *coef, const double *count_dev) {
     __shared__ double red[2][4][128];
+    if (count_dev) count = *count_dev;
     const int c = threadIdx.x & 127, sl = threadIdx.x >> 7;
     double s = 0.0, q = 0.0;
     if (c < C)
@@ -409,6 +411,16 @@ __global__ void drn_part_reduce_kernel(const float *part, int nb, int W, float *
     double s = 0.0;
     for (int b = b2; b < nb; b += nb2) s += part[(size_t)b * W + w];
     out[(size_t)b2 * W + w] = (float)s;
+}
+
+// synchronised BatchNorm: partial [nb][W] -> one fp64 row [W] (the all-reduced operand) and optionally a second copy
+__global__ void drn_sync_reduce_kernel(const float *part, int nb, int W, double *out, double *copy) {
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= W) return;
+    double s = 0.0;
+    for (int b = 0; b < nb; ++b) s += part[(size_t)b * W + w];
+    out[w] = s;
+    if (copy) copy[w] = s;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -487,10 +499,15 @@ __global__ __launch_bounds__(NT) void drn_mask_reduce_kernel(const MaskArgs a) {
 }
 
 // partial [nb][3][C] -> d gamma, d beta and the DY table [k | c0 | c1]:  dy = k*g + c0 + c1*y
-__global__ __launch_bounds__(NT) void drn_bn_bwd_finalize_kernel(const float *part, int nb, int C, int which, double count,
+// `local` (synchronised BatchNorm): this rank's own sums [3][C]; d gamma / d beta come from those while the table uses
+// the sums and the count of the whole job
+template <typename PT>
+__global__ __launch_bounds__(NT) void drn_bn_bwd_finalize_kernel(const PT *part, int nb, int C, int which, double count,
                                                                  const float *gamma, const float *fcoef, float *bcoef,
-                                                                 float *dgamma, float *dbeta) {
+                                                                 float *dgamma, float *dbeta, const PT *local,
+                                                                 const double *count_dev) {
     __shared__ double red[2][4][128];
+    if (count_dev) count = *count_dev;
     const int c = threadIdx.x & 127, sl = threadIdx.x >> 7;
     double s = 0.0, q = 0.0;
     if (c < C)
@@ -505,7 +522,12 @@ __global__ __launch_bounds__(NT) void drn_bn_bwd_finalize_kernel(const float *pa
         const double k = (double)gamma[c] * rstd;
         const double c1 = -k * rstd * dg / count;
         bcoef[c] = (float)k; bcoef[CSTR + c] = (float)(-k * s / count - c1 * mean); bcoef[2 * CSTR + c] = (float)c1;
-        dgamma[c] = (float)dg; dbeta[c] = (float)s;
+        if (local) {
+            const double sl_ = (double)local[c], ql_ = (double)local[(size_t)which * C + c];
+            dgamma[c] = (float)(rstd * (ql_ - mean * sl_)); dbeta[c] = (float)sl_;
+        } else {
+            dgamma[c] = (float)dg; dbeta[c] = (float)s;
+        }
     }
 }
 
@@ -733,6 +755,11 @@ struct Ctx {
     void *ws; DrnWs w; hipStream_t s;
     const mivit_deepresnet_params *prm;
     bool use_running = false;      // inference: BatchNorm with the running statistics
+    // synchronised BatchNorm (staged entry points): `stats` = [2][3][128] fp64 exchanged by the caller between stages
+    double *stats = nullptr; int stage = -1; const double *gcount = nullptr;
+    bool sync() const { return stats != nullptr; }
+    bool in(int st) const { return !stats || st == stage; }
+    double *stat(int k) const { return stats + (size_t)k * 3 * 128; }
     float *fco(int i) const { return static_cast<float *>(at(ws, w.fcoef)) + (size_t)i * 4 * CSTR; }
     float *bco(int i) const { return static_cast<float *>(at(ws, w.bcoef)) + (size_t)i * 3 * CSTR; }
     void *y(int i) const { return at(ws, w.y[i]); }
@@ -760,8 +787,27 @@ int bn_finalize(const Ctx &c, int i, const float *part, int nb) {
         return 0;
     }
     RC(squeeze_parts(c, part, nb, 2 * C));
-    hipLaunchKernelGGL(drn_bn_finalize_kernel, dim3(1), dim3(NT), 0, c.s, part, nb, C, c.count(), b.gamma, b.beta, b.running_mean,
-                       b.running_var, c.momentum, c.eps, c.fco(i));
+    hipLaunchKernelGGL(drn_bn_finalize_kernel<float>, dim3(1), dim3(NT), 0, c.s, part, nb, C, c.count(), b.gamma, b.beta, b.running_mean,
+                       b.running_var, c.momentum, c.eps, c.fco(i), (const double *)nullptr);
+    MIVIT_LAUNCH_CHECK();
+    return 0;
+}
+
+// after a convolution: either finish BatchNorm i from this rank's partials, or (synchronised) leave the local sums in
+// stats slot k for the caller to all-reduce
+int bn_produce(const Ctx &c, int i, int k, const float *part, int nb) {
+    if (!c.sync()) return bn_finalize(c, i, part, nb);
+    const int W = 2 * DRN_CO[i];
+    hipLaunchKernelGGL(drn_sync_reduce_kernel, dim3(ceil_div(W, 128)), dim3(128), 0, c.s, part, nb, W, c.stat(k), (double *)nullptr);
+    MIVIT_LAUNCH_CHECK();
+    return 0;
+}
+// before BatchNorm i is applied: (synchronised) finish it from the all-reduced sums in slot k and the job-wide count
+int bn_consume(const Ctx &c, int i, int k) {
+    if (!c.sync()) return 0;
+    const mivit_conv_bn &b = c.prm->conv[i];
+    hipLaunchKernelGGL(drn_bn_finalize_kernel<double>, dim3(1), dim3(NT), 0, c.s, c.stat(k), 1, DRN_CO[i], 0.0, b.gamma, b.beta,
+                       b.running_mean, b.running_var, c.momentum, c.eps, c.fco(i), c.gcount);
     MIVIT_LAUNCH_CHECK();
     return 0;
 }
@@ -796,10 +842,12 @@ int pack_weights(const Ctx &c) {
 
 template <typename T>
 int forward_t(const Ctx &c, const float *x, float *tokens) {
-    RC(pack_weights<T>(c));
+    // stages (synchronised BatchNorm runs one per call, the caller all-reduces c.stats in between; otherwise all six run)
     float *part = c.part(), *part_b = part + (size_t)c.w.parts_cap * 3 * 128;
     int nb = 0;
-    {   // conv0
+    ConvArgs a{};
+    if (c.in(0)) {   // conv0
+        RC(pack_weights<T>(c));
         int t, nt;
         choose_tile(c.dtype, c.P, &t, &nt);
         const Geom g = make_geom(c.dtype, c.N, c.P, conv0_slots(t));
@@ -807,33 +855,42 @@ int forward_t(const Ctx &c, const float *x, float *tokens) {
         const size_t lds = (size_t)g.F * g.HPt * 4 + 16 * 2 * 32 * 4 + (size_t)2 * g.RT * 4;
         hipLaunchKernelGGL(drn_conv0_kernel<T>, dim3(nb), dim3(NT), lds, c.s, x, c.prm->conv[0].weight, static_cast<T *>(c.y(0)), part, g);
         MIVIT_LAUNCH_CHECK();
-        RC(bn_finalize(c, 0, part, nb));
+        RC(bn_produce(c, 0, 0, part, nb));
     }
-    ConvArgs a{};
-    // block 1: conv1 (32->64) + skip (1x1) from a0 = relu(BN0(y0))
-    a = ConvArgs{};
-    a.A = TileSrc{c.y(0), nullptr, c.fco(0), nullptr};
-    a.W = at(c.ws, c.w.wf[1]); a.W2 = at(c.ws, c.w.wf[3]); a.out = c.y(1); a.out2 = c.y(3); a.stats = part; a.stats2 = part_b;
-    RC((run_conv<T, 32, 64, 1, PRO_ACT1, 32>(c, a, &nb)));
-    RC(bn_finalize(c, 1, part, nb)); RC(bn_finalize(c, 3, part_b, nb));
-    // block 1: conv2 (64->64) from relu(BN1(y11))
-    a = ConvArgs{};
-    a.A = TileSrc{c.y(1), nullptr, c.fco(1), nullptr};
-    a.W = at(c.ws, c.w.wf[2]); a.out = c.y(2); a.stats = part;
-    RC((run_conv<T, 64, 64, 0, PRO_ACT1, 64>(c, a, &nb)));
-    RC(bn_finalize(c, 2, part, nb));
-    // block 2: conv1 (64->128) + skip from o1 = relu(BN2(y12) + BN3(y1s))
-    a = ConvArgs{};
-    a.A = TileSrc{c.y(2), c.y(3), c.fco(2), c.fco(3)};
-    a.W = at(c.ws, c.w.wf[4]); a.W2 = at(c.ws, c.w.wf[6]); a.out = c.y(4); a.out2 = c.y(6); a.stats = part; a.stats2 = part_b;
-    RC((run_conv<T, 64, 128, 1, PRO_ACT2, 64>(c, a, &nb)));
-    RC(bn_finalize(c, 4, part, nb)); RC(bn_finalize(c, 6, part_b, nb));
-    // block 2: conv2 (128->128)
-    a = ConvArgs{};
-    a.A = TileSrc{c.y(4), nullptr, c.fco(4), nullptr};
-    a.W = at(c.ws, c.w.wf[5]); a.out = c.y(5); a.stats = part;
-    RC((run_conv<T, 128, 128, 0, PRO_ACT1, 128>(c, a, &nb)));
-    RC(bn_finalize(c, 5, part, nb));
+    if (c.in(1)) {   // block 1: conv1 (32->64) + skip (1x1) from a0 = relu(BN0(y0))
+        RC(bn_consume(c, 0, 0));
+        a = ConvArgs{};
+        a.A = TileSrc{c.y(0), nullptr, c.fco(0), nullptr};
+        a.W = at(c.ws, c.w.wf[1]); a.W2 = at(c.ws, c.w.wf[3]); a.out = c.y(1); a.out2 = c.y(3); a.stats = part; a.stats2 = part_b;
+        RC((run_conv<T, 32, 64, 1, PRO_ACT1, 32>(c, a, &nb)));
+        RC(bn_produce(c, 1, 0, part, nb)); RC(bn_produce(c, 3, 1, part_b, nb));
+    }
+    if (c.in(2)) {   // block 1: conv2 (64->64) from relu(BN1(y11))
+        RC(bn_consume(c, 1, 0)); RC(bn_consume(c, 3, 1));
+        a = ConvArgs{};
+        a.A = TileSrc{c.y(1), nullptr, c.fco(1), nullptr};
+        a.W = at(c.ws, c.w.wf[2]); a.out = c.y(2); a.stats = part;
+        RC((run_conv<T, 64, 64, 0, PRO_ACT1, 64>(c, a, &nb)));
+        RC(bn_produce(c, 2, 0, part, nb));
+    }
+    if (c.in(3)) {   // block 2: conv1 (64->128) + skip from o1 = relu(BN2(y12) + BN3(y1s))
+        RC(bn_consume(c, 2, 0));
+        a = ConvArgs{};
+        a.A = TileSrc{c.y(2), c.y(3), c.fco(2), c.fco(3)};
+        a.W = at(c.ws, c.w.wf[4]); a.W2 = at(c.ws, c.w.wf[6]); a.out = c.y(4); a.out2 = c.y(6); a.stats = part; a.stats2 = part_b;
+        RC((run_conv<T, 64, 128, 1, PRO_ACT2, 64>(c, a, &nb)));
+        RC(bn_produce(c, 4, 0, part, nb)); RC(bn_produce(c, 6, 1, part_b, nb));
+    }
+    if (c.in(4)) {   // block 2: conv2 (128->128)
+        RC(bn_consume(c, 4, 0)); RC(bn_consume(c, 6, 1));
+        a = ConvArgs{};
+        a.A = TileSrc{c.y(4), nullptr, c.fco(4), nullptr};
+        a.W = at(c.ws, c.w.wf[5]); a.out = c.y(5); a.stats = part;
+        RC((run_conv<T, 128, 128, 0, PRO_ACT1, 128>(c, a, &nb)));
+        RC(bn_produce(c, 5, 0, part, nb));
+    }
+    if (!c.in(5)) return 0;
+    RC(bn_consume(c, 5, 0));
     // pooling + fc
     float *pooled = static_cast<float *>(at(c.ws, c.w.pooled));
     hipLaunchKernelGGL(drn_pool_kernel<T>, dim3(c.N), dim3(128), 0, c.s, static_cast<const T *>(c.y(5)), static_cast<const T *>(c.y(6)),
@@ -864,8 +921,23 @@ int bn_bwd_finalize(const Ctx &c, int i, int which, int nb, const mivit_deepresn
     const int C = DRN_CO[i];
     const float *part = c.part();
     RC(squeeze_parts(c, part, nb, 3 * C));
-    hipLaunchKernelGGL(drn_bn_bwd_finalize_kernel, dim3(1), dim3(NT), 0, c.s, part, nb, C, which, c.count(), c.prm->conv[i].gamma,
-                       c.fco(i), c.bco(i), gr->conv[i].gamma, gr->conv[i].beta);
+    hipLaunchKernelGGL(drn_bn_bwd_finalize_kernel<float>, dim3(1), dim3(NT), 0, c.s, part, nb, C, which, c.count(), c.prm->conv[i].gamma,
+                       c.fco(i), c.bco(i), gr->conv[i].gamma, gr->conv[i].beta, (const float *)nullptr, (const double *)nullptr);
+    MIVIT_LAUNCH_CHECK();
+    return 0;
+}
+// after a mask pass over C channels: (synchronised) local sums [3][C] -> stats slot 0 (all-reduced) and slot 1 (kept local)
+int bwd_produce(const Ctx &c, int C, int nb) {
+    if (!c.sync()) return 0;
+    hipLaunchKernelGGL(drn_sync_reduce_kernel, dim3(ceil_div(3 * C, 128)), dim3(128), 0, c.s, c.part(), nb, 3 * C, c.stat(0), c.stat(1));
+    MIVIT_LAUNCH_CHECK();
+    return 0;
+}
+// gradient table + d gamma / d beta of BatchNorm i: from this rank's partials, or (synchronised) from the exchanged sums
+int bwd_consume(const Ctx &c, int i, int which, int nb, const mivit_deepresnet_grads *gr) {
+    if (!c.sync()) return bn_bwd_finalize(c, i, which, nb, gr);
+    hipLaunchKernelGGL(drn_bn_bwd_finalize_kernel<double>, dim3(1), dim3(NT), 0, c.s, c.stat(0), 1, DRN_CO[i], which, 0.0,
+                       c.prm->conv[i].gamma, c.fco(i), c.bco(i), gr->conv[i].gamma, gr->conv[i].beta, (const double *)c.stat(1), c.gcount);
     MIVIT_LAUNCH_CHECK();
     return 0;
 }
@@ -895,58 +967,74 @@ int run_wgrad(const Ctx &c, const TileSrc &A, const TileSrc &D, float *dW) {
 
 template <typename T>
 int backward_t(const Ctx &c, const float *x, const float *dtokens, const mivit_deepresnet_grads *gr) {
+    // stages as in forward_t: each ends with a mask pass whose sums the next stage's BatchNorm gradient table needs
     float *pooled = static_cast<float *>(at(c.ws, c.w.pooled)), *dpooled = static_cast<float *>(at(c.ws, c.w.dpooled));
-    // fc: dpooled = dtokens W ; dW = dtokens^T pooled ; db
-    LinearDgradArgs d{};
-    d.dtype = MIVIT_F32; d.dy = dtokens; d.dy_is_f32 = 1; d.lddy = c.E; d.W = c.prm->fc_weight; d.M = c.N; d.N = c.E; d.K = 128;
-    d.act = MIVIT_ACT_NONE; d.dx = dpooled; d.lddx = 128; d.dx_is_f32 = 1;
-    RC(launch_linear_dgrad(d, c.s));
-    LinearWgradArgs wg{};
-    wg.dtype = MIVIT_F32; wg.dy = dtokens; wg.dy_is_f32 = 1; wg.lddy = c.E; wg.x = pooled; wg.x_is_f32 = 1; wg.ldx = 128;
-    wg.M = c.N; wg.N = c.E; wg.K = 128; wg.dW = gr->fc_weight; wg.db = gr->fc_bias; wg.ws = at(c.ws, c.w.lin);
-    wg.ws_bytes = linear_wgrad_ws_bytes(c.N, c.E, 128);
-    RC(launch_linear_wgrad(wg, c.s));
-
     void *X1 = at(c.ws, c.w.X[0]), *X2 = at(c.ws, c.w.X[1]), *X3 = at(c.ws, c.w.X[2]);
     int nb = 0;
-    // ---- top: g2 = pool-gradient * [o2 > 0] -> X1 ; BatchNorm 5 (conv2) and 6 (skip) of block 2
-    RC((run_mask<T, 128, true, true>(c, dpooled, 5, 6, X1, &nb)));
-    RC(bn_bwd_finalize(c, 5, 1, nb, gr)); RC(bn_bwd_finalize(c, 6, 2, nb, gr));
+    ConvArgs a{};
     const TileSrc dy22{X1, c.y(5), c.bco(5), nullptr}, dy2s{X1, c.y(6), c.bco(6), nullptr};
     const TileSrc a21{c.y(4), nullptr, c.fco(4), nullptr}, o1{c.y(2), c.y(3), c.fco(2), c.fco(3)};
-    RC((run_wgrad<T, 128, 128, 9, PRO_ACT1>(c, a21, dy22, gr->conv[5].weight)));
-    RC((run_wgrad<T, 64, 128, 1, PRO_ACT2>(c, o1, dy2s, gr->conv[6].weight)));
-    ConvArgs a{};
-    a.A = dy22; a.W = at(c.ws, c.w.wd[5]); a.out = X2;                                   // d a21 -> X2
-    RC((run_conv<T, 128, 128, 0, PRO_DY, 128>(c, a, nullptr)));
-    // ---- BatchNorm 4 (block 2 conv1): g21 in place in X2
-    RC((run_mask<T, 128, false, false>(c, X2, 4, 4, X2, &nb)));
-    RC(bn_bwd_finalize(c, 4, 1, nb, gr));
     const TileSrc dy21{X2, c.y(4), c.bco(4), nullptr};
-    RC((run_wgrad<T, 64, 128, 9, PRO_ACT2>(c, o1, dy21, gr->conv[4].weight)));
-    a = ConvArgs{};
-    a.A = dy21; a.B = dy2s; a.W = at(c.ws, c.w.wd[4]); a.W2 = at(c.ws, c.w.wd[6]); a.out = X3;   // d o1 -> X3 [R,64]
-    RC((run_conv<T, 128, 64, 2, PRO_DY, 128>(c, a, nullptr)));
-    // ---- block 1 output: g1 in place in X3 ; BatchNorm 2 (conv2) and 3 (skip)
-    RC((run_mask<T, 64, true, false>(c, X3, 2, 3, X3, &nb)));
-    RC(bn_bwd_finalize(c, 2, 1, nb, gr)); RC(bn_bwd_finalize(c, 3, 2, nb, gr));
     const TileSrc dy12{X3, c.y(2), c.bco(2), nullptr}, dy1s{X3, c.y(3), c.bco(3), nullptr};
     const TileSrc a11{c.y(1), nullptr, c.fco(1), nullptr}, a0{c.y(0), nullptr, c.fco(0), nullptr};
-    RC((run_wgrad<T, 64, 64, 9, PRO_ACT1>(c, a11, dy12, gr->conv[2].weight)));
-    RC((run_wgrad<T, 32, 64, 1, PRO_ACT1>(c, a0, dy1s, gr->conv[3].weight)));
-    a = ConvArgs{};
-    a.A = dy12; a.W = at(c.ws, c.w.wd[2]); a.out = X1;                                   // d a11 -> X1 [R,64]
-    RC((run_conv<T, 64, 64, 0, PRO_DY, 64>(c, a, nullptr)));
-    RC((run_mask<T, 64, false, false>(c, X1, 1, 1, X1, &nb)));
-    RC(bn_bwd_finalize(c, 1, 1, nb, gr));
     const TileSrc dy11{X1, c.y(1), c.bco(1), nullptr};
-    RC((run_wgrad<T, 32, 64, 9, PRO_ACT1>(c, a0, dy11, gr->conv[1].weight)));
-    a = ConvArgs{};
-    a.A = dy11; a.B = dy1s; a.W = at(c.ws, c.w.wd[1]); a.W2 = at(c.ws, c.w.wd[3]); a.out = X2;   // d a0 -> X2 [R,32]
-    RC((run_conv<T, 64, 32, 2, PRO_DY, 64>(c, a, nullptr)));
-    RC((run_mask<T, 32, false, false>(c, X2, 0, 0, X2, &nb)));
-    RC(bn_bwd_finalize(c, 0, 1, nb, gr));
-    {   // first convolution's weight gradient
+    if (c.in(0)) {
+        // fc: dpooled = dtokens W ; dW = dtokens^T pooled ; db
+        LinearDgradArgs d{};
+        d.dtype = MIVIT_F32; d.dy = dtokens; d.dy_is_f32 = 1; d.lddy = c.E; d.W = c.prm->fc_weight; d.M = c.N; d.N = c.E; d.K = 128;
+        d.act = MIVIT_ACT_NONE; d.dx = dpooled; d.lddx = 128; d.dx_is_f32 = 1;
+        RC(launch_linear_dgrad(d, c.s));
+        LinearWgradArgs wg{};
+        wg.dtype = MIVIT_F32; wg.dy = dtokens; wg.dy_is_f32 = 1; wg.lddy = c.E; wg.x = pooled; wg.x_is_f32 = 1; wg.ldx = 128;
+        wg.M = c.N; wg.N = c.E; wg.K = 128; wg.dW = gr->fc_weight; wg.db = gr->fc_bias; wg.ws = at(c.ws, c.w.lin);
+        wg.ws_bytes = linear_wgrad_ws_bytes(c.N, c.E, 128);
+        RC(launch_linear_wgrad(wg, c.s));
+        // ---- top: g2 = pool-gradient * [o2 > 0] -> X1 ; BatchNorm 5 (conv2) and 6 (skip) of block 2
+        RC((run_mask<T, 128, true, true>(c, dpooled, 5, 6, X1, &nb)));
+        RC(bwd_produce(c, 128, nb));
+    }
+    if (c.in(1)) {
+        RC(bwd_consume(c, 5, 1, nb, gr)); RC(bwd_consume(c, 6, 2, nb, gr));
+        RC((run_wgrad<T, 128, 128, 9, PRO_ACT1>(c, a21, dy22, gr->conv[5].weight)));
+        RC((run_wgrad<T, 64, 128, 1, PRO_ACT2>(c, o1, dy2s, gr->conv[6].weight)));
+        a = ConvArgs{};
+        a.A = dy22; a.W = at(c.ws, c.w.wd[5]); a.out = X2;                                   // d a21 -> X2
+        RC((run_conv<T, 128, 128, 0, PRO_DY, 128>(c, a, nullptr)));
+        // ---- BatchNorm 4 (block 2 conv1): g21 in place in X2
+        RC((run_mask<T, 128, false, false>(c, X2, 4, 4, X2, &nb)));
+        RC(bwd_produce(c, 128, nb));
+    }
+    if (c.in(2)) {
+        RC(bwd_consume(c, 4, 1, nb, gr));
+        RC((run_wgrad<T, 64, 128, 9, PRO_ACT2>(c, o1, dy21, gr->conv[4].weight)));
+        a = ConvArgs{};
+        a.A = dy21; a.B = dy2s; a.W = at(c.ws, c.w.wd[4]); a.W2 = at(c.ws, c.w.wd[6]); a.out = X3;   // d o1 -> X3 [R,64]
+        RC((run_conv<T, 128, 64, 2, PRO_DY, 128>(c, a, nullptr)));
+        // ---- block 1 output: g1 in place in X3 ; BatchNorm 2 (conv2) and 3 (skip)
+        RC((run_mask<T, 64, true, false>(c, X3, 2, 3, X3, &nb)));
+        RC(bwd_produce(c, 64, nb));
+    }
+    if (c.in(3)) {
+        RC(bwd_consume(c, 2, 1, nb, gr)); RC(bwd_consume(c, 3, 2, nb, gr));
+        RC((run_wgrad<T, 64, 64, 9, PRO_ACT1>(c, a11, dy12, gr->conv[2].weight)));
+        RC((run_wgrad<T, 32, 64, 1, PRO_ACT1>(c, a0, dy1s, gr->conv[3].weight)));
+        a = ConvArgs{};
+        a.A = dy12; a.W = at(c.ws, c.w.wd[2]); a.out = X1;                                   // d a11 -> X1 [R,64]
+        RC((run_conv<T, 64, 64, 0, PRO_DY, 64>(c, a, nullptr)));
+        RC((run_mask<T, 64, false, false>(c, X1, 1, 1, X1, &nb)));
+        RC(bwd_produce(c, 64, nb));
+    }
+    if (c.in(4)) {
+        RC(bwd_consume(c, 1, 1, nb, gr));
+        RC((run_wgrad<T, 32, 64, 9, PRO_ACT1>(c, a0, dy11, gr->conv[1].weight)));
+        a = ConvArgs{};
+        a.A = dy11; a.B = dy1s; a.W = at(c.ws, c.w.wd[1]); a.W2 = at(c.ws, c.w.wd[3]); a.out = X2;   // d a0 -> X2 [R,32]
+        RC((run_conv<T, 64, 32, 2, PRO_DY, 64>(c, a, nullptr)));
+        RC((run_mask<T, 32, false, false>(c, X2, 0, 0, X2, &nb)));
+        RC(bwd_produce(c, 32, nb));
+    }
+    if (c.in(5)) {   // first convolution's weight gradient
+        RC(bwd_consume(c, 0, 1, nb, gr));
         int t, nt;
         choose_tile(c.dtype, c.P, &t, &nt);
         const Geom g = make_geom(c.dtype, c.N, c.P, conv0_slots(t));
@@ -987,6 +1075,20 @@ extern "C" int mivit_deepresnet_train_supported(int dtype, int patch_size) { ret
 extern "C" size_t mivit_deepresnet_train_workspace_bytes(int dtype, int N, int P, int E) {
     if (N <= 0 || E <= 0 || !drn_train_supported(dtype, P)) return 0;
     return make_ws(dtype, N, P, E).total;
+}
+
+// introspection for tests / diagnostics: byte offsets of the workspace regions
+// [0..6] raw convolution outputs y0..y6, [7] forward tables, [8] gradient tables, [9] pooled, [10] dpooled, [11] partials,
+// [12..14] gradient buffers X1..X3, [15] total
+extern "C" int mivit_deepresnet_train_workspace_layout(int dtype, int N, int P, int E, size_t *offsets) {
+    MIVIT_CHECK(offsets, "deepresnet_train_workspace_layout: null pointer");
+    if (N <= 0 || E <= 0 || !drn_train_supported(dtype, P)) { mivit_set_error("deepresnet_train_workspace_layout: unsupported shape"); return 3; }
+    const DrnWs w = make_ws(dtype, N, P, E);
+    for (int i = 0; i < 7; ++i) offsets[i] = w.y[i];
+    offsets[7] = w.fcoef; offsets[8] = w.bcoef; offsets[9] = w.pooled; offsets[10] = w.dpooled; offsets[11] = w.part;
+    for (int i = 0; i < 3; ++i) offsets[12 + i] = w.X[i];
+    offsets[15] = w.total;
+    return 0;
 }
 
 extern "C" int mivit_deepresnet_train_fwd(int dtype, const mivit_deepresnet_params *params, const float *x, int N, int P, int E,
@@ -1036,6 +1138,43 @@ extern "C" int mivit_deepresnet_train_bwd(int dtype, const mivit_deepresnet_para
                        (uint64_t)grads->fc_weight, (uint64_t)grads->fc_bias, (uint64_t)__builtin_bit_cast(uint32_t, eps)})
         key.push_back(v);
     return graph_run(key.data(), (int)key.size(), c.s, body);
+}
+
+// Synchronised BatchNorm under data parallelism: the same forward / backward cut into six stages each.  A stage leaves
+// this rank's BatchNorm sums in `stats` ([2][3][128] fp64, device); the caller all-reduces them (forward: the whole
+// buffer; backward: the first [3][128] only -- the second keeps the local sums d gamma / d beta are made from) and calls
+// the next stage, which finishes the statistics with *global_count (device fp64) = frames of the whole job x P^2.
+extern "C" int mivit_deepresnet_train_fwd_stage(int dtype, const mivit_deepresnet_params *params, const float *x, int N, int P, int E,
+                                                float momentum, float eps, float *tokens, void *workspace, size_t workspace_bytes,
+                                                int stage, const double *global_count, double *stats, void *stream) {
+    MIVIT_CHECK(dtype == MIVIT_F32 || dtype == MIVIT_BF16, "bad dtype %d", dtype);
+    RC(check_params(params));
+    MIVIT_CHECK(x && tokens && workspace && stats && global_count, "deepresnet_train_fwd_stage: null pointer");
+    MIVIT_CHECK(N > 0 && E > 0, "deepresnet_train_fwd_stage: empty problem");
+    MIVIT_CHECK(stage >= 0 && stage < MIVIT_DEEPRESNET_STAGES, "deepresnet_train_fwd_stage: bad stage %d", stage);
+    if (!drn_train_supported(dtype, P)) { mivit_set_error("deepresnet_train_fwd_stage: unsupported frame side %d", P); return 3; }
+    Ctx c{dtype, N, P, E, eps, momentum, workspace, make_ws(dtype, N, P, E), static_cast<hipStream_t>(stream), params};
+    MIVIT_CHECK(workspace_bytes >= c.w.total, "deepresnet_train_fwd_stage: workspace too small (%zu < %zu)", workspace_bytes, c.w.total);
+    c.stats = stats; c.stage = stage; c.gcount = global_count;
+    prof_set_tag(MIVIT_PROF_OP);
+    return dtype == MIVIT_F32 ? forward_t<float>(c, x, tokens) : forward_t<bf16>(c, x, tokens);
+}
+
+extern "C" int mivit_deepresnet_train_bwd_stage(int dtype, const mivit_deepresnet_params *params, const float *x, const float *dtokens,
+                                                int N, int P, int E, float eps, const mivit_deepresnet_grads *grads, void *workspace,
+                                                size_t workspace_bytes, int stage, const double *global_count, double *stats, void *stream) {
+    MIVIT_CHECK(dtype == MIVIT_F32 || dtype == MIVIT_BF16, "bad dtype %d", dtype);
+    RC(check_params(params));
+    MIVIT_CHECK(x && dtokens && workspace && stats && global_count && grads && grads->fc_weight && grads->fc_bias, "deepresnet_train_bwd_stage: null pointer");
+    for (int i = 0; i < 7; ++i)
+        MIVIT_CHECK(grads->conv[i].weight && grads->conv[i].gamma && grads->conv[i].beta, "deepresnet_train_bwd_stage: null gradient %d", i);
+    MIVIT_CHECK(stage >= 0 && stage < MIVIT_DEEPRESNET_STAGES, "deepresnet_train_bwd_stage: bad stage %d", stage);
+    if (!drn_train_supported(dtype, P)) { mivit_set_error("deepresnet_train_bwd_stage: unsupported frame side %d", P); return 3; }
+    Ctx c{dtype, N, P, E, eps, 0.f, workspace, make_ws(dtype, N, P, E), static_cast<hipStream_t>(stream), params};
+    MIVIT_CHECK(workspace_bytes >= c.w.total, "deepresnet_train_bwd_stage: workspace too small (%zu < %zu)", workspace_bytes, c.w.total);
+    c.stats = stats; c.stage = stage; c.gcount = global_count;
+    prof_set_tag(MIVIT_PROF_OP);
+    return dtype == MIVIT_F32 ? backward_t<float>(c, x, dtokens, grads) : backward_t<bf16>(c, x, dtokens, grads);
 }
 
 extern "C" int mivit_deepresnet_infer(int dtype, const mivit_deepresnet_params *params, const float *x, int N, int P, int E,

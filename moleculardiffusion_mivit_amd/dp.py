@@ -60,12 +60,18 @@ def broadcast_parameters(model, src: int = 0, group=None):
         dist.broadcast(b, src=src, group=group)
 
 
-def attach(model, group=None, broadcast: bool = True):
+def attach(model, group=None, broadcast: bool = True, sync_batchnorm: bool = False):
     """Make `model` (a GeneralTransformer) data-parallel over `group`: gradients produced by its backward are
     averaged across ranks, overlapped stage by stage.  Parameters outside the arena (external embeddings) are
-    averaged by `finish_external_grads` after backward."""
+    averaged by `finish_external_grads` after backward.  `sync_batchnorm`: a DeepResNet embedding normalises with
+    the statistics of the whole job's minibatch instead of the rank's shard."""
     if broadcast:
         broadcast_parameters(model, 0, group)
+    emb = getattr(model, "embedding", None)
+    if sync_batchnorm:
+        if not hasattr(emb, "sync_batchnorm"):
+            raise ValueError("sync_batchnorm=True needs a DeepResNetEmbedding (the only embedding with BatchNorm)")
+        emb.sync_batchnorm(group)
     model._dp = StagedGradReducer(model._plan.stage_ranges, group)
     return model
 

@@ -195,10 +195,18 @@ class ResidualBlock(nn.Module):
 class DeepResNetEmbedding(nn.Module):
     """Per-frame conv stack (reference models.py:230-257), handing pre-norm tokens [B,T,E] to the HIP engine
     (MIVIT_EMBED_EXTERNAL).  Inference (``eval()`` + no grad) runs one fused hand-written HIP kernel with BatchNorm
-    folded into the convolutions (csrc/deepresnet.hip); training (batch-statistics BatchNorm) runs on stock
-    PyTorch-ROCm (MIOpen).
+    folded into the convolutions (csrc/deepresnet.hip); training (batch-statistics BatchNorm) runs the hand-written
+    conv / BatchNorm forward + backward of csrc/deepresnet_train.hip.  Under data parallelism ``sync_batchnorm(group)``
+    makes those statistics job-wide (one small all-reduce per BatchNorm stage), as on the reference's single device.
     ``patch_size`` is accepted and ignored, as in the reference."""
     _mivit_embedding = N.EMBED_EXTERNAL
+    _sync_bn = False
+    _sync_group = None
+
+    def sync_batchnorm(self, group=None, enabled: bool = True):
+        """Take the training-mode BatchNorm statistics over every rank of ``group`` (torch.distributed)."""
+        self._sync_bn, self._sync_group = bool(enabled), group
+        return self
 
     def __init__(self, patch_size=7, embed_dim=128):
         super().__init__()
@@ -273,7 +281,12 @@ class DeepResNetEmbedding(nn.Module):
             params += [conv.weight, bn.weight, bn.bias]
             running.append((bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None))
         params += [self.fc.weight, self.fc.bias]
-        out = _ops.deepresnet_train(frames, dtype, pairs[0][1].momentum, pairs[0][1].eps, running, params)
+        import torch.distributed as dist
+        if self._sync_bn and dist.is_available() and dist.is_initialized() and dist.get_world_size(self._sync_group) > 1:
+            out = _ops.deepresnet_train_sync(frames, dtype, pairs[0][1].momentum, pairs[0][1].eps, running, params,
+                                             self._sync_group)
+        else:
+            out = _ops.deepresnet_train(frames, dtype, pairs[0][1].momentum, pairs[0][1].eps, running, params)
         with torch.no_grad():
             for _, bn in pairs:
                 if bn.track_running_stats:
@@ -288,6 +301,9 @@ class DeepResNetEmbedding(nn.Module):
             return _ops.deepresnet_eval(x.reshape(b * n, h, w), self.folded(dtype), self.fc.out_features).view(b, n, -1)
         if self._native_train_ok(x):
             return self._forward_native_train(x.reshape(b * n, h, w)).view(b, n, -1)
+        if self.training and self._sync_bn:
+            raise RuntimeError("synchronised BatchNorm needs the native DeepResNet training kernels (GPU tensors, square "
+                               "frames, equal BatchNorm settings); there is no per-rank fallback")
         if self._native_infer_ok(x):          # frame too large for the fused kernel: layer-by-layer kernels, running stats
             pairs = self._conv_bn_pairs()
             dtype = torch.bfloat16 if getattr(self, "_mivit_precision", "fp32") == "bf16" else torch.float32

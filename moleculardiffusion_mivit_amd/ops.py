@@ -230,6 +230,79 @@ class _DeepResNetTrain(torch.autograd.Function):
         return (None, None, None, None, None, *grads)
 
 
+DEEPRESNET_STAGES = 6
+
+
+class _DeepResNetTrainSync(torch.autograd.Function):
+    """_DeepResNetTrain with BatchNorm statistics synchronised over a process group: the native forward /
+    backward run stage by stage with one small fp64 all-reduce of the BatchNorm sums between stages, so every rank
+    normalises with the statistics of the whole minibatch -- what the single-device reference (models.py:206-225,233)
+    computes.  d gamma / d beta stay per-rank sums like every other parameter gradient (the DP all-reduce averages them)."""
+
+    @staticmethod
+    def forward(ctx, x, dtype_code, momentum, eps, running, group, *params):
+        import torch.distributed as dist
+        n, p, _ = x.shape
+        e = params[21].shape[0]
+        prm = N.DeepResNetParams()
+        for i in range(7):
+            w, g, b = params[3 * i:3 * i + 3]
+            rm, rv = running[i]
+            prm.conv[i] = N.ConvBn(w.data_ptr(), g.data_ptr(), b.data_ptr(), rm.data_ptr() if rm is not None else None,
+                                   rv.data_ptr() if rv is not None else None)
+        prm.fc_weight, prm.fc_bias = params[21].data_ptr(), params[22].data_ptr()
+        nbytes = N.lib.mivit_deepresnet_train_workspace_bytes(dtype_code, n, p, e)
+        if nbytes == 0:
+            raise N.MivitError(f"DeepResNet training kernels do not support frame side {p}")
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        tokens = torch.empty(n, e, device=x.device, dtype=torch.float32)
+        count = torch.full((1,), float(n * p * p), dtype=torch.float64, device=x.device)
+        dist.all_reduce(count, group=group)
+        stats = torch.zeros(2, 3, 128, dtype=torch.float64, device=x.device)
+        for stage in range(DEEPRESNET_STAGES):
+            N.check(N.lib.mivit_deepresnet_train_fwd_stage(dtype_code, ctypes.addressof(prm), _p(x), n, p, e, momentum, eps,
+                                                           _p(tokens), _p(ws), nbytes, stage, _p(count), _p(stats), _s(x)),
+                    "mivit_deepresnet_train_fwd_stage")
+            if stage + 1 < DEEPRESNET_STAGES:
+                dist.all_reduce(stats, group=group)
+        ctx.save_for_backward(x, ws, count, *params)
+        ctx.meta = (dtype_code, n, p, e, eps, nbytes, group)
+        return tokens
+
+    @staticmethod
+    def backward(ctx, dtokens):
+        import torch.distributed as dist
+        x, ws, count, *params = ctx.saved_tensors
+        dtype_code, n, p, e, eps, nbytes, group = ctx.meta
+        prm, gr = N.DeepResNetParams(), N.DeepResNetGrads()
+        grads = [torch.empty_like(t) for t in params]
+        for i in range(7):
+            w, g, b = params[3 * i:3 * i + 3]
+            prm.conv[i] = N.ConvBn(w.data_ptr(), g.data_ptr(), b.data_ptr(), None, None)
+            gr.conv[i] = N.ConvBnGrad(*[t.data_ptr() for t in grads[3 * i:3 * i + 3]])
+        prm.fc_weight, prm.fc_bias = params[21].data_ptr(), params[22].data_ptr()
+        gr.fc_weight, gr.fc_bias = grads[21].data_ptr(), grads[22].data_ptr()
+        dtokens = dtokens.contiguous().float()
+        stats = torch.zeros(2, 3, 128, dtype=torch.float64, device=x.device)
+        for stage in range(DEEPRESNET_STAGES):
+            N.check(N.lib.mivit_deepresnet_train_bwd_stage(dtype_code, ctypes.addressof(prm), _p(x), _p(dtokens), n, p, e, eps,
+                                                           ctypes.addressof(gr), _p(ws), nbytes, stage, _p(count), _p(stats),
+                                                           _s(x)), "mivit_deepresnet_train_bwd_stage")
+            if stage + 1 < DEEPRESNET_STAGES:
+                dist.all_reduce(stats[0], group=group)       # stats[1] keeps this rank's sums (d gamma / d beta)
+        return (None, None, None, None, None, None, *grads)
+
+
+def deepresnet_train_sync(x, dtype, momentum, eps, running, params, group=None):
+    """deepresnet_train with BatchNorm statistics taken over every rank of ``group`` (default process group)."""
+    _gpu(x, *params)
+    for t in params:
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise TypeError("DeepResNet parameters must be contiguous float32 tensors")
+    return _DeepResNetTrainSync.apply(x.contiguous().float(), N.BF16 if dtype == torch.bfloat16 else N.F32, float(momentum),
+                                      float(eps), running, group, *params)
+
+
 def deepresnet_train(x, dtype, momentum, eps, running, params):
     """x [N,P,P] fp32 frames -> tokens [N,E] fp32; ``running`` = 7 pairs (running_mean, running_var) updated in place
     (or (None, None)); ``params`` = the 23 parameter tensors (fp32, contiguous, reference layouts)."""
