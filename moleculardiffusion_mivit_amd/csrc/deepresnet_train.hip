@@ -132,18 +132,124 @@ __device__ __forceinline__ void fill_rows(T *tile, const TileSrc &s, const int *
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// LDS image layout of the convolution kernels (16-bit types): conflict-free A-fragment reads.
+// A fragment read is one ds_read_b128 per lane: lane (cq, g) takes the 16 B k-chunk g of output pixel cq's cell.  The
+// instruction is served in groups of 16 lanes that mix two k-chunks, so with a cell stride of s 16-byte units the group is
+// conflict-free only for s = 2, 6, 10, 14 (mod 16): 32 B of padding per cell for 32 / 64 / 128 channels (16 B made every
+// group 2-way).  Consecutive output pixels must also look like consecutive cells to the banks, so each image row is padded
+// to cancel the two halo cells a row wrap skips, and each slot to cancel the jump to the next frame (measured before:
+// SQ_LDS_BANK_CONFLICT = 40-54 % of SQ_LDS_IDX_ACTIVE on every convolution; model: 2.1-2.9 -> 1.05 cycles per group).
+// fp32 (parity mode; ds_read_b32 fragments) keeps the plain layout.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T, int C>
+struct Img {
+    static constexpr int PADE = sizeof(T) == 2 ? 16 : 4;                    // elements of padding per cell
+    static constexpr int CS = C + PADE, CSB = CS * (int)sizeof(T);
+    static constexpr int RPB = sizeof(T) == 2 ? (256 - (2 * CSB) % 256) % 256 : 0;     // row padding, bytes
+    int rowe, slote;                                                         // elements per image row / per slot
+    __host__ __device__ Img(int th, int tw) {
+        rowe = (tw + 2) * CS + RPB / (int)sizeof(T);
+        const int rowb = rowe * (int)sizeof(T);
+        const int spb = sizeof(T) == 2 ? (((th * tw * CSB - (th + 2) * rowb) % 256) + 256) % 256 : 0;
+        slote = (th + 2) * rowe + spb / (int)sizeof(T);
+    }
+};
+
+// cellsrc[cell] = global pixel row behind the cell (or -1), cellpos[cell] = element offset of the cell in an Img layout
+__device__ __forceinline__ void build_cell_tables(const Geom &g, int group, int *cellsrc, int *cellpos, int cs, int rowe, int slote,
+                                                  int tid) {
+    const int W2 = g.tw + 2;
+    for (int i = tid; i < g.F * g.HPt; i += 512) {
+        cellsrc[i] = cell_source(g, group, i);
+        const int s = i / g.HPt, rem = i - s * g.HPt, cy = rem / W2, cx = rem - cy * W2;
+        cellpos[i] = s * slote + cy * rowe + cx * cs;
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void unpack16(const uint4 &v, float *out) {
+    if constexpr (sizeof(T) == 4) {
+        out[0] = __uint_as_float(v.x); out[1] = __uint_as_float(v.y); out[2] = __uint_as_float(v.z); out[3] = __uint_as_float(v.w);
+    } else {
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { out[2 * i] = __uint_as_float(w[i] << 16); out[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+    }
+}
+
+// Fill one Img image: every cell is written (loaded + normalised, or zero).  A thread's channel chunk is the same for all
+// its cells (NT is a multiple of the chunks per cell), so the BatchNorm coefficients sit in registers, and the cells are
+// taken U at a time with all their global loads issued before the first use: one cell per iteration left every load's HBM
+// latency exposed (the loop was ~2/3 of a workgroup's life).  Halo / dead cells load row 0 (cached) and store zero.
+template <typename T, int C, int PRO, int U = 8>
+__device__ __forceinline__ void fill_image(T *tile, const TileSrc &s, const Geom &g, const int *cellsrc, const int *cellpos, int tid) {
+    constexpr int V = vec_el<T>(), CV = C / V, CPP = NT / CV;          // cells per pass of the workgroup
+    static_assert(NT % CV == 0, "fixed channel chunk per thread");
+    const int c = (tid % CV) * V, ncell = g.F * g.HPt;
+    float k0[V], k1[V], k2[V], k3[V];        // (same expressions, in the same order, as transform_store / the mask and pooling kernels)
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+        k2[e] = k3[e] = 0.f;
+        if (PRO == PRO_ACT1) { k0[e] = s.ca[2 * CSTR + c + e]; k1[e] = s.ca[3 * CSTR + c + e]; }
+        else if (PRO == PRO_ACT2) { k0[e] = s.ca[2 * CSTR + c + e]; k1[e] = s.ca[3 * CSTR + c + e]; k2[e] = s.cb[2 * CSTR + c + e]; k3[e] = s.cb[3 * CSTR + c + e]; }
+        else { k0[e] = s.ca[c + e]; k1[e] = s.ca[CSTR + c + e]; k2[e] = s.ca[2 * CSTR + c + e]; }
+    }
+    const T *p0 = static_cast<const T *>(s.p0) + c, *p1 = static_cast<const T *>(s.p1) + c;
+    for (int base = tid / CV; base < ncell; base += U * CPP) {
+        int src[U], pos[U];
+        uint4 ra[U], rb[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int cell = base + u * CPP, cc = cell < ncell ? cell : base;
+            src[u] = cellsrc[cc]; pos[u] = cell < ncell ? cellpos[cc] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t row = src[u] > 0 ? src[u] : 0;
+            ra[u] = *reinterpret_cast<const uint4 *>(p0 + row * C);
+            if (PRO != PRO_ACT1) rb[u] = *reinterpret_cast<const uint4 *>(p1 + row * C);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float a[V], b[V], o[V];
+            unpack16<T>(ra[u], a);
+            if (PRO != PRO_ACT1) unpack16<T>(rb[u], b);
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                float v;
+                if (PRO == PRO_ACT1) v = fmaxf(k0[e] * a[e] + k1[e], 0.f);
+                else if (PRO == PRO_ACT2) v = fmaxf(k0[e] * a[e] + k1[e] + k2[e] * b[e] + k3[e], 0.f);
+                else v = k0[e] * a[e] + k1[e] + k2[e] * b[e];
+                o[e] = src[u] >= 0 ? v : 0.f;
+            }
+            if (pos[u] >= 0) store16(tile + pos[u] + c, o);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // implicit-GEMM core: acc[j][mt] += sum_{tap, ci} in[pixel(mt) + tap][ci] * W[co(j)][tap][ci]   (two column tiles / wave)
 // weight fragments are prefetched one chunk (G k-steps) ahead: they come from L2, the image fragments from LDS
 // ---------------------------------------------------------------------------------------------------------------
-template <typename T, int CIN, int TAPS, int MT>
-__device__ __forceinline__ void conv_accum2(f32x4 (&acc)[2][MT], const T *in, const T *w0, const T *w1,
-                                            const int (&hidx)[MT], int nm, int HW2, int lane) {
+// The first MTC row tiles are computed unconditionally (dead ones read a valid cell and are ignored by the epilogue), so the
+// loop body has no branch, and the schedule is pinned with sched_group_barrier: left alone the scheduler serialises
+// read -> wait -> 2 MFMAs per tile to save registers (SQ_WAIT_ANY 0.68, MFMA busy 0.23 on the 128 -> 128 convolution).
+// Per chunk of two k-steps: all fragment reads of step 0, then step 0's MFMAs with step 1's reads slotted in between them,
+// then step 1's MFMAs.  Weight fragments (from L2) are prefetched one chunk ahead.
+template <typename T, int CIN, int TAPS, int MT, int MTC>
+__device__ __forceinline__ void conv_accum2_t(f32x4 (&acc)[2][MT], const T *in, const T *w0, const T *w1,
+                                              const int (&hidx)[MT], int rowe, int lane) {
+    // hidx[mt] = element offset of this lane's output pixel in the Img layout; rowe = elements per image row
     typedef typename Mma<T>::Frag Frag;
-    constexpr int KS = Mma<T>::KS, KL = sizeof(T) == 2 ? 8 : 1, CS = CIN + pad_el<T>();
-    constexpr int NC = CIN / KS, TOT = TAPS * NC, G = 2, NCH = (TOT + G - 1) / G;
+    constexpr int KS = Mma<T>::KS, KL = sizeof(T) == 2 ? 8 : 1, CS = Img<T, CIN>::CS;
+    constexpr int NC = CIN / KS, TOT = TAPS * NC, G = 2, NCH = TOT / G;
     static_assert(CIN % KS == 0, "channel count must be a multiple of the MFMA k step");
     const int g = lane >> 4;
     w0 += g * KL; w1 += g * KL; in += g * KL;
+    auto offset = [&](int s) {
+        const int tap = s / NC, c0 = (s - tap * NC) * KS;
+        return (TAPS == 9 ? ((tap / 3 - 1) * rowe + (tap % 3 - 1) * CS) : 0) + c0;
+    };
     Frag cur[2][G], nxt[2][G];
 #pragma unroll
     for (int j = 0; j < G; ++j) {
@@ -152,32 +258,59 @@ __device__ __forceinline__ void conv_accum2(f32x4 (&acc)[2][MT], const T *in, co
     }
 #pragma unroll 1
     for (int ch = 0; ch < NCH; ++ch) {
-        if (ch + 1 < NCH) {
 #pragma unroll
-            for (int j = 0; j < G; ++j) {
-                int s = (ch + 1) * G + j;
-                s = s < TOT ? s : TOT - 1;
-                nxt[0][j] = frag_at<T>(w0 + s * KS); nxt[1][j] = frag_at<T>(w1 + s * KS);
-            }
+        for (int j = 0; j < G; ++j) {                       // (clamped: the last prefetch re-reads the final k-step)
+            int s = (ch + 1) * G + j;
+            s = s < TOT ? s : TOT - 1;
+            nxt[0][j] = frag_at<T>(w0 + s * KS); nxt[1][j] = frag_at<T>(w1 + s * KS);
+        }
+        const int o0 = offset(ch * G), o1 = offset(ch * G + 1);
+        Frag a0[MTC], a1[MTC];
+#pragma unroll
+        for (int mt = 0; mt < MTC; ++mt) a0[mt] = frag_at<T>(in + hidx[mt] + o0);
+#pragma unroll
+        for (int mt = 0; mt < MTC; ++mt) {
+            acc[0][mt] = Mma<T>::mma(a0[mt], cur[0][0], acc[0][mt]);
+            acc[1][mt] = Mma<T>::mma(a0[mt], cur[1][0], acc[1][mt]);
+            a1[mt] = frag_at<T>(in + hidx[mt] + o1);
         }
 #pragma unroll
-        for (int j = 0; j < G; ++j) {
-            const int s = ch * G + j;
-            if (s < TOT) {
-                const int tap = s / NC, c0 = (s - tap * NC) * KS;
-                const int off = TAPS == 9 ? ((tap / 3 - 1) * HW2 + (tap % 3 - 1)) : 0;
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-                    if (mt < nm) {
-                        const Frag a = frag_at<T>(in + (hidx[mt] + off) * CS + c0);
-                        acc[0][mt] = Mma<T>::mma(a, cur[0][j], acc[0][mt]);
-                        acc[1][mt] = Mma<T>::mma(a, cur[1][j], acc[1][mt]);
-                    }
-            }
+        for (int mt = 0; mt < MTC; ++mt) {
+            acc[0][mt] = Mma<T>::mma(a1[mt], cur[0][1], acc[0][mt]);
+            acc[1][mt] = Mma<T>::mma(a1[mt], cur[1][1], acc[1][mt]);
         }
+        __builtin_amdgcn_sched_group_barrier(0x100, MTC, 0);
+#pragma unroll
+        for (int mt = 0; mt < MTC; ++mt) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 2 * MTC, 0);
 #pragma unroll
         for (int j = 0; j < G; ++j) { cur[0][j] = nxt[0][j]; cur[1][j] = nxt[1][j]; }
     }
+    if constexpr (TOT % G != 0) {                           // odd number of k-steps: the last one alone
+        const int o0 = offset(TOT - 1);
+        Frag a0[MTC];
+#pragma unroll
+        for (int mt = 0; mt < MTC; ++mt) a0[mt] = frag_at<T>(in + hidx[mt] + o0);
+#pragma unroll
+        for (int mt = 0; mt < MTC; ++mt) {
+            acc[0][mt] = Mma<T>::mma(a0[mt], cur[0][0], acc[0][mt]);
+            acc[1][mt] = Mma<T>::mma(a0[mt], cur[1][0], acc[1][mt]);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, MTC, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 2 * MTC, 0);
+    }
+}
+
+template <typename T, int CIN, int TAPS, int MT>
+__device__ __forceinline__ void conv_accum2(f32x4 (&acc)[2][MT], const T *in, const T *w0, const T *w1,
+                                            const int (&hidx)[MT], int nm, int rowe, int lane) {
+    constexpr int MH = (MT + 1) / 2;
+    if (nm <= 0) return;
+    if (nm > MH) conv_accum2_t<T, CIN, TAPS, MT, MT>(acc, in, w0, w1, hidx, rowe, lane);       // all tiles (dead ones wasted)
+    else conv_accum2_t<T, CIN, TAPS, MT, MH>(acc, in, w0, w1, hidx, rowe, lane);              // the first half (small groups)
 }
 
 struct ConvArgs {
@@ -193,6 +326,11 @@ __device__ __forceinline__ void conv_epilogue(const f32x4 (&acc)[2][MT], T *out,
                                               int mt0, int nm, int ng, int lane, int wave, int tid) {
     constexpr int NG = COUT / 32, MQ = 8 / NG;
     const int g = lane >> 4, cq = lane & 15;
+    // this lane's output rows (4 consecutive table entries per row tile): one batch of LDS reads, not one per store
+    int4 rows[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+        rows[mt] = mt < nm ? *reinterpret_cast<const int4 *>(rowg + (mt0 + mt) * 16 + 4 * g) : make_int4(-1, -1, -1, -1);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int co = (2 * ng + j) * 16 + cq;
@@ -200,9 +338,10 @@ __device__ __forceinline__ void conv_epilogue(const f32x4 (&acc)[2][MT], T *out,
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
             if (mt < nm) {
+                const int rr[4] = {rows[mt].x, rows[mt].y, rows[mt].z, rows[mt].w};
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int grow = rowg[(mt0 + mt) * 16 + 4 * g + r];
+                    const int grow = rr[r];
                     if (grow >= 0) {
                         const float v = acc[j][mt][r];
                         out[(size_t)grow * COUT + co] = from_f32<T>(v);
@@ -229,46 +368,49 @@ __device__ __forceinline__ void conv_epilogue(const f32x4 (&acc)[2][MT], T *out,
     }
 }
 
-constexpr int ROWS_PAD = MAXM * 16;     // row tables cover all 11 row tiles
 
 // SECOND: 0 none | 1 second OUTPUT out2 = conv1x1(tile A, W2) (forward skip branch) | 2 second INPUT tile B (CIN2 channels,
 // DY prologue) whose 1x1 convolution accumulates into the same output (data gradient of conv1 + skip)
-template <typename T, int CIN, int COUT, int SECOND, int PRO, int CIN2>
-__global__ __launch_bounds__(NT) void drn_conv_kernel(const ConvArgs a) {
+// MM: row tiles per workgroup (MAXM: one workgroup per CU with up to 160 KB of LDS)
+template <typename T, int CIN, int COUT, int SECOND, int PRO, int CIN2, int MM>
+__global__ __launch_bounds__(NT, MM == MAXM ? 2 : 4) void drn_conv_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int NG = COUT / 32, MQ = 8 / NG, MT = (MAXM + MQ - 1) / MQ;
-    constexpr int CS = CIN + pad_el<T>(), CS2 = CIN2 + pad_el<T>();
+    constexpr int ROWS_PAD = MM * 16;
+    constexpr int NG = COUT / 32, MQ = 8 / NG, MT = (MM + MQ - 1) / MQ;
+    static_assert(SECOND != 2 || CIN2 == CIN, "the two input images share one cell table");
     constexpr bool STATS = PRO != PRO_DY;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, cq = lane & 15;
     const Geom &g = a.g;
-    const int W2 = g.tw + 2, NM = (g.RT + 15) / 16;
+    const int NM = (g.RT + 15) / 16;
+    const Img<T, CIN> img(g.th, g.tw);
     T *tileA = reinterpret_cast<T *>(smem);
-    T *tileB = tileA + g.F * g.HPt * CS;
-    float *red = reinterpret_cast<float *>(tileB + (SECOND == 2 ? g.F * g.HPt * CS2 : 0));   // [8][2][32]
+    T *tileB = tileA + g.F * img.slote;
+    float *red = reinterpret_cast<float *>(tileB + (SECOND == 2 ? g.F * img.slote : 0));   // [8][2][32]
     int *rowg = reinterpret_cast<int *>(red + 8 * 2 * 32), *rowc = rowg + ROWS_PAD, *cellsrc = rowc + ROWS_PAD;
+    int *cellpos = cellsrc + g.F * g.HPt;
 
     build_row_tables(g, blockIdx.x, ROWS_PAD, rowg, rowc, tid);
-    build_cell_table(g, blockIdx.x, cellsrc, tid);
+    build_cell_tables(g, blockIdx.x, cellsrc, cellpos, Img<T, CIN>::CS, img.rowe, img.slote, tid);
     __syncthreads();
-    fill_halo<T, CIN, PRO>(tileA, a.A, g, cellsrc, tid);
-    if (SECOND == 2) fill_halo<T, CIN2, PRO_DY>(tileB, a.B, g, cellsrc, tid);
+    fill_image<T, CIN, PRO>(tileA, a.A, g, cellsrc, cellpos, tid);
+    if (SECOND == 2) fill_image<T, CIN2, PRO_DY>(tileB, a.B, g, cellsrc, cellpos, tid);
     __syncthreads();
 
     const int ng = wave % NG, mq = wave / NG, per = (NM + MQ - 1) / MQ, mt0 = mq * per;
     const int nm = max(0, min(per, NM - mt0));
     int hidx[MT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) hidx[mt] = rowc[min((mt0 + mt) * 16 + cq, ROWS_PAD - 1)];
+    for (int mt = 0; mt < MT; ++mt) hidx[mt] = cellpos[rowc[min((mt0 + mt) * 16 + cq, ROWS_PAD - 1)]];
     f32x4 acc[2][MT];
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) { acc[0][mt] = zero; acc[1][mt] = zero; }
 
     const T *w = static_cast<const T *>(a.W) + (size_t)(2 * ng * 16 + cq) * 9 * CIN;
-    conv_accum2<T, CIN, 9, MT>(acc, tileA, w, w + (size_t)16 * 9 * CIN, hidx, nm, W2, lane);
+    conv_accum2<T, CIN, 9, MT>(acc, tileA, w, w + (size_t)16 * 9 * CIN, hidx, nm, img.rowe, lane);
     if (SECOND == 2) {
         const T *w2 = static_cast<const T *>(a.W2) + (size_t)(2 * ng * 16 + cq) * CIN2;
-        conv_accum2<T, CIN2, 1, MT>(acc, tileB, w2, w2 + (size_t)16 * CIN2, hidx, nm, W2, lane);
+        conv_accum2<T, CIN2, 1, MT>(acc, tileB, w2, w2 + (size_t)16 * CIN2, hidx, nm, img.rowe, lane);
     }
     conv_epilogue<T, COUT, MT, STATS>(acc, static_cast<T *>(a.out), STATS ? a.stats + (size_t)blockIdx.x * 2 * COUT : nullptr, red,
                                       rowg, mt0, nm, ng, lane, wave, tid);
@@ -276,7 +418,7 @@ __global__ __launch_bounds__(NT) void drn_conv_kernel(const ConvArgs a) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) { acc[0][mt] = zero; acc[1][mt] = zero; }
         const T *w2 = static_cast<const T *>(a.W2) + (size_t)(2 * ng * 16 + cq) * CIN;
-        conv_accum2<T, CIN, 1, MT>(acc, tileA, w2, w2 + (size_t)16 * CIN, hidx, nm, W2, lane);
+        conv_accum2<T, CIN, 1, MT>(acc, tileA, w2, w2 + (size_t)16 * CIN, hidx, nm, img.rowe, lane);
         conv_epilogue<T, COUT, MT, STATS>(acc, static_cast<T *>(a.out2), a.stats2 + (size_t)blockIdx.x * 2 * COUT, red, rowg, mt0, nm,
                                           ng, lane, wave, tid);
     }
@@ -693,13 +835,22 @@ size_t image_bytes(int dtype, int t, int F, int C) { return (size_t)F * (t + 2) 
 
 // slots per workgroup: as many as fit 176 output pixels and need(F) <= 160 KB of LDS
 template <typename NeedFn>
-int slots_fit(int t, NeedFn need) {
-    int F = (MAXM * 16) / (t * t);
-    while (F >= 1 && need(F) > (size_t)160 * 1024) --F;
+int slots_fit(int t, NeedFn need, int mm = MAXM, size_t cap = (size_t)160 * 1024) {
+    int F = (mm * 16) / (t * t);
+    while (F >= 1 && need(F) > cap) --F;
     return F;
 }
-size_t conv_lds(int dtype, int t, int F, int CIN, int CIN2) {
-    return image_bytes(dtype, t, F, CIN) + (CIN2 ? image_bytes(dtype, t, F, CIN2) : 0) + 8 * 2 * 32 * 4 + 2 * ROWS_PAD * 4 +
+// bytes of one Img<T, C> image of F slots (same arithmetic as the device struct)
+size_t conv_image_bytes(int dtype, int t, int F, int C) {
+    const int es = (int)dtype_size(dtype);
+    if (es != 2) return (size_t)F * (t + 2) * (t + 2) * (C + 4) * es;
+    const int csb = (C + 16) * es, rowb = (t + 2) * csb + (256 - (2 * csb) % 256) % 256;
+    const int spb = (((t * t * csb - (t + 2) * rowb) % 256) + 256) % 256;
+    return (size_t)F * ((size_t)(t + 2) * rowb + spb);
+}
+size_t conv_lds(int dtype, int t, int F, int CIN, int CIN2, int mm = MAXM) {
+    return conv_image_bytes(dtype, t, F, CIN) + (CIN2 ? conv_image_bytes(dtype, t, F, CIN2) : 0) + 8 * 2 * 32 * 4 + 2 * mm * 16 * 4 +
+           (size_t)F * (t + 2) * (t + 2) * 4 +
            (size_t)F * (t + 2) * (t + 2) * 4;
 }
 size_t wgrad_lds(int dtype, int t, int F, int CIN, int COUT /* c_out window held in LDS */) {
@@ -812,21 +963,29 @@ int bn_consume(const Ctx &c, int i, int k) {
     return 0;
 }
 
-template <typename T, int CIN, int COUT, int SECOND, int PRO, int CIN2>
-int run_conv(const Ctx &c, const ConvArgs &proto, int *nblocks) {
+template <typename T, int CIN, int COUT, int SECOND, int PRO, int CIN2, int MM>
+int run_conv_mm(const Ctx &c, const ConvArgs &proto, int *nblocks, int t, int F) {
     ConvArgs a = proto;
-    int t, nt;
-    choose_tile(c.dtype, c.P, &t, &nt);
-    const int F = slots_fit(t, [&](int f) { return conv_lds(c.dtype, t, f, CIN, SECOND == 2 ? CIN2 : 0); });
     a.g = make_geom(c.dtype, c.N, c.P, F);
-    const size_t lds = conv_lds(c.dtype, t, F, CIN, SECOND == 2 ? CIN2 : 0);
-    auto kern = drn_conv_kernel<T, CIN, COUT, SECOND, PRO, CIN2>;
+    const size_t lds = conv_lds(c.dtype, t, F, CIN, SECOND == 2 ? CIN2 : 0, MM);
+    auto kern = drn_conv_kernel<T, CIN, COUT, SECOND, PRO, CIN2, MM>;
     RC(set_lds(kern, lds));
     const int blocks = ceil_div(a.g.units, F);
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(NT), lds, c.s, a);
     MIVIT_LAUNCH_CHECK();
     if (nblocks) *nblocks = blocks;
     return 0;
+}
+
+template <typename T, int CIN, int COUT, int SECOND, int PRO, int CIN2>
+int run_conv(const Ctx &c, const ConvArgs &proto, int *nblocks) {
+    // one workgroup per CU with as many frames as fit: half-size groups, two co-resident per CU (MM = MAXM / 2, <= 80 KB,
+    // <= 128 VGPRs), measured 4-5 % slower at 9 x 9 (bf16) and 20 % slower in fp32 -- the weights are re-streamed per group
+    int t, nt;
+    choose_tile(c.dtype, c.P, &t, &nt);
+    constexpr int C2 = SECOND == 2 ? CIN2 : 0;
+    const int F = slots_fit(t, [&](int f) { return conv_lds(c.dtype, t, f, CIN, C2); });
+    return run_conv_mm<T, CIN, COUT, SECOND, PRO, CIN2, MAXM>(c, proto, nblocks, t, F);
 }
 
 template <typename T>
