@@ -22,9 +22,7 @@
 namespace {
 
 constexpr int NT = 512, MAXM = 22;          // 8 waves; <= 352 output pixels (22 MFMA row tiles) per workgroup
-constexpr int PADB = 16;                    // bytes of padding per pixel row in LDS (bank spread)
 constexpr int CSTR = 128;                   // stride of the per-channel coefficient tables
-template <typename T> constexpr int pad_el() { return PADB / (int)sizeof(T); }
 template <typename T> constexpr int vec_el() { return 16 / (int)sizeof(T); }
 
 const int DRN_CO[7] = {32, 64, 64, 64, 128, 128, 128};
@@ -74,9 +72,6 @@ __device__ __forceinline__ int cell_source(const Geom &g, int group, int cell) {
     if (y < 0 || y >= g.P || x < 0 || x >= g.P) return -1;
     return frame * g.PP + y * g.P + x;
 }
-__device__ __forceinline__ void build_cell_table(const Geom &g, int group, int *cellsrc, int tid) {
-    for (int i = tid; i < g.F * g.HPt; i += 512) cellsrc[i] = cell_source(g, group, i);
-}
 
 // ---------------------------------------------------------------------------------------------------------------
 // normalise-on-load
@@ -89,46 +84,16 @@ struct TileSrc {
     const float *cb;    // ACT2: forward table of BN(y')
 };
 
-template <typename T, int C, int PRO>
-__device__ __forceinline__ void transform_store(T *dst, const TileSrc &s, int64_t grow, int c) {
-    constexpr int V = vec_el<T>();
-    float a[V], b[V], o[V];
-    if (grow < 0) {
-#pragma unroll
-        for (int e = 0; e < V; ++e) o[e] = 0.f;
-    } else {
-        load16(static_cast<const T *>(s.p0) + grow * C + c, a);
-        if (PRO != PRO_ACT1) load16(static_cast<const T *>(s.p1) + grow * C + c, b);
-#pragma unroll
-        for (int e = 0; e < V; ++e) {
-            if (PRO == PRO_ACT1) o[e] = fmaxf(s.ca[2 * CSTR + c + e] * a[e] + s.ca[3 * CSTR + c + e], 0.f);
-            else if (PRO == PRO_ACT2)
-                o[e] = fmaxf(s.ca[2 * CSTR + c + e] * a[e] + s.ca[3 * CSTR + c + e] + s.cb[2 * CSTR + c + e] * b[e] +
-                             s.cb[3 * CSTR + c + e], 0.f);
-            else o[e] = s.ca[c + e] * a[e] + s.ca[CSTR + c + e] + s.ca[2 * CSTR + c + e] * b[e];
-        }
-    }
-    store16(dst, o);
-}
 
-// zero-haloed images of all F slots: every cell is written (loaded + transformed, or zero)
-template <typename T, int C, int PRO>
-__device__ __forceinline__ void fill_halo(T *tile, const TileSrc &s, const Geom &g, const int *cellsrc, int tid) {
-    constexpr int V = vec_el<T>(), CV = C / V, CS = C + pad_el<T>();
-    for (int i = tid; i < g.F * g.HPt * CV; i += NT) {
-        const int cell = i / CV, c = (i - cell * CV) * V;
-        transform_store<T, C, PRO>(tile + cell * CS + c, s, cellsrc[cell], c);
-    }
-}
+template <typename T, int CW, int CTOT, int PRO, int U, typename PosFn>
+__device__ __forceinline__ void fill_batched(T *tile, const TileSrc &s, int n, const int *srcrow, PosFn pos, int c_off, int tid);
 
-// plain row-ordered image [nrows][CB] of the channel window c_off .. c_off + CB of a CTOT-channel tensor (dead rows zero)
+// weight-gradient kernel (accumulators live across the fill: 4 entries in flight): plain row-ordered image [nrows][CB] of
+// the channel window c_off .. c_off + CB (dead rows zero); rows 32 B (16-bit) / 16 B (fp32) apart modulo the bank period
 template <typename T, int CB, int CTOT, int PRO>
 __device__ __forceinline__ void fill_rows(T *tile, const TileSrc &s, const int *rowg, int nrows, int c_off, int tid) {
-    constexpr int V = vec_el<T>(), CV = CB / V, CS = CB + pad_el<T>();
-    for (int i = tid; i < nrows * CV; i += NT) {
-        const int r = i / CV, c = (i - r * CV) * V;
-        transform_store<T, CTOT, PRO>(tile + r * CS + c, s, rowg[r], c_off + c);
-    }
+    constexpr int CS = CB + (sizeof(T) == 2 ? 16 : 4);
+    fill_batched<T, CB, CTOT, PRO, 4>(tile, s, nrows, rowg, [](int r) { return r * CS; }, c_off, tid);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -177,16 +142,18 @@ __device__ __forceinline__ void unpack16(const uint4 &v, float *out) {
     }
 }
 
-// Fill one Img image: every cell is written (loaded + normalised, or zero).  A thread's channel chunk is the same for all
-// its cells (NT is a multiple of the chunks per cell), so the BatchNorm coefficients sit in registers, and the cells are
-// taken U at a time with all their global loads issued before the first use: one cell per iteration left every load's HBM
-// latency exposed (the loop was ~2/3 of a workgroup's life).  Halo / dead cells load row 0 (cached) and store zero.
-template <typename T, int C, int PRO, int U = 8>
-__device__ __forceinline__ void fill_image(T *tile, const TileSrc &s, const Geom &g, const int *cellsrc, const int *cellpos, int tid) {
-    constexpr int V = vec_el<T>(), CV = C / V, CPP = NT / CV;          // cells per pass of the workgroup
+// Fill an LDS image: entry i (a cell or a row) takes the channel window [c_off, c_off + CW) of row srcrow[i] of a
+// CTOT-channel tensor, normalised on the way, and lands at element pos(i); srcrow[i] < 0 stores zero.  A thread's channel
+// chunk is the same for all its entries (NT is a multiple of the chunks per entry), so the BatchNorm coefficients sit in
+// registers, and the entries are taken U at a time with all their global loads issued before the first use: one entry
+// per iteration left every load's HBM latency exposed (the loop was ~2/3 of a convolution workgroup's life).  Zero
+// entries load row 0 (cached).
+template <typename T, int CW, int CTOT, int PRO, int U, typename PosFn>
+__device__ __forceinline__ void fill_batched(T *tile, const TileSrc &s, int n, const int *srcrow, PosFn pos, int c_off, int tid) {
+    constexpr int V = vec_el<T>(), CV = CW / V, EPP = NT / CV;          // entries per pass of the workgroup
     static_assert(NT % CV == 0, "fixed channel chunk per thread");
-    const int c = (tid % CV) * V, ncell = g.F * g.HPt;
-    float k0[V], k1[V], k2[V], k3[V];        // (same expressions, in the same order, as transform_store / the mask and pooling kernels)
+    const int cw = (tid % CV) * V, c = c_off + cw;
+    float k0[V], k1[V], k2[V], k3[V];        // (same expressions, in the same order, as the mask and pooling kernels)
 #pragma unroll
     for (int e = 0; e < V; ++e) {
         k2[e] = k3[e] = 0.f;
@@ -195,19 +162,19 @@ __device__ __forceinline__ void fill_image(T *tile, const TileSrc &s, const Geom
         else { k0[e] = s.ca[c + e]; k1[e] = s.ca[CSTR + c + e]; k2[e] = s.ca[2 * CSTR + c + e]; }
     }
     const T *p0 = static_cast<const T *>(s.p0) + c, *p1 = static_cast<const T *>(s.p1) + c;
-    for (int base = tid / CV; base < ncell; base += U * CPP) {
-        int src[U], pos[U];
+    for (int base = tid / CV; base < n; base += U * EPP) {
+        int src[U], dst[U];
         uint4 ra[U], rb[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int cell = base + u * CPP, cc = cell < ncell ? cell : base;
-            src[u] = cellsrc[cc]; pos[u] = cell < ncell ? cellpos[cc] : -1;
+            const int i = base + u * EPP, ic = i < n ? i : base;
+            src[u] = srcrow[ic]; dst[u] = i < n ? pos(ic) : -1;
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t row = src[u] > 0 ? src[u] : 0;
-            ra[u] = *reinterpret_cast<const uint4 *>(p0 + row * C);
-            if (PRO != PRO_ACT1) rb[u] = *reinterpret_cast<const uint4 *>(p1 + row * C);
+            ra[u] = *reinterpret_cast<const uint4 *>(p0 + row * CTOT);
+            if (PRO != PRO_ACT1) rb[u] = *reinterpret_cast<const uint4 *>(p1 + row * CTOT);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -222,9 +189,15 @@ __device__ __forceinline__ void fill_image(T *tile, const TileSrc &s, const Geom
                 else v = k0[e] * a[e] + k1[e] + k2[e] * b[e];
                 o[e] = src[u] >= 0 ? v : 0.f;
             }
-            if (pos[u] >= 0) store16(tile + pos[u] + c, o);
+            if (dst[u] >= 0) store16(tile + dst[u] + cw, o);
         }
     }
+}
+
+// zero-haloed Img image of all F slots (convolution kernels)
+template <typename T, int C, int PRO, int U = 8>
+__device__ __forceinline__ void fill_image(T *tile, const TileSrc &s, const Geom &g, const int *cellsrc, const int *cellpos, int tid) {
+    fill_batched<T, C, C, PRO, U>(tile, s, g.F * g.HPt, cellsrc, [&](int cell) { return cellpos[cell]; }, 0, tid);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -698,15 +671,20 @@ __global__ __launch_bounds__(NT) void drn_wgrad_kernel(const WgradArgs a) {
     constexpr int WGM = CIN >= 64 ? 2 : 4, WGN = 8 / WGM;
     constexpr int WM = COB / 16 / WGM, WN = CIN / 16 / WGN;
     static_assert(WM >= 1 && WN >= 1 && TAPS * WM * WN <= 36, "wave tile / accumulator budget");
-    constexpr int CSA = CIN + pad_el<T>(), CSD = COB + pad_el<T>();
+    // LDS: the activation image in the Img layout and dy rows 32 B apart modulo 256: the transposing reads take 8
+    // consecutive rows x 32 B per half wave, conflict-free when consecutive rows (cells) sit 8 banks apart
+    // (before: 16 B of padding, SQ_LDS_BANK_CONFLICT = 41-44 % of SQ_LDS_IDX_ACTIVE)
+    constexpr int CSA = Img<T, CIN>::CS, CSD = COB + Img<T, COB>::PADE;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, cq = lane & 15, q = cq >> 2, p = cq & 3;
     const int wm = wave % WGM, wn = wave / WGM;
     const int co_off = blockIdx.y * COB;
     const Geom &gm = a.g;
-    const int W2 = gm.tw + 2, RP = (gm.RT + 31) / 32 * 32;
-    T *tileA = reinterpret_cast<T *>(smem);                     // [F*HPt][CSA]  zero-haloed input activation
-    T *tileD = tileA + gm.F * gm.HPt * CSA;                     // [RP][CSD]     dy window, plain row order, dead rows zero
+    const int RP = (gm.RT + 31) / 32 * 32;
+    const Img<T, CIN> img(gm.th, gm.tw);
+    T *tileA = reinterpret_cast<T *>(smem);                     // Img image: zero-haloed input activation
+    T *tileD = tileA + gm.F * img.slote;                        // [RP][CSD]     dy window, plain row order, dead rows zero
     int *rowg = reinterpret_cast<int *>(tileD + RP * CSD), *hmap = rowg + RP, *cellsrc = hmap + RP;   // [RP], [RP], [F*HPt]
+    int *cellpos = cellsrc + gm.F * gm.HPt;                     // [F*HPt]
     f32x4 acc[TAPS][WM][WN];
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -718,9 +696,10 @@ __global__ __launch_bounds__(NT) void drn_wgrad_kernel(const WgradArgs a) {
     for (int grp = blockIdx.x; grp < a.ngroups; grp += gridDim.x) {
         __syncthreads();
         build_row_tables(gm, grp, RP, rowg, hmap, tid);
-        build_cell_table(gm, grp, cellsrc, tid);
+        build_cell_tables(gm, grp, cellsrc, cellpos, CSA, img.rowe, img.slote, tid);
         __syncthreads();
-        fill_halo<T, CIN, PROA>(tileA, a.A, gm, cellsrc, tid);
+        for (int r = tid; r < RP; r += NT) hmap[r] = cellpos[hmap[r]];          // cell index -> element offset in the image
+        fill_image<T, CIN, PROA, (PROA == PRO_ACT2 ? 2 : 4)>(tileA, a.A, gm, cellsrc, cellpos, tid);
         fill_rows<T, COB, COUT, PRO_DY>(tileD, a.D, rowg, RP, co_off, tid);
         __syncthreads();
         const int ksteps = RP / 32;
@@ -738,12 +717,12 @@ __global__ __launch_bounds__(NT) void drn_wgrad_kernel(const WgradArgs a) {
                 const int hl = hmap[rlo], hh = hmap[rhi];
 #pragma unroll
                 for (int t = 0; t < TAPS; ++t) {
-                    const int off = TAPS == 9 ? ((t / 3 - 1) * W2 + (t % 3 - 1)) : 0;
+                    const int off = TAPS == 9 ? ((t / 3 - 1) * img.rowe + (t % 3 - 1) * CSA) : 0;
 #pragma unroll
                     for (int j = 0; j < WN; ++j) {
                         const int ci0 = (wn * WN + j) * 16 + 4 * p;
-                        const bf16x8 bfr = tr_pair(reinterpret_cast<const bf16 *>(tileA) + (hl + off) * CSA + ci0,
-                                                   reinterpret_cast<const bf16 *>(tileA) + (hh + off) * CSA + ci0);
+                        const bf16x8 bfr = tr_pair(reinterpret_cast<const bf16 *>(tileA) + hl + off + ci0,
+                                                   reinterpret_cast<const bf16 *>(tileA) + hh + off + ci0);
 #pragma unroll
                         for (int i = 0; i < WM; ++i) acc[t][i][j] = Mma<bf16>::mma(af[i], bfr, acc[t][i][j]);
                     }
@@ -758,10 +737,10 @@ __global__ __launch_bounds__(NT) void drn_wgrad_kernel(const WgradArgs a) {
                     const int h = hmap[r];
 #pragma unroll
                     for (int t = 0; t < TAPS; ++t) {
-                        const int off = TAPS == 9 ? ((t / 3 - 1) * W2 + (t % 3 - 1)) : 0;
+                        const int off = TAPS == 9 ? ((t / 3 - 1) * img.rowe + (t % 3 - 1) * CSA) : 0;
 #pragma unroll
                         for (int j = 0; j < WN; ++j) {
-                            const float bfr = reinterpret_cast<const float *>(tileA)[(h + off) * CSA + (wn * WN + j) * 16 + cq];
+                            const float bfr = reinterpret_cast<const float *>(tileA)[h + off + (wn * WN + j) * 16 + cq];
 #pragma unroll
                             for (int i = 0; i < WM; ++i) acc[t][i][j] = Mma<float>::mma(af[i], bfr, acc[t][i][j]);
                         }
@@ -831,7 +810,6 @@ Geom make_geom(int dtype, int N, int P, int F) {
     g.F = F; g.HPt = (t + 2) * (t + 2); g.RT = F * t * t;
     return g;
 }
-size_t image_bytes(int dtype, int t, int F, int C) { return (size_t)F * (t + 2) * (t + 2) * (C * dtype_size(dtype) + PADB); }
 
 // slots per workgroup: as many as fit 176 output pixels and need(F) <= 160 KB of LDS
 template <typename NeedFn>
@@ -855,8 +833,8 @@ size_t conv_lds(int dtype, int t, int F, int CIN, int CIN2, int mm = MAXM) {
 }
 size_t wgrad_lds(int dtype, int t, int F, int CIN, int COUT /* c_out window held in LDS */) {
     const int RP = (F * t * t + 31) / 32 * 32;
-    return image_bytes(dtype, t, F, CIN) + (size_t)RP * (COUT * dtype_size(dtype) + PADB) + (size_t)RP * 8 +
-           (size_t)F * (t + 2) * (t + 2) * 4;
+    return conv_image_bytes(dtype, t, F, CIN) + (size_t)RP * (COUT * dtype_size(dtype) + (dtype_size(dtype) == 2 ? 32 : 16)) +
+           (size_t)RP * 8 + (size_t)2 * F * (t + 2) * (t + 2) * 4;
 }
 int conv0_slots(int t) { return std::max(1, 512 / (t * t)); }
 
