@@ -122,11 +122,12 @@ struct Img {
 
 // cellsrc[cell] = global pixel row behind the cell (or -1), cellpos[cell] = element offset of the cell in an Img layout
 __device__ __forceinline__ void build_cell_tables(const Geom &g, int group, int *cellsrc, int *cellpos, int cs, int rowe, int slote,
-                                                  int tid) {
+                                                  int tid, bool interior_only = false) {
     const int W2 = g.tw + 2;
     for (int i = tid; i < g.F * g.HPt; i += 512) {
-        cellsrc[i] = cell_source(g, group, i);
         const int s = i / g.HPt, rem = i - s * g.HPt, cy = rem / W2, cx = rem - cy * W2;
+        const bool halo = cy == 0 || cy == g.th + 1 || cx == 0 || cx == g.tw + 1;
+        cellsrc[i] = interior_only && halo ? -1 : cell_source(g, group, i);      // (a 1x1 convolution never reads the halo)
         cellpos[i] = s * slote + cy * rowe + cx * cs;
     }
 }
@@ -243,14 +244,14 @@ __device__ __forceinline__ void conv_accum2_t(f32x4 (&acc)[2][MT], const T *in, 
         for (int mt = 0; mt < MTC; ++mt) a0[mt] = frag_at<T>(in + hidx[mt] + o0);
 #pragma unroll
         for (int mt = 0; mt < MTC; ++mt) {
-            acc[0][mt] = Mma<T>::mma(a0[mt], cur[0][0], acc[0][mt]);
-            acc[1][mt] = Mma<T>::mma(a0[mt], cur[1][0], acc[1][mt]);
+            acc[0][mt] = Mma<T>::mma(cur[0][0], a0[mt], acc[0][mt]);
+            acc[1][mt] = Mma<T>::mma(cur[1][0], a0[mt], acc[1][mt]);
             a1[mt] = frag_at<T>(in + hidx[mt] + o1);
         }
 #pragma unroll
         for (int mt = 0; mt < MTC; ++mt) {
-            acc[0][mt] = Mma<T>::mma(a1[mt], cur[0][1], acc[0][mt]);
-            acc[1][mt] = Mma<T>::mma(a1[mt], cur[1][1], acc[1][mt]);
+            acc[0][mt] = Mma<T>::mma(cur[0][1], a1[mt], acc[0][mt]);
+            acc[1][mt] = Mma<T>::mma(cur[1][1], a1[mt], acc[1][mt]);
         }
         __builtin_amdgcn_sched_group_barrier(0x100, MTC, 0);
 #pragma unroll
@@ -269,8 +270,8 @@ __device__ __forceinline__ void conv_accum2_t(f32x4 (&acc)[2][MT], const T *in, 
         for (int mt = 0; mt < MTC; ++mt) a0[mt] = frag_at<T>(in + hidx[mt] + o0);
 #pragma unroll
         for (int mt = 0; mt < MTC; ++mt) {
-            acc[0][mt] = Mma<T>::mma(a0[mt], cur[0][0], acc[0][mt]);
-            acc[1][mt] = Mma<T>::mma(a0[mt], cur[1][0], acc[1][mt]);
+            acc[0][mt] = Mma<T>::mma(cur[0][0], a0[mt], acc[0][mt]);
+            acc[1][mt] = Mma<T>::mma(cur[1][0], a0[mt], acc[1][mt]);
         }
         __builtin_amdgcn_sched_group_barrier(0x100, MTC, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, 2 * MTC, 0);
@@ -292,40 +293,63 @@ struct ConvArgs {
     const void *W, *W2;          // [COUT][9][CIN], [COUT][CIN or CIN2]
     void *out, *out2;            // [N*P*P, COUT]
     float *stats, *stats2;       // [blocks][2][COUT] partial sum / sum of squares
+    int dbg;                     // timing experiments only (MIVIT_DRN_DBG): 1 skip fill, 2 skip MFMA loop, 4 skip epilogue, 8 skip tables
 };
 
+// 4 consecutive channels of one pixel <-> one 8-byte (16-bit types) / 16-byte (fp32) access
+template <typename T>
+__device__ __forceinline__ void store4(T *p, const float *v) {
+    if constexpr (sizeof(T) == 4) {
+        *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+        const uint32_t lo = (uint32_t)from_f32<T>(v[0]).v | ((uint32_t)from_f32<T>(v[1]).v << 16);
+        const uint32_t hi = (uint32_t)from_f32<T>(v[2]).v | ((uint32_t)from_f32<T>(v[3]).v << 16);
+        *reinterpret_cast<uint2 *>(p) = make_uint2(lo, hi);
+    }
+}
+template <typename T>
+__device__ __forceinline__ void load4(const T *p, float *v) {
+    if constexpr (sizeof(T) == 4) {
+        const float4 f = *reinterpret_cast<const float4 *>(p);
+        v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
+    } else {
+        const uint2 u = *reinterpret_cast<const uint2 *>(p);
+        v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
+        v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
+    }
+}
+
+// The accumulators hold the TRANSPOSED product (weights are the MFMA's row operand): acc[j][mt][r] = output pixel
+// (mt0 + mt) * 16 + cq, channel (2 ng + j) * 16 + 4 g + r -- four consecutive channels of one pixel per lane, so a row tile
+// leaves as one 8-byte store per lane (pixel-major accumulators needed 4 two-byte stores: 169 of the 128 -> 128
+// convolution's 1000 us).
 template <typename T, int COUT, int MT, bool STATS>
 __device__ __forceinline__ void conv_epilogue(const f32x4 (&acc)[2][MT], T *out, float *stats, float *red, const int *rowg,
                                               int mt0, int nm, int ng, int lane, int wave, int tid) {
     constexpr int NG = COUT / 32, MQ = 8 / NG;
     const int g = lane >> 4, cq = lane & 15;
-    // this lane's output rows (4 consecutive table entries per row tile): one batch of LDS reads, not one per store
-    int4 rows[MT];
+    int rows[MT];                                  // this lane's output pixel per row tile: one batch of LDS reads
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-        rows[mt] = mt < nm ? *reinterpret_cast<const int4 *>(rowg + (mt0 + mt) * 16 + 4 * g) : make_int4(-1, -1, -1, -1);
+    for (int mt = 0; mt < MT; ++mt) rows[mt] = mt < nm ? rowg[(mt0 + mt) * 16 + cq] : -1;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int co = (2 * ng + j) * 16 + cq;
-        float s = 0.f, ss = 0.f;
+        const int co = (2 * ng + j) * 16 + 4 * g;
+        float s[4] = {0.f, 0.f, 0.f, 0.f}, ss[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
-            if (mt < nm) {
-                const int rr[4] = {rows[mt].x, rows[mt].y, rows[mt].z, rows[mt].w};
+            if (rows[mt] >= 0) {
+                const float v[4] = {acc[j][mt][0], acc[j][mt][1], acc[j][mt][2], acc[j][mt][3]};
+                store4<T>(out + (size_t)rows[mt] * COUT + co, v);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int grow = rr[r];
-                    if (grow >= 0) {
-                        const float v = acc[j][mt][r];
-                        out[(size_t)grow * COUT + co] = from_f32<T>(v);
-                        s += v; ss += v * v;
-                    }
-                }
+                for (int r = 0; r < 4; ++r) { s[r] += v[r]; ss[r] += v[r] * v[r]; }
             }
         if (STATS) {
-            s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
-            ss += __shfl_xor(ss, 16, 64); ss += __shfl_xor(ss, 32, 64);
-            if (g == 0) { red[(wave * 2 + 0) * 32 + j * 16 + cq] = s; red[(wave * 2 + 1) * 32 + j * 16 + cq] = ss; }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                for (int m = 1; m < 16; m <<= 1) { s[r] += __shfl_xor(s[r], m, 64); ss[r] += __shfl_xor(ss[r], m, 64); }
+                if (cq == 0) { red[(wave * 2 + 0) * 32 + j * 16 + 4 * g + r] = s[r]; red[(wave * 2 + 1) * 32 + j * 16 + 4 * g + r] = ss[r]; }
+            }
         }
     }
     if (STATS) {
@@ -343,7 +367,8 @@ __device__ __forceinline__ void conv_epilogue(const f32x4 (&acc)[2][MT], T *out,
 
 
 // SECOND: 0 none | 1 second OUTPUT out2 = conv1x1(tile A, W2) (forward skip branch) | 2 second INPUT tile B (CIN2 channels,
-// DY prologue) whose 1x1 convolution accumulates into the same output (data gradient of conv1 + skip)
+// DY prologue) whose 1x1 convolution accumulates into the same output (data gradient of conv1 + skip) | 3 no 3x3 part:
+// out += conv1x1(tile A, W2) (the skip's data gradient as its own pass, after the 3x3 pass wrote out)
 // MM: row tiles per workgroup (MAXM: one workgroup per CU with up to 160 KB of LDS)
 template <typename T, int CIN, int COUT, int SECOND, int PRO, int CIN2, int MM>
 __global__ __launch_bounds__(NT, MM == MAXM ? 2 : 4) void drn_conv_kernel(const ConvArgs a) {
@@ -363,10 +388,12 @@ __global__ __launch_bounds__(NT, MM == MAXM ? 2 : 4) void drn_conv_kernel(const 
     int *cellpos = cellsrc + g.F * g.HPt;
 
     build_row_tables(g, blockIdx.x, ROWS_PAD, rowg, rowc, tid);
-    build_cell_tables(g, blockIdx.x, cellsrc, cellpos, Img<T, CIN>::CS, img.rowe, img.slote, tid);
+    build_cell_tables(g, blockIdx.x, cellsrc, cellpos, Img<T, CIN>::CS, img.rowe, img.slote, tid, SECOND == 3);
     __syncthreads();
+    if (!(a.dbg & 1)) {
     fill_image<T, CIN, PRO>(tileA, a.A, g, cellsrc, cellpos, tid);
     if (SECOND == 2) fill_image<T, CIN2, PRO_DY>(tileB, a.B, g, cellsrc, cellpos, tid);
+    }
     __syncthreads();
 
     const int ng = wave % NG, mq = wave / NG, per = (NM + MQ - 1) / MQ, mt0 = mq * per;
@@ -379,12 +406,32 @@ __global__ __launch_bounds__(NT, MM == MAXM ? 2 : 4) void drn_conv_kernel(const 
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) { acc[0][mt] = zero; acc[1][mt] = zero; }
 
-    const T *w = static_cast<const T *>(a.W) + (size_t)(2 * ng * 16 + cq) * 9 * CIN;
-    conv_accum2<T, CIN, 9, MT>(acc, tileA, w, w + (size_t)16 * 9 * CIN, hidx, nm, img.rowe, lane);
+    if (a.dbg & 2) {
+    } else if (SECOND == 3) {
+        // start from what the 3x3 pass left in out (all loads of the lane issued together), add the 1x1 convolution
+        const int gq = lane >> 4;
+        const T *out = static_cast<const T *>(a.out);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int grow = mt < nm ? rowg[(mt0 + mt) * 16 + cq] : -1;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float v[4] = {0.f, 0.f, 0.f, 0.f};
+                if (grow >= 0) load4<T>(out + (size_t)grow * COUT + (2 * ng + j) * 16 + 4 * gq, v);
+                acc[j][mt] = f32x4{v[0], v[1], v[2], v[3]};
+            }
+        }
+        const T *w2 = static_cast<const T *>(a.W2) + (size_t)(2 * ng * 16 + cq) * CIN;
+        conv_accum2<T, CIN, 1, MT>(acc, tileA, w2, w2 + (size_t)16 * CIN, hidx, nm, img.rowe, lane);
+    } else {
+        const T *w = static_cast<const T *>(a.W) + (size_t)(2 * ng * 16 + cq) * 9 * CIN;
+        conv_accum2<T, CIN, 9, MT>(acc, tileA, w, w + (size_t)16 * 9 * CIN, hidx, nm, img.rowe, lane);
+    }
     if (SECOND == 2) {
         const T *w2 = static_cast<const T *>(a.W2) + (size_t)(2 * ng * 16 + cq) * CIN2;
         conv_accum2<T, CIN2, 1, MT>(acc, tileB, w2, w2 + (size_t)16 * CIN2, hidx, nm, img.rowe, lane);
     }
+    if (!(a.dbg & 4))
     conv_epilogue<T, COUT, MT, STATS>(acc, static_cast<T *>(a.out), STATS ? a.stats + (size_t)blockIdx.x * 2 * COUT : nullptr, red,
                                       rowg, mt0, nm, ng, lane, wave, tid);
     if (SECOND == 1) {
@@ -944,6 +991,7 @@ int bn_consume(const Ctx &c, int i, int k) {
 template <typename T, int CIN, int COUT, int SECOND, int PRO, int CIN2, int MM>
 int run_conv_mm(const Ctx &c, const ConvArgs &proto, int *nblocks, int t, int F) {
     ConvArgs a = proto;
+    { static const int dbg = [] { const char *e = getenv("MIVIT_DRN_DBG"); return e ? atoi(e) : 0; }(); a.dbg = dbg; }
     a.g = make_geom(c.dtype, c.N, c.P, F);
     const size_t lds = conv_lds(c.dtype, t, F, CIN, SECOND == 2 ? CIN2 : 0, MM);
     auto kern = drn_conv_kernel<T, CIN, COUT, SECOND, PRO, CIN2, MM>;
@@ -964,6 +1012,11 @@ int run_conv(const Ctx &c, const ConvArgs &proto, int *nblocks) {
     constexpr int C2 = SECOND == 2 ? CIN2 : 0;
     const int F = slots_fit(t, [&](int f) { return conv_lds(c.dtype, t, f, CIN, C2); });
     return run_conv_mm<T, CIN, COUT, SECOND, PRO, CIN2, MAXM>(c, proto, nblocks, t, F);
+}
+
+int split_skip_dgrad() {
+    static const int mode = [] { const char *e = getenv("MIVIT_DRN_SPLIT_SKIP"); return e ? atoi(e) : 1; }();
+    return mode;
 }
 
 template <typename T>
@@ -1145,8 +1198,18 @@ int backward_t(const Ctx &c, const float *x, const float *dtokens, const mivit_d
         RC(bwd_consume(c, 4, 1, nb, gr));
         RC((run_wgrad<T, 64, 128, 9, PRO_ACT2>(c, o1, dy21, gr->conv[4].weight)));
         a = ConvArgs{};
-        a.A = dy21; a.B = dy2s; a.W = at(c.ws, c.w.wd[4]); a.W2 = at(c.ws, c.w.wd[6]); a.out = X3;   // d o1 -> X3 [R,64]
-        RC((run_conv<T, 128, 64, 2, PRO_DY, 128>(c, a, nullptr)));
+        // d o1 -> X3 [R,64]: the 3x3 pass, then the skip's 1x1 pass adds to it (one kernel with both images in LDS holds
+        // half the frames per workgroup and re-streams the weights twice as often: 1.74 ms vs the two passes' sum)
+        if (split_skip_dgrad()) {
+            a.A = dy21; a.W = at(c.ws, c.w.wd[4]); a.out = X3;
+            RC((run_conv<T, 128, 64, 0, PRO_DY, 128>(c, a, nullptr)));
+            a = ConvArgs{};
+            a.A = dy2s; a.W2 = at(c.ws, c.w.wd[6]); a.out = X3;
+            RC((run_conv<T, 128, 64, 3, PRO_DY, 128>(c, a, nullptr)));
+        } else {
+            a.A = dy21; a.B = dy2s; a.W = at(c.ws, c.w.wd[4]); a.W2 = at(c.ws, c.w.wd[6]); a.out = X3;
+            RC((run_conv<T, 128, 64, 2, PRO_DY, 128>(c, a, nullptr)));
+        }
         // ---- block 1 output: g1 in place in X3 ; BatchNorm 2 (conv2) and 3 (skip)
         RC((run_mask<T, 64, true, false>(c, X3, 2, 3, X3, &nb)));
         RC(bwd_produce(c, 64, nb));
@@ -1165,8 +1228,16 @@ int backward_t(const Ctx &c, const float *x, const float *dtokens, const mivit_d
         RC(bwd_consume(c, 1, 1, nb, gr));
         RC((run_wgrad<T, 32, 64, 9, PRO_ACT1>(c, a0, dy11, gr->conv[1].weight)));
         a = ConvArgs{};
-        a.A = dy11; a.B = dy1s; a.W = at(c.ws, c.w.wd[1]); a.W2 = at(c.ws, c.w.wd[3]); a.out = X2;   // d a0 -> X2 [R,32]
-        RC((run_conv<T, 64, 32, 2, PRO_DY, 64>(c, a, nullptr)));
+        if (split_skip_dgrad()) {                                                              // d a0 -> X2 [R,32]
+            a.A = dy11; a.W = at(c.ws, c.w.wd[1]); a.out = X2;
+            RC((run_conv<T, 64, 32, 0, PRO_DY, 64>(c, a, nullptr)));
+            a = ConvArgs{};
+            a.A = dy1s; a.W2 = at(c.ws, c.w.wd[3]); a.out = X2;
+            RC((run_conv<T, 64, 32, 3, PRO_DY, 64>(c, a, nullptr)));
+        } else {
+            a.A = dy11; a.B = dy1s; a.W = at(c.ws, c.w.wd[1]); a.W2 = at(c.ws, c.w.wd[3]); a.out = X2;
+            RC((run_conv<T, 64, 32, 2, PRO_DY, 64>(c, a, nullptr)));
+        }
         RC((run_mask<T, 32, false, false>(c, X2, 0, 0, X2, &nb)));
         RC(bwd_produce(c, 32, nb));
     }
