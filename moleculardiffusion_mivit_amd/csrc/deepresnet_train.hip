@@ -485,19 +485,26 @@ __global__ __launch_bounds__(NT) void drn_conv0_kernel(const float *x, const flo
 }
 
 // weight gradient of the first convolution: dW0[co][tap] = sum_r dy0[r][co] * x[pixel(r) + tap]
+// thread = (row set rs, 8-channel chunk cv): one 16-byte load of g and of y per row (a lane per channel made 2-byte loads:
+// 357 us for 0.3 GB), all of a group's rows in flight before the first use; [9 taps][8 channels] partial sums in registers
 template <typename T>
 __global__ __launch_bounds__(NT) void drn_wgrad0_kernel(const float *x, const TileSrc d, float *slab, const Geom g, int ngroups) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, W2 = g.tw + 2;
+    constexpr int V = vec_el<T>(), CV = 32 / V, NRS = NT / CV, U = 4;
+    const int tid = threadIdx.x, W2 = g.tw + 2, lane = tid & 63, wave = tid >> 6;
     float *xs = reinterpret_cast<float *>(smem);            // [F][HPt]
-    float *red = xs + g.F * g.HPt;                          // [16][32*9]
+    float *red = xs + g.F * g.HPt;                          // [8 waves][288]
     int *rowg = reinterpret_cast<int *>(red + 16 * 288), *rowc = rowg + g.RT;
-    const int co = tid & 31, rs = tid >> 5;
-    const float k = d.ca[co], c0 = d.ca[CSTR + co], c1 = d.ca[2 * CSTR + co];
-    const T *gsrc = static_cast<const T *>(d.p0), *ysrc = static_cast<const T *>(d.p1);
-    float acc[9];
+    const int c = (tid % CV) * V, rs = tid / CV;
+    float k[V], c0[V], c1[V];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) acc[t] = 0.f;
+    for (int e = 0; e < V; ++e) { k[e] = d.ca[c + e]; c0[e] = d.ca[CSTR + c + e]; c1[e] = d.ca[2 * CSTR + c + e]; }
+    const T *gsrc = static_cast<const T *>(d.p0) + c, *ysrc = static_cast<const T *>(d.p1) + c;
+    float acc[9][V];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[t][e] = 0.f;
     for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
         __syncthreads();
         build_row_tables(g, grp, g.RT, rowg, rowc, tid);
@@ -506,22 +513,55 @@ __global__ __launch_bounds__(NT) void drn_wgrad0_kernel(const float *x, const Ti
             xs[i] = src >= 0 ? x[src] : 0.f;
         }
         __syncthreads();
-        for (int r = rs; r < g.RT; r += NT / 32) {
-            const int grow = rowg[r];
-            if (grow < 0) continue;
-            const float dy = k * to_f32(gsrc[(size_t)grow * 32 + co]) + c0 + c1 * to_f32(ysrc[(size_t)grow * 32 + co]);
-            const int h = rowc[r];
+        for (int base = rs; base < g.RT; base += U * NRS) {
+            int grow[U], h[U];
+            uint4 rg[U], ry[U];
 #pragma unroll
-            for (int t = 0; t < 9; ++t) acc[t] += dy * xs[h + (t / 3 - 1) * W2 + (t % 3 - 1)];
+            for (int u = 0; u < U; ++u) {
+                const int r = base + u * NRS, rc = r < g.RT ? r : base;
+                grow[u] = r < g.RT ? rowg[rc] : -1; h[u] = rowc[rc];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const size_t row = grow[u] > 0 ? grow[u] : 0;
+                rg[u] = *reinterpret_cast<const uint4 *>(gsrc + row * 32); ry[u] = *reinterpret_cast<const uint4 *>(ysrc + row * 32);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                float gv[V], yv[V], xv[9];
+                unpack16<T>(rg[u], gv); unpack16<T>(ry[u], yv);
+#pragma unroll
+                for (int t = 0; t < 9; ++t) xv[t] = grow[u] >= 0 ? xs[h[u] + (t / 3 - 1) * W2 + (t % 3 - 1)] : 0.f;
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    const float dy = k[e] * gv[e] + c0[e] + c1[e] * yv[e];
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) acc[t][e] += dy * xv[t];
+                }
+            }
         }
     }
-    __syncthreads();
+    // lanes of a wave that share a channel chunk (lane % CV) -> lane < CV, then the 8 waves through LDS
 #pragma unroll
-    for (int t = 0; t < 9; ++t) red[rs * 288 + co * 9 + t] = acc[t];
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            float v = acc[t][e];
+#pragma unroll
+            for (int m = CV; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
+            acc[t][e] = v;
+        }
+    __syncthreads();
+    if (lane < CV) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int e = 0; e < V; ++e) red[wave * 288 + (c + e) * 9 + t] = acc[t][e];
+    }
     __syncthreads();
     if (tid < 288) {
         float v = 0.f;
-        for (int kk = 0; kk < NT / 32; ++kk) v += red[kk * 288 + tid];
+        for (int kk = 0; kk < NT / 64; ++kk) v += red[kk * 288 + tid];
         slab[(size_t)blockIdx.x * 288 + tid] = v;
     }
 }
@@ -590,13 +630,40 @@ __global__ void drn_sync_reduce_kernel(const float *part, int nb, int W, double 
 // ---------------------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(128) void drn_pool_kernel(const T *ya, const T *yb, const float *ca, const float *cb, float *pooled, int PP) {
-    const int c = threadIdx.x;
-    const size_t base = (size_t)blockIdx.x * PP * 128;
-    const float sa = ca[2 * CSTR + c], ha = ca[3 * CSTR + c], sb = cb[2 * CSTR + c], hb = cb[3 * CSTR + c];
+    // one frame per workgroup; thread = (pixel set ps, 8-channel chunk): 16-byte loads, 4 pixels in flight per thread
+    constexpr int V = vec_el<T>(), CV = 128 / V, NPS = 128 / CV, U = 4;
+    __shared__ float red[NPS][128];
+    const int c = (threadIdx.x % CV) * V, ps = threadIdx.x / CV;
+    const size_t base = (size_t)blockIdx.x * PP * 128 + c;
+    float sa[V], ha[V], sb[V], hb[V], acc[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+        sa[e] = ca[2 * CSTR + c + e]; ha[e] = ca[3 * CSTR + c + e]; sb[e] = cb[2 * CSTR + c + e]; hb[e] = cb[3 * CSTR + c + e];
+        acc[e] = 0.f;
+    }
+    for (int p0 = ps; p0 < PP; p0 += U * NPS) {
+        uint4 ra[U], rb[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int p = p0 + u * NPS < PP ? p0 + u * NPS : p0;
+            ra[u] = *reinterpret_cast<const uint4 *>(ya + base + (size_t)p * 128); rb[u] = *reinterpret_cast<const uint4 *>(yb + base + (size_t)p * 128);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float a[V], b[V];
+            unpack16<T>(ra[u], a); unpack16<T>(rb[u], b);
+            const bool live = p0 + u * NPS < PP;
+#pragma unroll
+            for (int e = 0; e < V; ++e) acc[e] += live ? fmaxf(sa[e] * a[e] + ha[e] + sb[e] * b[e] + hb[e], 0.f) : 0.f;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < V; ++e) red[ps][c + e] = acc[e];
+    __syncthreads();
     float s = 0.f;
-    for (int p = 0; p < PP; ++p)
-        s += fmaxf(sa * to_f32(ya[base + (size_t)p * 128 + c]) + ha + sb * to_f32(yb[base + (size_t)p * 128 + c]) + hb, 0.f);
-    pooled[(size_t)blockIdx.x * 128 + c] = s / (float)PP;
+#pragma unroll
+    for (int k = 0; k < NPS; ++k) s += red[k][threadIdx.x];
+    pooled[(size_t)blockIdx.x * 128 + threadIdx.x] = s / (float)PP;
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -83,7 +83,7 @@ def test_fp32_adamw_trajectory(name):
         loss = F.mse_loss(m(xs), ls)
         loss.backward()
         opt.step()
-        losses.append(float(loss))
+        losses.append(float(loss.detach()))
     sch.step()
     ref = fx["adamw_losses"]
     assert np.abs(np.array(losses) - ref).max() / np.abs(ref).max() < FP32_TOL
@@ -442,7 +442,7 @@ def test_fp16_training_with_grad_scaler():
         scaler.scale(loss).backward()
         scaler.step(opt)
         scaler.update()
-        losses.append(float(loss)); scales.append(scaler.get_scale())
+        losses.append(float(loss.detach())); scales.append(scaler.get_scale())
         if step == 0:
             assert scales[0] < 2.0 ** 40                      # overflow detected ...
             for k, p in m.named_parameters():
