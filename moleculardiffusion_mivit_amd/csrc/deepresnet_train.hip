@@ -610,9 +610,15 @@ __global__ void drn_bn_running_kernel(int C, const float *gamma, const float *be
 __global__ void drn_part_reduce_kernel(const float *part, int nb, int W, float *out, int nb2) {
     const int w = blockIdx.y * blockDim.x + threadIdx.x, b2 = blockIdx.x;
     if (w >= W) return;
-    double s = 0.0;
-    for (int b = b2; b < nb; b += nb2) s += part[(size_t)b * W + w];
-    out[(size_t)b2 * W + w] = (float)s;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;          // four independent chains: the loads of a round are in flight together
+    int b = b2;
+    for (; b + 3 * nb2 < nb; b += 4 * nb2) {
+        const float v0 = part[(size_t)b * W + w], v1 = part[(size_t)(b + nb2) * W + w];
+        const float v2 = part[(size_t)(b + 2 * nb2) * W + w], v3 = part[(size_t)(b + 3 * nb2) * W + w];
+        s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+    }
+    for (; b < nb; b += nb2) s0 += part[(size_t)b * W + w];
+    out[(size_t)b2 * W + w] = (float)((s0 + s1) + (s2 + s3));
 }
 
 // synchronised BatchNorm: partial [nb][W] -> one fp64 row [W] (the all-reduced operand) and optionally a second copy
