@@ -289,7 +289,7 @@ __device__ __forceinline__ void conv_accum2(f32x4 (&acc)[2][MT], const T *in, co
 
 struct ConvArgs {
     Geom g;
-    TileSrc A, B;
+    TileSrc A;
     const void *W, *W2;          // [COUT][9][CIN], [COUT][CIN or CIN2]
     void *out, *out2;            // [N*P*P, COUT]
     float *stats, *stats2;       // [blocks][2][COUT] partial sum / sum of squares
@@ -366,34 +366,30 @@ __device__ __forceinline__ void conv_epilogue(const f32x4 (&acc)[2][MT], T *out,
 }
 
 
-// SECOND: 0 none | 1 second OUTPUT out2 = conv1x1(tile A, W2) (forward skip branch) | 2 second INPUT tile B (CIN2 channels,
-// DY prologue) whose 1x1 convolution accumulates into the same output (data gradient of conv1 + skip) | 3 no 3x3 part:
-// out += conv1x1(tile A, W2) (the skip's data gradient as its own pass, after the 3x3 pass wrote out)
+// SECOND: 0 none | 1 second OUTPUT out2 = conv1x1(tile A, W2) (forward skip branch) | 3 no 3x3 part:
+// out += conv1x1(tile A, W2) (the skip's data gradient as its own pass, after the 3x3 pass wrote out; a variant that held
+// both gradient images in LDS fitted half the frames per workgroup and was slower than the two passes together)
 // MM: row tiles per workgroup (MAXM: one workgroup per CU with up to 160 KB of LDS)
 template <typename T, int CIN, int COUT, int SECOND, int PRO, int CIN2, int MM>
 __global__ __launch_bounds__(NT, MM == MAXM ? 2 : 4) void drn_conv_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int ROWS_PAD = MM * 16;
     constexpr int NG = COUT / 32, MQ = 8 / NG, MT = (MM + MQ - 1) / MQ;
-    static_assert(SECOND != 2 || CIN2 == CIN, "the two input images share one cell table");
+    static_assert(SECOND == 0 || SECOND == 1 || SECOND == 3, "see above");
     constexpr bool STATS = PRO != PRO_DY;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, cq = lane & 15;
     const Geom &g = a.g;
     const int NM = (g.RT + 15) / 16;
     const Img<T, CIN> img(g.th, g.tw);
     T *tileA = reinterpret_cast<T *>(smem);
-    T *tileB = tileA + g.F * img.slote;
-    float *red = reinterpret_cast<float *>(tileB + (SECOND == 2 ? g.F * img.slote : 0));   // [8][2][32]
+    float *red = reinterpret_cast<float *>(tileA + g.F * img.slote);   // [8][2][32]
     int *rowg = reinterpret_cast<int *>(red + 8 * 2 * 32), *rowc = rowg + ROWS_PAD, *cellsrc = rowc + ROWS_PAD;
     int *cellpos = cellsrc + g.F * g.HPt;
 
     build_row_tables(g, blockIdx.x, ROWS_PAD, rowg, rowc, tid);
     build_cell_tables(g, blockIdx.x, cellsrc, cellpos, Img<T, CIN>::CS, img.rowe, img.slote, tid, SECOND == 3);
     __syncthreads();
-    if (!(a.dbg & 1)) {
-    fill_image<T, CIN, PRO>(tileA, a.A, g, cellsrc, cellpos, tid);
-    if (SECOND == 2) fill_image<T, CIN2, PRO_DY>(tileB, a.B, g, cellsrc, cellpos, tid);
-    }
+    if (!(a.dbg & 1)) fill_image<T, CIN, PRO>(tileA, a.A, g, cellsrc, cellpos, tid);
     __syncthreads();
 
     const int ng = wave % NG, mq = wave / NG, per = (NM + MQ - 1) / MQ, mt0 = mq * per;
@@ -426,10 +422,6 @@ __global__ __launch_bounds__(NT, MM == MAXM ? 2 : 4) void drn_conv_kernel(const 
     } else {
         const T *w = static_cast<const T *>(a.W) + (size_t)(2 * ng * 16 + cq) * 9 * CIN;
         conv_accum2<T, CIN, 9, MT>(acc, tileA, w, w + (size_t)16 * 9 * CIN, hidx, nm, img.rowe, lane);
-    }
-    if (SECOND == 2) {
-        const T *w2 = static_cast<const T *>(a.W2) + (size_t)(2 * ng * 16 + cq) * CIN2;
-        conv_accum2<T, CIN2, 1, MT>(acc, tileB, w2, w2 + (size_t)16 * CIN2, hidx, nm, img.rowe, lane);
     }
     if (!(a.dbg & 4))
     conv_epilogue<T, COUT, MT, STATS>(acc, static_cast<T *>(a.out), STATS ? a.stats + (size_t)blockIdx.x * 2 * COUT : nullptr, red,
@@ -962,7 +954,7 @@ bool drn_train_supported(int dtype, int P) {
     if (P < 1 || P > 4096) return false;
     int t, nt;
     choose_tile(dtype, P, &t, &nt);
-    return slots_fit(t, [&](int F) { return conv_lds(dtype, t, F, 128, 128); }) >= 1 &&
+    return slots_fit(t, [&](int F) { return conv_lds(dtype, t, F, 128, 0); }) >= 1 &&
            slots_fit(t, [&](int F) { return wgrad_lds(dtype, t, F, 128, 64); }) >= 1;
 }
 
@@ -1066,7 +1058,7 @@ int run_conv_mm(const Ctx &c, const ConvArgs &proto, int *nblocks, int t, int F)
     ConvArgs a = proto;
     { static const int dbg = [] { const char *e = getenv("MIVIT_DRN_DBG"); return e ? atoi(e) : 0; }(); a.dbg = dbg; }
     a.g = make_geom(c.dtype, c.N, c.P, F);
-    const size_t lds = conv_lds(c.dtype, t, F, CIN, SECOND == 2 ? CIN2 : 0, MM);
+    const size_t lds = conv_lds(c.dtype, t, F, CIN, 0, MM);
     auto kern = drn_conv_kernel<T, CIN, COUT, SECOND, PRO, CIN2, MM>;
     RC(set_lds(kern, lds));
     const int blocks = ceil_div(a.g.units, F);
@@ -1082,14 +1074,8 @@ int run_conv(const Ctx &c, const ConvArgs &proto, int *nblocks) {
     // <= 128 VGPRs), measured 4-5 % slower at 9 x 9 (bf16) and 20 % slower in fp32 -- the weights are re-streamed per group
     int t, nt;
     choose_tile(c.dtype, c.P, &t, &nt);
-    constexpr int C2 = SECOND == 2 ? CIN2 : 0;
-    const int F = slots_fit(t, [&](int f) { return conv_lds(c.dtype, t, f, CIN, C2); });
+    const int F = slots_fit(t, [&](int f) { return conv_lds(c.dtype, t, f, CIN, 0); });
     return run_conv_mm<T, CIN, COUT, SECOND, PRO, CIN2, MAXM>(c, proto, nblocks, t, F);
-}
-
-int split_skip_dgrad() {
-    static const int mode = [] { const char *e = getenv("MIVIT_DRN_SPLIT_SKIP"); return e ? atoi(e) : 1; }();
-    return mode;
 }
 
 template <typename T>
@@ -1271,18 +1257,12 @@ int backward_t(const Ctx &c, const float *x, const float *dtokens, const mivit_d
         RC(bwd_consume(c, 4, 1, nb, gr));
         RC((run_wgrad<T, 64, 128, 9, PRO_ACT2>(c, o1, dy21, gr->conv[4].weight)));
         a = ConvArgs{};
-        // d o1 -> X3 [R,64]: the 3x3 pass, then the skip's 1x1 pass adds to it (one kernel with both images in LDS holds
-        // half the frames per workgroup and re-streams the weights twice as often: 1.74 ms vs the two passes' sum)
-        if (split_skip_dgrad()) {
-            a.A = dy21; a.W = at(c.ws, c.w.wd[4]); a.out = X3;
-            RC((run_conv<T, 128, 64, 0, PRO_DY, 128>(c, a, nullptr)));
-            a = ConvArgs{};
-            a.A = dy2s; a.W2 = at(c.ws, c.w.wd[6]); a.out = X3;
-            RC((run_conv<T, 128, 64, 3, PRO_DY, 128>(c, a, nullptr)));
-        } else {
-            a.A = dy21; a.B = dy2s; a.W = at(c.ws, c.w.wd[4]); a.W2 = at(c.ws, c.w.wd[6]); a.out = X3;
-            RC((run_conv<T, 128, 64, 2, PRO_DY, 128>(c, a, nullptr)));
-        }
+        // d o1 -> X3 [R,64]: the 3x3 pass, then the skip's 1x1 pass adds to it
+        a.A = dy21; a.W = at(c.ws, c.w.wd[4]); a.out = X3;
+        RC((run_conv<T, 128, 64, 0, PRO_DY, 128>(c, a, nullptr)));
+        a = ConvArgs{};
+        a.A = dy2s; a.W2 = at(c.ws, c.w.wd[6]); a.out = X3;
+        RC((run_conv<T, 128, 64, 3, PRO_DY, 128>(c, a, nullptr)));
         // ---- block 1 output: g1 in place in X3 ; BatchNorm 2 (conv2) and 3 (skip)
         RC((run_mask<T, 64, true, false>(c, X3, 2, 3, X3, &nb)));
         RC(bwd_produce(c, 64, nb));
@@ -1301,16 +1281,11 @@ int backward_t(const Ctx &c, const float *x, const float *dtokens, const mivit_d
         RC(bwd_consume(c, 1, 1, nb, gr));
         RC((run_wgrad<T, 32, 64, 9, PRO_ACT1>(c, a0, dy11, gr->conv[1].weight)));
         a = ConvArgs{};
-        if (split_skip_dgrad()) {                                                              // d a0 -> X2 [R,32]
-            a.A = dy11; a.W = at(c.ws, c.w.wd[1]); a.out = X2;
-            RC((run_conv<T, 64, 32, 0, PRO_DY, 64>(c, a, nullptr)));
-            a = ConvArgs{};
-            a.A = dy1s; a.W2 = at(c.ws, c.w.wd[3]); a.out = X2;
-            RC((run_conv<T, 64, 32, 3, PRO_DY, 64>(c, a, nullptr)));
-        } else {
-            a.A = dy11; a.B = dy1s; a.W = at(c.ws, c.w.wd[1]); a.W2 = at(c.ws, c.w.wd[3]); a.out = X2;
-            RC((run_conv<T, 64, 32, 2, PRO_DY, 64>(c, a, nullptr)));
-        }
+        a.A = dy11; a.W = at(c.ws, c.w.wd[1]); a.out = X2;                                     // d a0 -> X2 [R,32]
+        RC((run_conv<T, 64, 32, 0, PRO_DY, 64>(c, a, nullptr)));
+        a = ConvArgs{};
+        a.A = dy1s; a.W2 = at(c.ws, c.w.wd[3]); a.out = X2;
+        RC((run_conv<T, 64, 32, 3, PRO_DY, 64>(c, a, nullptr)));
         RC((run_mask<T, 32, false, false>(c, X2, 0, 0, X2, &nb)));
         RC(bwd_produce(c, 32, nb));
     }
