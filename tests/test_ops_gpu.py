@@ -340,3 +340,74 @@ def test_wgrad_small_exact(M, N, K):
     dW.zero_()
     N_.check(N_.lib.mivit_wgrad_small(p(dyg), N, p(xg), K, M, N, K, p(dW), None, p(ws), ws.numel(), st), "wgrad_small")
     assert torch.equal(dW.cpu(), (dy.double().t() @ x.double()).float())
+
+
+# ---- DeepResNet staged entry points (synchronised BatchNorm ABI) with a world of one ---------------------------------
+@pytest.mark.parametrize("dtype_name,P,n", [("fp32", 9, 12), ("bf16", 9, 40), ("bf16", 16, 6)])
+def test_deepresnet_staged_entry_points_match_the_single_call(dtype_name, P, n):
+    """mivit_deepresnet_train_fwd_stage / _bwd_stage called stage by stage with *global_count = this rank's own count and no
+    exchange in between must reproduce mivit_deepresnet_train_fwd / _bwd (same kernels; the statistics go through one fp64
+    row instead of the fp32 partial chain, so not bitwise: 1e-5 of the largest value).  Also pins the workspace layout
+    introspection: the raw convolution outputs found at the reported offsets have the reported shapes and are finite."""
+    import ctypes
+    from moleculardiffusion_mivit_amd import _native as N
+    from moleculardiffusion_mivit_amd.helpers.models import DeepResNetEmbedding
+    E = 32
+    torch.manual_seed(P * 100 + n)
+    emb = DeepResNetEmbedding(P, E).cuda()
+    x = (torch.rand(n, P, P, device="cuda") * 1.5 - 0.25).contiguous()
+    dtok = torch.randn(n, E, device="cuda")
+    params = []
+    for conv, bn in emb._conv_bn_pairs():
+        params += [conv.weight.detach(), bn.weight.detach(), bn.bias.detach()]
+    params += [emb.fc.weight.detach(), emb.fc.bias.detach()]
+    code = N.F32 if dtype_name == "fp32" else N.BF16
+    nbytes = N.lib.mivit_deepresnet_train_workspace_bytes(code, n, P, E)
+    assert nbytes > 0
+    off = (ctypes.c_size_t * 16)()
+    N.check(N.lib.mivit_deepresnet_train_workspace_layout(code, n, P, E, ctypes.addressof(off)), "layout")
+    assert off[15] == nbytes and list(off[:15]) == sorted(off[:15])
+    s = torch.cuda.current_stream().cuda_stream
+
+    def run(staged):
+        prm, gr = N.DeepResNetParams(), N.DeepResNetGrads()
+        grads = [torch.zeros_like(t) for t in params]
+        for i in range(7):
+            w, g, b = params[3 * i:3 * i + 3]
+            prm.conv[i] = N.ConvBn(w.data_ptr(), g.data_ptr(), b.data_ptr(), None, None)
+            gr.conv[i] = N.ConvBnGrad(*[t.data_ptr() for t in grads[3 * i:3 * i + 3]])
+        prm.fc_weight, prm.fc_bias = params[21].data_ptr(), params[22].data_ptr()
+        gr.fc_weight, gr.fc_bias = grads[21].data_ptr(), grads[22].data_ptr()
+        ws = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
+        tokens = torch.empty(n, E, device="cuda")
+        if staged:
+            count = torch.full((1,), float(n * P * P), dtype=torch.float64, device="cuda")
+            stats = torch.zeros(2, 3, 128, dtype=torch.float64, device="cuda")
+            for st in range(6):
+                N.check(N.lib.mivit_deepresnet_train_fwd_stage(code, ctypes.addressof(prm), x.data_ptr(), n, P, E, 0.1, 1e-5,
+                                                               tokens.data_ptr(), ws.data_ptr(), nbytes, st, count.data_ptr(),
+                                                               stats.data_ptr(), s), "fwd_stage")
+            for st in range(6):
+                N.check(N.lib.mivit_deepresnet_train_bwd_stage(code, ctypes.addressof(prm), x.data_ptr(), dtok.data_ptr(), n, P, E, 1e-5,
+                                                               ctypes.addressof(gr), ws.data_ptr(), nbytes, st, count.data_ptr(),
+                                                               stats.data_ptr(), s), "bwd_stage")
+        else:
+            N.check(N.lib.mivit_deepresnet_train_fwd(code, ctypes.addressof(prm), x.data_ptr(), n, P, E, 0.1, 1e-5, tokens.data_ptr(),
+                                                     ws.data_ptr(), nbytes, s), "fwd")
+            N.check(N.lib.mivit_deepresnet_train_bwd(code, ctypes.addressof(prm), x.data_ptr(), dtok.data_ptr(), n, P, E, 1e-5,
+                                                     ctypes.addressof(gr), ws.data_ptr(), nbytes, s), "bwd")
+        torch.cuda.synchronize()
+        return tokens, grads, ws
+
+    t_a, g_a, ws = run(False)
+    t_b, g_b, _ = run(True)
+    assert float((t_a - t_b).abs().max()) <= 1e-5 * float(t_a.abs().max())
+    gmax = max(float(g.abs().max()) for g in g_a)
+    for ga, gb in zip(g_a, g_b):
+        assert float((ga - gb).abs().max()) <= 1e-5 * gmax + (3e-3 * gmax if dtype_name == "bf16" else 0.0)
+    es = 4 if dtype_name == "fp32" else 2
+    y0 = ws[off[0]:off[0] + n * P * P * 32 * es].view(torch.float32 if es == 4 else torch.bfloat16)
+    assert y0.numel() == n * P * P * 32 and bool(torch.isfinite(y0.float()).all()) and float(y0.float().abs().max()) > 0
+    with pytest.raises(N.MivitError):
+        N.check(N.lib.mivit_deepresnet_train_fwd_stage(code, None, x.data_ptr(), n, P, E, 0.1, 1e-5, t_a.data_ptr(), ws.data_ptr(),
+                                                       nbytes, 9, None, None, s), "fwd_stage")
