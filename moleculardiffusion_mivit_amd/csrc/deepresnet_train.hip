@@ -205,66 +205,84 @@ __device__ __forceinline__ void fill_image(T *tile, const TileSrc &s, const Geom
 // implicit-GEMM core: acc[j][mt] += sum_{tap, ci} in[pixel(mt) + tap][ci] * W[co(j)][tap][ci]   (two column tiles / wave)
 // weight fragments are prefetched one chunk (G k-steps) ahead: they come from L2, the image fragments from LDS
 // ---------------------------------------------------------------------------------------------------------------
+template <typename T, int CIN, int TAPS>
+struct ConvK {
+    static constexpr int KS = Mma<T>::KS, KL = sizeof(T) == 2 ? 8 : 1, CS = Img<T, CIN>::CS;
+    static constexpr int NC = CIN / KS, TOT = TAPS * NC, G = 2, NCH = TOT / G;
+    static_assert(CIN % KS == 0, "channel count must be a multiple of the MFMA k step");
+    static __device__ __forceinline__ int offset(int s, int rowe) {
+        const int tap = s / NC, c0 = (s - tap * NC) * KS;
+        return (TAPS == 9 ? ((tap / 3 - 1) * rowe + (tap % 3 - 1) * CS) : 0) + c0;
+    }
+};
+
+// one chunk = two k-steps with the weight fragments in `cur`; the next chunk's fragments are loaded into `nxt` first
+template <typename T, int CIN, int TAPS, int MT, int MTC>
+__device__ __forceinline__ void conv_chunk(f32x4 (&acc)[2][MT], const T *in, const T *w0, const T *w1, const int (&hidx)[MT], int rowe,
+                                           int ch, const typename Mma<T>::Frag (&cur)[2][2], typename Mma<T>::Frag (&nxt)[2][2]) {
+    typedef typename Mma<T>::Frag Frag;
+    using K = ConvK<T, CIN, TAPS>;
+#pragma unroll
+    for (int j = 0; j < K::G; ++j) {                       // (clamped: the last prefetch re-reads the final k-step)
+        int s = (ch + 1) * K::G + j;
+        s = s < K::TOT ? s : K::TOT - 1;
+        nxt[0][j] = frag_at<T>(w0 + s * K::KS); nxt[1][j] = frag_at<T>(w1 + s * K::KS);
+    }
+    const int o0 = K::offset(ch * K::G, rowe), o1 = K::offset(ch * K::G + 1, rowe);
+    Frag a0[MTC], a1[MTC];
+#pragma unroll
+    for (int mt = 0; mt < MTC; ++mt) a0[mt] = frag_at<T>(in + hidx[mt] + o0);
+#pragma unroll
+    for (int mt = 0; mt < MTC; ++mt) {
+        acc[0][mt] = Mma<T>::mma(cur[0][0], a0[mt], acc[0][mt]);
+        acc[1][mt] = Mma<T>::mma(cur[1][0], a0[mt], acc[1][mt]);
+        a1[mt] = frag_at<T>(in + hidx[mt] + o1);
+    }
+#pragma unroll
+    for (int mt = 0; mt < MTC; ++mt) {
+        acc[0][mt] = Mma<T>::mma(cur[0][1], a1[mt], acc[0][mt]);
+        acc[1][mt] = Mma<T>::mma(cur[1][1], a1[mt], acc[1][mt]);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x020, 2 * K::G, 0);    // next chunk's weight fragments leave first (a full chunk of lead)
+    __builtin_amdgcn_sched_group_barrier(0x100, MTC, 0);
+#pragma unroll
+    for (int mt = 0; mt < MTC; ++mt) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 2 * MTC, 0);
+}
+
 // The first MTC row tiles are computed unconditionally (dead ones read a valid cell and are ignored by the epilogue), so the
 // loop body has no branch, and the schedule is pinned with sched_group_barrier: left alone the scheduler serialises
 // read -> wait -> 2 MFMAs per tile to save registers (SQ_WAIT_ANY 0.68, MFMA busy 0.23 on the 128 -> 128 convolution).
-// Per chunk of two k-steps: all fragment reads of step 0, then step 0's MFMAs with step 1's reads slotted in between them,
-// then step 1's MFMAs.  Weight fragments (from L2) are prefetched one chunk ahead.
+// Per chunk of two k-steps: the next chunk's weight fragments (from L2) leave first, then all image fragment reads of step
+// 0, then step 0's MFMAs with step 1's reads slotted in between them, then step 1's MFMAs.  The two weight-fragment
+// buffers swap roles chunk by chunk (no register copies, so a fragment is waited for at its first use one chunk later).
 template <typename T, int CIN, int TAPS, int MT, int MTC>
 __device__ __forceinline__ void conv_accum2_t(f32x4 (&acc)[2][MT], const T *in, const T *w0, const T *w1,
                                               const int (&hidx)[MT], int rowe, int lane) {
     // hidx[mt] = element offset of this lane's output pixel in the Img layout; rowe = elements per image row
     typedef typename Mma<T>::Frag Frag;
-    constexpr int KS = Mma<T>::KS, KL = sizeof(T) == 2 ? 8 : 1, CS = Img<T, CIN>::CS;
-    constexpr int NC = CIN / KS, TOT = TAPS * NC, G = 2, NCH = TOT / G;
-    static_assert(CIN % KS == 0, "channel count must be a multiple of the MFMA k step");
+    using K = ConvK<T, CIN, TAPS>;
     const int g = lane >> 4;
-    w0 += g * KL; w1 += g * KL; in += g * KL;
-    auto offset = [&](int s) {
-        const int tap = s / NC, c0 = (s - tap * NC) * KS;
-        return (TAPS == 9 ? ((tap / 3 - 1) * rowe + (tap % 3 - 1) * CS) : 0) + c0;
-    };
-    Frag cur[2][G], nxt[2][G];
+    w0 += g * K::KL; w1 += g * K::KL; in += g * K::KL;
+    Frag fa[2][K::G], fb[2][K::G];
 #pragma unroll
-    for (int j = 0; j < G; ++j) {
-        const int s = j < TOT ? j : TOT - 1;
-        cur[0][j] = frag_at<T>(w0 + s * KS); cur[1][j] = frag_at<T>(w1 + s * KS);
+    for (int j = 0; j < K::G; ++j) {
+        const int s = j < K::TOT ? j : K::TOT - 1;
+        fa[0][j] = frag_at<T>(w0 + s * K::KS); fa[1][j] = frag_at<T>(w1 + s * K::KS);
     }
+    int ch = 0;
 #pragma unroll 1
-    for (int ch = 0; ch < NCH; ++ch) {
-#pragma unroll
-        for (int j = 0; j < G; ++j) {                       // (clamped: the last prefetch re-reads the final k-step)
-            int s = (ch + 1) * G + j;
-            s = s < TOT ? s : TOT - 1;
-            nxt[0][j] = frag_at<T>(w0 + s * KS); nxt[1][j] = frag_at<T>(w1 + s * KS);
-        }
-        const int o0 = offset(ch * G), o1 = offset(ch * G + 1);
-        Frag a0[MTC], a1[MTC];
-#pragma unroll
-        for (int mt = 0; mt < MTC; ++mt) a0[mt] = frag_at<T>(in + hidx[mt] + o0);
-#pragma unroll
-        for (int mt = 0; mt < MTC; ++mt) {
-            acc[0][mt] = Mma<T>::mma(cur[0][0], a0[mt], acc[0][mt]);
-            acc[1][mt] = Mma<T>::mma(cur[1][0], a0[mt], acc[1][mt]);
-            a1[mt] = frag_at<T>(in + hidx[mt] + o1);
-        }
-#pragma unroll
-        for (int mt = 0; mt < MTC; ++mt) {
-            acc[0][mt] = Mma<T>::mma(cur[0][1], a1[mt], acc[0][mt]);
-            acc[1][mt] = Mma<T>::mma(cur[1][1], a1[mt], acc[1][mt]);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x100, MTC, 0);
-#pragma unroll
-        for (int mt = 0; mt < MTC; ++mt) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, 2 * MTC, 0);
-#pragma unroll
-        for (int j = 0; j < G; ++j) { cur[0][j] = nxt[0][j]; cur[1][j] = nxt[1][j]; }
+    for (; ch + 1 < K::NCH; ch += 2) {
+        conv_chunk<T, CIN, TAPS, MT, MTC>(acc, in, w0, w1, hidx, rowe, ch, fa, fb);
+        conv_chunk<T, CIN, TAPS, MT, MTC>(acc, in, w0, w1, hidx, rowe, ch + 1, fb, fa);
     }
-    if constexpr (TOT % G != 0) {                           // odd number of k-steps: the last one alone
-        const int o0 = offset(TOT - 1);
+    if constexpr (K::NCH % 2 != 0) conv_chunk<T, CIN, TAPS, MT, MTC>(acc, in, w0, w1, hidx, rowe, K::NCH - 1, fa, fb);
+    if constexpr (K::TOT % K::G != 0) {                      // odd number of k-steps: the last one alone
+        const Frag (&cur)[2][K::G] = K::NCH % 2 != 0 ? fb : fa;
+        const int o0 = K::offset(K::TOT - 1, rowe);
         Frag a0[MTC];
 #pragma unroll
         for (int mt = 0; mt < MTC; ++mt) a0[mt] = frag_at<T>(in + hidx[mt] + o0);
