@@ -10,7 +10,8 @@
 // A convolution is an implicit GEMM on MFMA over F whole frames that sit in LDS as zero-haloed [pixel][channel] images
 // (rows = output pixels, k = (tap, input channel)); weights are read from an L2-resident [c_out][tap][c_in] pack.  The
 // same kernel serves forward (epilogue: raw output + per-channel sum / sum-of-squares partials for the batch
-// statistics) and data-gradient (flipped-tap pack, DY prologue; the 1x1 skip branch accumulates into the same tile).
+// statistics) and data-gradient (flipped-tap pack, DY prologue; the 1x1 skip branch's gradient is a second pass that
+// starts its accumulators from the 3x3 pass's output).  LDS layouts are bank-conflict-free by construction (Img).
 // The weight gradient contracts over pixels: both operands are read TRANSPOSED out of their natural LDS images with
 // ds_read_tr16_b64 (bf16) / scalar reads (fp32); partial sums per workgroup go to a slab that is reduced
 // deterministically (no atomics anywhere).
@@ -44,7 +45,7 @@ __device__ __forceinline__ bf16x8 frag_at<bf16>(const bf16 *p) { return *reinter
 struct Geom {
     int N, P, PP;
     int th, tw, ntx, tpf, units;     // tile size, tiles per frame row, tiles per frame, N * tpf
-    int F, HPt, RT;                  // slots per workgroup, cells per slot image, F * th * tw rows (<= 176)
+    int F, HPt, RT;                  // slots per workgroup, cells per slot image, F * th * tw rows (<= MAXM * 16 = 352)
 };
 
 // per-workgroup lookup tables in LDS: rowg[r] = global pixel row (frame*P*P + y*P + x) or -1, rowc[r] = halo cell of row r
@@ -941,7 +942,7 @@ Geom make_geom(int dtype, int N, int P, int F) {
     return g;
 }
 
-// slots per workgroup: as many as fit 176 output pixels and need(F) <= 160 KB of LDS
+// slots per workgroup: as many as fit mm * 16 output pixels and need(F) <= cap bytes of LDS
 template <typename NeedFn>
 int slots_fit(int t, NeedFn need, int mm = MAXM, size_t cap = (size_t)160 * 1024) {
     int F = (mm * 16) / (t * t);
