@@ -14,7 +14,7 @@ import torch
 from torch.utils.data import DataLoader
 
 from ...helpers import generation as gen
-from .._common import backward_and_step, make_scaler
+from .._common import DataParallel, backward_and_step, make_scaler
 from .trainSettingsPSFNoise import *       # noqa: F401,F403  (constants + factories, as the reference does :7)
 from . import trainSettingsPSFNoise as S
 
@@ -31,11 +31,15 @@ def save_results(validation_losses, all_gen_labels, models, path_addition="", ou
 def run_training(num_cycles=100, N=64, TrainingDs_list=([1, 1], [3, 1], [5, 1], [7, 1], [9, 1], [10.2, 1]),
                  shuffle=True, verbose=False, seed=None, out_dir=".", save=True, device=None, **model_kwargs):
     device = device or S.device
+    par = DataParallel()                                       # a no-op unless torch.distributed runs > 1 rank
+    print = par.log                                            # noqa: A001  (rank 0 speaks)
+    save = save and par.rank == 0
     print("Using device:", device)
     g = torch.Generator().manual_seed(seed) if seed is not None else None
     models, optimizers, schedulers = S.getTrainingModels(**model_kwargs)
     for name in models:
         models[name] = models[name].to(device)
+    par.prepare(models)
     batch_size = 1 if S.adaptive_batch_size != -1 else 16
     val_videos = S.load_validation_data(S.nFrames, skip_inorder=True, generator=g)[:5]
     val_labels = torch.tensor([1, 3, 5, 7, 9], dtype=torch.float32)
@@ -68,11 +72,14 @@ def run_training(num_cycles=100, N=64, TrainingDs_list=([1, 1], [3, 1], [5, 1], 
             model.train()
             optimizer, scheduler = optimizers[name], schedulers[name]
             for batch_images, batch_labels in dataloader:
+                (batch_images, batch_labels), weight = par.shard(batch_images, batch_labels)
                 batch_images, batch_labels = batch_images.to(device), batch_labels.to(device)
                 optimizer.zero_grad()
                 predictions = S.make_prediction(model, name, batch_images, eval=False)
                 loss = S.loss_function(predictions, batch_labels)
-                backward_and_step(loss, optimizer, scalers[name])
+                if weight != 1.0:
+                    loss = loss * weight
+                backward_and_step(loss, optimizer, scalers[name], model, par)
             scheduler.step()
 
         for name, model in models.items():

@@ -62,13 +62,63 @@ def make_scaler(model):
     return torch.amp.GradScaler("cuda", init_scale=2.0 ** 16, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000)
 
 
-def backward_and_step(loss, optimizer, scaler=None):
-    """loss.backward(); optimizer.step()  (trainModelsPSFNoise.py:192-193), through the loss scaler when there is one."""
+class DataParallel:
+    """Data parallelism for the training loops, active when torch.distributed is initialised with
+    more than one rank (one process per GPU, `torchrun`-style); a no-op otherwise, so the single-process loops are the
+    reference's.  Every rank runs the same loop on the same generated data (same seed) and takes its contiguous slice of
+    each minibatch, so the job's minibatch IS the reference's; gradients are averaged over ranks (MiViT models: overlapped
+    with the native backward, `dp.attach`; a DeepResNet embedding normalises with job-wide BatchNorm statistics), the
+    loss of a ragged tail is weighted by its share of the minibatch, and only rank 0 prints and saves."""
+
+    def __init__(self):
+        import torch.distributed as dist
+        self.on = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        self.rank = dist.get_rank() if self.on else 0
+        self.world = dist.get_world_size() if self.on else 1
+
+    def prepare(self, models):
+        if not self.on:
+            return
+        from .. import dp
+        for model in models.values():
+            if model is None:
+                continue
+            if hasattr(model, "_plan"):
+                dp.attach(model, sync_batchnorm=hasattr(getattr(model, "embedding", None), "sync_batchnorm"))
+            else:
+                dp.broadcast_parameters(model)            # stock-PyTorch baselines: averaged after backward
+
+    def shard(self, *tensors):
+        """This rank's slice of a minibatch and the weight of its mean loss in the minibatch's mean loss (x world: the
+        gradient average divides by world).  A minibatch smaller than the world is computed whole on every rank."""
+        n = tensors[0].shape[0]
+        if not self.on or n < self.world:
+            return tensors, 1.0
+        lo, hi = self.rank * n // self.world, (self.rank + 1) * n // self.world
+        return tuple(t[lo:hi] for t in tensors), (hi - lo) * self.world / n
+
+    def finish(self, model):
+        if self.on:
+            from .. import dp
+            dp.finish_external_grads(model)
+
+    def log(self, *args, **kwargs):
+        if self.rank == 0:
+            print(*args, **kwargs)
+
+
+def backward_and_step(loss, optimizer, scaler=None, model=None, parallel=None):
+    """loss.backward(); optimizer.step()  (trainModelsPSFNoise.py:192-193), through the loss scaler when there is one;
+    under data parallelism the gradients that are not reduced during backward are averaged before the step."""
     if scaler is None:
         loss.backward()
+        if parallel is not None and model is not None:
+            parallel.finish(model)
         optimizer.step()
     else:
         scaler.scale(loss).backward()
+        if parallel is not None and model is not None:
+            parallel.finish(model)
         scaler.step(optimizer)
         scaler.update()
 
@@ -81,6 +131,10 @@ def run_cycles(S, models, optimizers, schedulers, make_batch_data, predict, num_
     for name in models:
         if models[name] is not None:
             models[name] = models[name].to(device)
+    par = DataParallel()
+    par.prepare(models)
+    print = par.log                                            # noqa: A001  (rank 0 speaks)
+    save = save and par.rank == 0
     if batch_size is None:
         batch_size = 1 if S.adaptive_batch_size != -1 else 16
     validation_losses = {name: {**{f"val_{float(D)}": [] for D in D_VALUES}, "val_avg": []} for name in models}
@@ -104,10 +158,13 @@ def run_cycles(S, models, optimizers, schedulers, make_batch_data, predict, num_
             if name not in scalers:
                 scalers[name] = make_scaler(model)
             for *bt, bl in loader:
+                (*bt, bl), weight = par.shard(*bt, bl)
                 bt = [t.to(device) for t in bt]
                 opt.zero_grad()
                 loss = S.loss_function(predict(model, name, *bt), bl.to(device))
-                backward_and_step(loss, opt, scalers[name])
+                if weight != 1.0:
+                    loss = loss * weight
+                backward_and_step(loss, opt, scalers[name], model, par)
             sch.step()
         for name, model in models.items():
             if model is None:

@@ -148,3 +148,26 @@ def test_sync_batchnorm_is_refused_where_it_cannot_run():
         emb(torch.rand(2, 3, 5, 5))
     emb.sync_batchnorm(enabled=False)
     assert emb(torch.rand(2, 3, 5, 5)).shape == (2, 3, 16)          # plain PyTorch stack on CPU tensors, as before
+
+
+def test_training_loop_shard_rule():
+    """experiments._common.DataParallel.shard: contiguous slices that cover the minibatch, loss weight = share x world (so the
+    rank-averaged gradient is the minibatch mean's), whole minibatch on every rank when it is smaller than the world, and a
+    strict no-op without torch.distributed."""
+    from moleculardiffusion_mivit_amd.experiments._common import DataParallel
+    par = DataParallel()
+    x, y = torch.arange(10.).view(10, 1), torch.arange(10)
+    (a, b), w = par.shard(x, y)
+    assert not par.on and a is x and b is y and w == 1.0
+    seen = []
+    for rank in range(4):
+        par.on, par.rank, par.world = True, rank, 4
+        (a, b), w = par.shard(x, y)
+        assert torch.equal(a.flatten().long(), b) and len(b) in (2, 3)
+        # rank-mean loss x w, averaged over ranks: each sample ends up with weight w / (n_r * world) == 1 / n
+        assert abs(w / (len(b) * par.world) - 1.0 / 10) < 1e-12
+        seen += b.tolist()
+    assert seen == list(range(10))
+    par.rank = 1
+    (a, b), w = par.shard(x[:3], y[:3])                     # 3 sequences, 4 ranks: everyone computes all of them
+    assert len(b) == 3 and w == 1.0
