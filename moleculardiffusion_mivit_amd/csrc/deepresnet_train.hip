@@ -217,93 +217,102 @@ struct ConvK {
     }
 };
 
-// one chunk = two k-steps with the weight fragments in `cur`; the next chunk's fragments are loaded into `nxt` first
-template <typename T, int CIN, int TAPS, int MT, int MTC>
-__device__ __forceinline__ void conv_chunk(f32x4 (&acc)[2][MT], const T *in, const T *w0, const T *w1, const int (&hidx)[MT], int rowe,
-                                           int ch, const typename Mma<T>::Frag (&cur)[2][2], typename Mma<T>::Frag (&nxt)[2][2]) {
+// GE k-steps with the weight fragments in `cur` (PREFETCH: the next chunk's fragments are loaded into `nxt` first).
+// NTW = 16-column tiles per wave.  A k-step is walked in SUB sub-steps of TS row tiles (NTW = 1 owns twice the row tiles, so
+// it takes them in two halves to keep the fragment double buffer at 2 x 11); the image fragments of sub-step s + 1 are read
+// between the MFMAs of sub-step s.
+template <typename T, int CIN, int TAPS, int NTW, int MT, int MTC, int GE, bool PREFETCH>
+__device__ __forceinline__ void conv_chunk(f32x4 (&acc)[NTW][MT], const T *in, const T *const (&w)[NTW], const int (&hidx)[MT], int rowe,
+                                           int ch, const typename Mma<T>::Frag (&cur)[NTW][2], typename Mma<T>::Frag (&nxt)[NTW][2]) {
     typedef typename Mma<T>::Frag Frag;
     using K = ConvK<T, CIN, TAPS>;
+    constexpr int SUB = NTW == 1 ? 2 : 1, TS = (MTC + SUB - 1) / SUB, NSS = GE * SUB;
+    if constexpr (PREFETCH) {
 #pragma unroll
-    for (int j = 0; j < K::G; ++j) {                       // (clamped: the last prefetch re-reads the final k-step)
-        int s = (ch + 1) * K::G + j;
-        s = s < K::TOT ? s : K::TOT - 1;
-        nxt[0][j] = frag_at<T>(w0 + s * K::KS); nxt[1][j] = frag_at<T>(w1 + s * K::KS);
+        for (int j = 0; j < K::G; ++j) {                   // (clamped: the last prefetch re-reads the final k-step)
+            int s = (ch + 1) * K::G + j;
+            s = s < K::TOT ? s : K::TOT - 1;
+#pragma unroll
+            for (int n = 0; n < NTW; ++n) nxt[n][j] = frag_at<T>(w[n] + s * K::KS);
+        }
     }
-    const int o0 = K::offset(ch * K::G, rowe), o1 = K::offset(ch * K::G + 1, rowe);
-    Frag a0[MTC], a1[MTC];
+    int off[GE];
 #pragma unroll
-    for (int mt = 0; mt < MTC; ++mt) a0[mt] = frag_at<T>(in + hidx[mt] + o0);
+    for (int j = 0; j < GE; ++j) off[j] = K::offset(ch * K::G + j, rowe);
+    Frag a[2][TS];
 #pragma unroll
-    for (int mt = 0; mt < MTC; ++mt) {
-        acc[0][mt] = Mma<T>::mma(cur[0][0], a0[mt], acc[0][mt]);
-        acc[1][mt] = Mma<T>::mma(cur[1][0], a0[mt], acc[1][mt]);
-        a1[mt] = frag_at<T>(in + hidx[mt] + o1);
+    for (int t = 0; t < TS; ++t) a[0][t] = frag_at<T>(in + hidx[t] + off[0]);
+#pragma unroll
+    for (int ss = 0; ss < NSS; ++ss) {
+        const int j = ss / SUB, base = (ss % SUB) * TS, cnt = MTC - base < TS ? MTC - base : TS;
+        const int jn = (ss + 1) / SUB, basen = ((ss + 1) % SUB) * TS, cntn = ss + 1 < NSS ? (MTC - basen < TS ? MTC - basen : TS) : 0;
+#pragma unroll
+        for (int t = 0; t < TS; ++t) {
+            if (t < cnt) {
+#pragma unroll
+                for (int n = 0; n < NTW; ++n) acc[n][base + t] = Mma<T>::mma(cur[n][j], a[ss & 1][t], acc[n][base + t]);
+            }
+            if (t < cntn) a[(ss + 1) & 1][t] = frag_at<T>(in + hidx[basen + t] + off[jn < GE ? jn : GE - 1]);
+        }
     }
+    if constexpr (PREFETCH) __builtin_amdgcn_sched_group_barrier(0x020, NTW * K::G, 0);   // the weight fragments leave first
+    __builtin_amdgcn_sched_group_barrier(0x100, TS, 0);
 #pragma unroll
-    for (int mt = 0; mt < MTC; ++mt) {
-        acc[0][mt] = Mma<T>::mma(cur[0][1], a1[mt], acc[0][mt]);
-        acc[1][mt] = Mma<T>::mma(cur[1][1], a1[mt], acc[1][mt]);
-    }
-    __builtin_amdgcn_sched_group_barrier(0x020, 2 * K::G, 0);    // next chunk's weight fragments leave first (a full chunk of lead)
-    __builtin_amdgcn_sched_group_barrier(0x100, MTC, 0);
+    for (int ss = 0; ss < NSS; ++ss) {
+        const int base = (ss % SUB) * TS, cnt = MTC - base < TS ? MTC - base : TS;
+        const int basen = ((ss + 1) % SUB) * TS, cntn = ss + 1 < NSS ? (MTC - basen < TS ? MTC - basen : TS) : 0;
 #pragma unroll
-    for (int mt = 0; mt < MTC; ++mt) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        for (int t = 0; t < TS; ++t) {
+            if (t < cnt) __builtin_amdgcn_sched_group_barrier(0x008, NTW, 0);
+            if (t < cntn) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
     }
-    __builtin_amdgcn_sched_group_barrier(0x008, 2 * MTC, 0);
 }
 
 // The first MTC row tiles are computed unconditionally (dead ones read a valid cell and are ignored by the epilogue), so the
 // loop body has no branch, and the schedule is pinned with sched_group_barrier: left alone the scheduler serialises
 // read -> wait -> 2 MFMAs per tile to save registers (SQ_WAIT_ANY 0.68, MFMA busy 0.23 on the 128 -> 128 convolution).
-// Per chunk of two k-steps: the next chunk's weight fragments (from L2) leave first, then all image fragment reads of step
-// 0, then step 0's MFMAs with step 1's reads slotted in between them, then step 1's MFMAs.  The two weight-fragment
+// Per chunk of two k-steps: the next chunk's weight fragments (from L2) leave first, then all image fragment reads of the
+// first sub-step, then each sub-step's MFMAs with the next one's reads slotted in between them.  The two weight-fragment
 // buffers swap roles chunk by chunk (no register copies, so a fragment is waited for at its first use one chunk later).
-template <typename T, int CIN, int TAPS, int MT, int MTC>
-__device__ __forceinline__ void conv_accum2_t(f32x4 (&acc)[2][MT], const T *in, const T *w0, const T *w1,
-                                              const int (&hidx)[MT], int rowe, int lane) {
+template <typename T, int CIN, int TAPS, int NTW, int MT, int MTC>
+__device__ __forceinline__ void conv_accum_t(f32x4 (&acc)[NTW][MT], const T *in, const T *const (&w_)[NTW],
+                                             const int (&hidx)[MT], int rowe, int lane) {
     // hidx[mt] = element offset of this lane's output pixel in the Img layout; rowe = elements per image row
     typedef typename Mma<T>::Frag Frag;
     using K = ConvK<T, CIN, TAPS>;
     const int g = lane >> 4;
-    w0 += g * K::KL; w1 += g * K::KL; in += g * K::KL;
-    Frag fa[2][K::G], fb[2][K::G];
+    const T *w[NTW];
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) w[n] = w_[n] + g * K::KL;
+    in += g * K::KL;
+    Frag fa[NTW][K::G], fb[NTW][K::G];
 #pragma unroll
     for (int j = 0; j < K::G; ++j) {
         const int s = j < K::TOT ? j : K::TOT - 1;
-        fa[0][j] = frag_at<T>(w0 + s * K::KS); fa[1][j] = frag_at<T>(w1 + s * K::KS);
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) fa[n][j] = frag_at<T>(w[n] + s * K::KS);
     }
     int ch = 0;
 #pragma unroll 1
     for (; ch + 1 < K::NCH; ch += 2) {
-        conv_chunk<T, CIN, TAPS, MT, MTC>(acc, in, w0, w1, hidx, rowe, ch, fa, fb);
-        conv_chunk<T, CIN, TAPS, MT, MTC>(acc, in, w0, w1, hidx, rowe, ch + 1, fb, fa);
+        conv_chunk<T, CIN, TAPS, NTW, MT, MTC, K::G, true>(acc, in, w, hidx, rowe, ch, fa, fb);
+        conv_chunk<T, CIN, TAPS, NTW, MT, MTC, K::G, true>(acc, in, w, hidx, rowe, ch + 1, fb, fa);
     }
-    if constexpr (K::NCH % 2 != 0) conv_chunk<T, CIN, TAPS, MT, MTC>(acc, in, w0, w1, hidx, rowe, K::NCH - 1, fa, fb);
+    if constexpr (K::NCH % 2 != 0) conv_chunk<T, CIN, TAPS, NTW, MT, MTC, K::G, true>(acc, in, w, hidx, rowe, K::NCH - 1, fa, fb);
     if constexpr (K::TOT % K::G != 0) {                      // odd number of k-steps: the last one alone
-        const Frag (&cur)[2][K::G] = K::NCH % 2 != 0 ? fb : fa;
-        const int o0 = K::offset(K::TOT - 1, rowe);
-        Frag a0[MTC];
-#pragma unroll
-        for (int mt = 0; mt < MTC; ++mt) a0[mt] = frag_at<T>(in + hidx[mt] + o0);
-#pragma unroll
-        for (int mt = 0; mt < MTC; ++mt) {
-            acc[0][mt] = Mma<T>::mma(cur[0][0], a0[mt], acc[0][mt]);
-            acc[1][mt] = Mma<T>::mma(cur[1][0], a0[mt], acc[1][mt]);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x100, MTC, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 2 * MTC, 0);
+        if constexpr (K::NCH % 2 != 0) conv_chunk<T, CIN, TAPS, NTW, MT, MTC, 1, false>(acc, in, w, hidx, rowe, K::NCH, fb, fa);
+        else conv_chunk<T, CIN, TAPS, NTW, MT, MTC, 1, false>(acc, in, w, hidx, rowe, K::NCH, fa, fb);
     }
 }
 
-template <typename T, int CIN, int TAPS, int MT>
-__device__ __forceinline__ void conv_accum2(f32x4 (&acc)[2][MT], const T *in, const T *w0, const T *w1,
-                                            const int (&hidx)[MT], int nm, int rowe, int lane) {
+template <typename T, int CIN, int TAPS, int NTW, int MT>
+__device__ __forceinline__ void conv_accum(f32x4 (&acc)[NTW][MT], const T *in, const T *const (&w)[NTW],
+                                           const int (&hidx)[MT], int nm, int rowe, int lane) {
     constexpr int MH = (MT + 1) / 2;
     if (nm <= 0) return;
-    if (nm > MH) conv_accum2_t<T, CIN, TAPS, MT, MT>(acc, in, w0, w1, hidx, rowe, lane);       // all tiles (dead ones wasted)
-    else conv_accum2_t<T, CIN, TAPS, MT, MH>(acc, in, w0, w1, hidx, rowe, lane);              // the first half (small groups)
+    if (nm > MH) conv_accum_t<T, CIN, TAPS, NTW, MT, MT>(acc, in, w, hidx, rowe, lane);       // all tiles (dead ones wasted)
+    else conv_accum_t<T, CIN, TAPS, NTW, MT, MH>(acc, in, w, hidx, rowe, lane);              // the first half (small groups)
 }
 
 struct ConvArgs {
@@ -342,17 +351,17 @@ __device__ __forceinline__ void load4(const T *p, float *v) {
 // (mt0 + mt) * 16 + cq, channel (2 ng + j) * 16 + 4 g + r -- four consecutive channels of one pixel per lane, so a row tile
 // leaves as one 8-byte store per lane (pixel-major accumulators needed 4 two-byte stores: 169 of the 128 -> 128
 // convolution's 1000 us).
-template <typename T, int COUT, int MT, bool STATS>
-__device__ __forceinline__ void conv_epilogue(const f32x4 (&acc)[2][MT], T *out, float *stats, float *red, const int *rowg,
+template <typename T, int COUT, int NTW, int MT, bool STATS>
+__device__ __forceinline__ void conv_epilogue(const f32x4 (&acc)[NTW][MT], T *out, float *stats, float *red, const int *rowg,
                                               int mt0, int nm, int ng, int lane, int wave, int tid) {
-    constexpr int NG = COUT / 32, MQ = 8 / NG;
+    constexpr int NG = COUT / (16 * NTW), MQ = 8 / NG;
     const int g = lane >> 4, cq = lane & 15;
     int rows[MT];                                  // this lane's output pixel per row tile: one batch of LDS reads
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) rows[mt] = mt < nm ? rowg[(mt0 + mt) * 16 + cq] : -1;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int co = (2 * ng + j) * 16 + 4 * g;
+    for (int j = 0; j < NTW; ++j) {
+        const int co = (NTW * ng + j) * 16 + 4 * g;
         float s[4] = {0.f, 0.f, 0.f, 0.f}, ss[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
@@ -374,7 +383,7 @@ __device__ __forceinline__ void conv_epilogue(const f32x4 (&acc)[2][MT], T *out,
     if (STATS) {
         __syncthreads();
         for (int t = tid; t < 2 * COUT; t += NT) {
-            const int which = t / COUT, c = t - which * COUT, ngc = c >> 5, cc = c & 31;
+            const int which = t / COUT, c = t - which * COUT, ngc = c / (16 * NTW), cc = c % (16 * NTW);
             float v = 0.f;
 #pragma unroll
             for (int mq = 0; mq < MQ; ++mq) v += red[((mq * NG + ngc) * 2 + which) * 32 + cc];
@@ -389,11 +398,16 @@ __device__ __forceinline__ void conv_epilogue(const f32x4 (&acc)[2][MT], T *out,
 // out += conv1x1(tile A, W2) (the skip's data gradient as its own pass, after the 3x3 pass wrote out; a variant that held
 // both gradient images in LDS fitted half the frames per workgroup and was slower than the two passes together)
 // MM: row tiles per workgroup (MAXM: one workgroup per CU with up to 160 KB of LDS)
-template <typename T, int CIN, int COUT, int SECOND, int PRO, int CIN2, int MM>
+// NTW: 16-column tiles per wave.  The 8 waves are NG = COUT / (16 NTW) column groups x MQ = 8 / NG row groups, and the MQ
+// waves of a column group stream the same weight fragments from L2; timing with the weight loads removed showed those loads
+// are what the loop waits for (128 -> 128: -18 %, 128 -> 64: -36 %, 64 -> 64: -46 %), so NTW = 1 (half the redundancy, twice the
+// LDS image reads per wave, which have room) is the default.
+template <typename T, int CIN, int COUT, int SECOND, int PRO, int CIN2, int MM, int NTW>
 __global__ __launch_bounds__(NT, MM == MAXM ? 2 : 4) void drn_conv_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int ROWS_PAD = MM * 16;
-    constexpr int NG = COUT / 32, MQ = 8 / NG, MT = (MM + MQ - 1) / MQ;
+    constexpr int NG = COUT / (16 * NTW), MQ = 8 / NG, MT = (MM + MQ - 1) / MQ;
+    static_assert(NG >= 1 && NG <= 8 && NG * MQ == 8, "wave grid");
     static_assert(SECOND == 0 || SECOND == 1 || SECOND == 3, "see above");
     constexpr bool STATS = PRO != PRO_DY;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, cq = lane & 15;
@@ -416,10 +430,19 @@ __global__ __launch_bounds__(NT, MM == MAXM ? 2 : 4) void drn_conv_kernel(const 
     int hidx[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) hidx[mt] = cellpos[rowc[min((mt0 + mt) * 16 + cq, ROWS_PAD - 1)]];
-    f32x4 acc[2][MT];
+    f32x4 acc[NTW][MT];
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) { acc[0][mt] = zero; acc[1][mt] = zero; }
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) acc[j][mt] = zero;
+    const T *w9[NTW], *w1[NTW];                    // this lane's rows of the 3x3 / 1x1 weight packs
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+        const size_t co = (size_t)((NTW * ng + j) * 16 + cq);
+        w9[j] = static_cast<const T *>(a.W) + co * 9 * CIN;
+        w1[j] = static_cast<const T *>(a.W2) + co * CIN;
+    }
 
     if (a.dbg & 2) {
     } else if (SECOND == 3) {
@@ -430,28 +453,27 @@ __global__ __launch_bounds__(NT, MM == MAXM ? 2 : 4) void drn_conv_kernel(const 
         for (int mt = 0; mt < MT; ++mt) {
             const int grow = mt < nm ? rowg[(mt0 + mt) * 16 + cq] : -1;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < NTW; ++j) {
                 float v[4] = {0.f, 0.f, 0.f, 0.f};
-                if (grow >= 0) load4<T>(out + (size_t)grow * COUT + (2 * ng + j) * 16 + 4 * gq, v);
+                if (grow >= 0) load4<T>(out + (size_t)grow * COUT + (NTW * ng + j) * 16 + 4 * gq, v);
                 acc[j][mt] = f32x4{v[0], v[1], v[2], v[3]};
             }
         }
-        const T *w2 = static_cast<const T *>(a.W2) + (size_t)(2 * ng * 16 + cq) * CIN;
-        conv_accum2<T, CIN, 1, MT>(acc, tileA, w2, w2 + (size_t)16 * CIN, hidx, nm, img.rowe, lane);
+        conv_accum<T, CIN, 1, NTW, MT>(acc, tileA, w1, hidx, nm, img.rowe, lane);
     } else {
-        const T *w = static_cast<const T *>(a.W) + (size_t)(2 * ng * 16 + cq) * 9 * CIN;
-        conv_accum2<T, CIN, 9, MT>(acc, tileA, w, w + (size_t)16 * 9 * CIN, hidx, nm, img.rowe, lane);
+        conv_accum<T, CIN, 9, NTW, MT>(acc, tileA, w9, hidx, nm, img.rowe, lane);
     }
     if (!(a.dbg & 4))
-    conv_epilogue<T, COUT, MT, STATS>(acc, static_cast<T *>(a.out), STATS ? a.stats + (size_t)blockIdx.x * 2 * COUT : nullptr, red,
-                                      rowg, mt0, nm, ng, lane, wave, tid);
+    conv_epilogue<T, COUT, NTW, MT, STATS>(acc, static_cast<T *>(a.out), STATS ? a.stats + (size_t)blockIdx.x * 2 * COUT : nullptr, red,
+                                           rowg, mt0, nm, ng, lane, wave, tid);
     if (SECOND == 1) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) { acc[0][mt] = zero; acc[1][mt] = zero; }
-        const T *w2 = static_cast<const T *>(a.W2) + (size_t)(2 * ng * 16 + cq) * CIN;
-        conv_accum2<T, CIN, 1, MT>(acc, tileA, w2, w2 + (size_t)16 * CIN, hidx, nm, img.rowe, lane);
-        conv_epilogue<T, COUT, MT, STATS>(acc, static_cast<T *>(a.out2), a.stats2 + (size_t)blockIdx.x * 2 * COUT, red, rowg, mt0, nm,
-                                          ng, lane, wave, tid);
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) acc[j][mt] = zero;
+        conv_accum<T, CIN, 1, NTW, MT>(acc, tileA, w1, hidx, nm, img.rowe, lane);
+        conv_epilogue<T, COUT, NTW, MT, STATS>(acc, static_cast<T *>(a.out2), a.stats2 + (size_t)blockIdx.x * 2 * COUT, red, rowg, mt0,
+                                               nm, ng, lane, wave, tid);
     }
 }
 
@@ -1072,13 +1094,13 @@ int bn_consume(const Ctx &c, int i, int k) {
     return 0;
 }
 
-template <typename T, int CIN, int COUT, int SECOND, int PRO, int CIN2, int MM>
+template <typename T, int CIN, int COUT, int SECOND, int PRO, int CIN2, int MM, int NTW>
 int run_conv_mm(const Ctx &c, const ConvArgs &proto, int *nblocks, int t, int F) {
     ConvArgs a = proto;
     { static const int dbg = [] { const char *e = getenv("MIVIT_DRN_DBG"); return e ? atoi(e) : 0; }(); a.dbg = dbg; }
     a.g = make_geom(c.dtype, c.N, c.P, F);
     const size_t lds = conv_lds(c.dtype, t, F, CIN, 0, MM);
-    auto kern = drn_conv_kernel<T, CIN, COUT, SECOND, PRO, CIN2, MM>;
+    auto kern = drn_conv_kernel<T, CIN, COUT, SECOND, PRO, CIN2, MM, NTW>;
     RC(set_lds(kern, lds));
     const int blocks = ceil_div(a.g.units, F);
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(NT), lds, c.s, a);
@@ -1094,7 +1116,11 @@ int run_conv(const Ctx &c, const ConvArgs &proto, int *nblocks) {
     int t, nt;
     choose_tile(c.dtype, c.P, &t, &nt);
     const int F = slots_fit(t, [&](int f) { return conv_lds(c.dtype, t, f, CIN, 0); });
-    return run_conv_mm<T, CIN, COUT, SECOND, PRO, CIN2, MAXM>(c, proto, nblocks, t, F);
+    // measured (B=1024 bf16, us under the profiler, NTW 2 -> 1): 128->128 992 -> 910, 128->64 890 -> 660, 64->64 501 -> 390,
+    // 64->32 405 -> 319; whole step 13.44 -> 12.75 ms with NTW = 1 everywhere (MIVIT_DRN_NTW=2 selects the old wave tile)
+    static const int ntw = [] { const char *e = getenv("MIVIT_DRN_NTW"); return e ? atoi(e) : 1; }();
+    if (ntw == 2) return run_conv_mm<T, CIN, COUT, SECOND, PRO, CIN2, MAXM, 2>(c, proto, nblocks, t, F);
+    return run_conv_mm<T, CIN, COUT, SECOND, PRO, CIN2, MAXM, 1>(c, proto, nblocks, t, F);
 }
 
 template <typename T>
