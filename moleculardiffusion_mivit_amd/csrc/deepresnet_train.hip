@@ -921,8 +921,15 @@ __global__ __launch_bounds__(NT) void drn_wgrad_kernel(const WgradArgs a) {
 __global__ void drn_wgrad_reduce_kernel(const float *slab, int nparts, int COUT, int TAPS, int CIN, float *dW) {
     const int n = COUT * TAPS * CIN, idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
-    float s = 0.f;
-    for (int k = 0; k < nparts; ++k) s += slab[(size_t)k * n + idx];
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;          // four chains (fixed order: still bitwise reproducible), 4 loads in flight
+    int k = 0;
+    for (; k + 3 < nparts; k += 4) {
+        const float v0 = slab[(size_t)k * n + idx], v1 = slab[(size_t)(k + 1) * n + idx];
+        const float v2 = slab[(size_t)(k + 2) * n + idx], v3 = slab[(size_t)(k + 3) * n + idx];
+        s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+    }
+    for (; k < nparts; ++k) s0 += slab[(size_t)k * n + idx];
+    const float s = (s0 + s1) + (s2 + s3);
     const int ci = idx % CIN, tap = (idx / CIN) % TAPS, co = idx / (CIN * TAPS);
     dW[((size_t)co * CIN + ci) * TAPS + tap] = s;
 }
