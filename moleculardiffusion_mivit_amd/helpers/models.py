@@ -282,7 +282,7 @@ class DeepResNetEmbedding(nn.Module):
             running.append((bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None))
         params += [self.fc.weight, self.fc.bias]
         import torch.distributed as dist
-        if self._sync_bn and dist.is_available() and dist.is_initialized() and dist.get_world_size(self._sync_group) > 1:
+        if self._sync_bn and dist.is_available() and dist.is_initialized():      # (a group of one rank works too: same kernels)
             out = _ops.deepresnet_train_sync(frames, dtype, pairs[0][1].momentum, pairs[0][1].eps, running, params,
                                              self._sync_group)
         else:
