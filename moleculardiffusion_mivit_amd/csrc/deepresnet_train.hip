@@ -18,6 +18,7 @@
 #include "common.h"
 #include "stream_prims.h"
 #include <algorithm>
+#include <type_traits>
 #include <vector>
 
 namespace {
@@ -320,7 +321,9 @@ struct ConvArgs {
     TileSrc A;
     const void *W, *W2;          // [COUT][9][CIN], [COUT][CIN or CIN2]
     void *out, *out2;            // [N*P*P, COUT]
-    float *stats, *stats2;       // [blocks][2][COUT] partial sum / sum of squares
+    float *stats, *stats2;       // [blocks][2][COUT] partial sum / sum of squares (EPI 1) or [blocks][3][COUT] mask sums (EPI 2, 3)
+    const void *my, *my2;        // EPI 2 / 3: raw outputs y (and y' of the skip branch) of the layer whose ReLU masks `out`
+    const float *mca, *mcb;      //            and their forward BatchNorm tables
     int dbg;                     // timing experiments only (MIVIT_DRN_DBG): 1 skip fill, 2 skip MFMA loop, 4 skip epilogue, 8 skip tables
 };
 
@@ -351,10 +354,14 @@ __device__ __forceinline__ void load4(const T *p, float *v) {
 // (mt0 + mt) * 16 + cq, channel (2 ng + j) * 16 + 4 g + r -- four consecutive channels of one pixel per lane, so a row tile
 // leaves as one 8-byte store per lane (pixel-major accumulators needed 4 two-byte stores: 169 of the 128 -> 128
 // convolution's 1000 us).
-template <typename T, int COUT, int NTW, int MT, bool STATS>
+// EPI: 0 store | 1 store + per-channel sum / sum of squares partials (forward BatchNorm statistics) | 2 / 3 the ReLU mask of
+// the layer below folded in (3: that layer adds a skip branch): g = v * [scale*y + shift (+ scale'*y' + shift') > 0] is what
+// is stored, with the partials sum g, sum g*y (, sum g*y') its BatchNorm backward needs -- the separate mask pass over the
+// gradient (read v, read y, write g) is gone for every gradient that a convolution produces.
+template <typename T, int COUT, int NTW, int MT, int EPI>
 __device__ __forceinline__ void conv_epilogue(const f32x4 (&acc)[NTW][MT], T *out, float *stats, float *red, const int *rowg,
-                                              int mt0, int nm, int ng, int lane, int wave, int tid) {
-    constexpr int NG = COUT / (16 * NTW), MQ = 8 / NG;
+                                              int mt0, int nm, int ng, int lane, int wave, int tid, const ConvArgs &a) {
+    constexpr int NG = COUT / (16 * NTW), MQ = 8 / NG, NS_ = EPI >= 2 ? 3 : 2;
     const int g = lane >> 4, cq = lane & 15;
     int rows[MT];                                  // this lane's output pixel per row tile: one batch of LDS reads
 #pragma unroll
@@ -362,31 +369,82 @@ __device__ __forceinline__ void conv_epilogue(const f32x4 (&acc)[NTW][MT], T *ou
 #pragma unroll
     for (int j = 0; j < NTW; ++j) {
         const int co = (NTW * ng + j) * 16 + 4 * g;
-        float s[4] = {0.f, 0.f, 0.f, 0.f}, ss[4] = {0.f, 0.f, 0.f, 0.f};
+        float s[4] = {0.f, 0.f, 0.f, 0.f}, ss[4] = {0.f, 0.f, 0.f, 0.f}, s3[4] = {0.f, 0.f, 0.f, 0.f};
+        float sA[4], hA[4], sB[4], hB[4];
+        if constexpr (EPI >= 2) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-            if (rows[mt] >= 0) {
-                const float v[4] = {acc[j][mt][0], acc[j][mt][1], acc[j][mt][2], acc[j][mt][3]};
-                store4<T>(out + (size_t)rows[mt] * COUT + co, v);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { s[r] += v[r]; ss[r] += v[r] * v[r]; }
+            for (int r = 0; r < 4; ++r) {
+                sA[r] = a.mca[2 * CSTR + co + r]; hA[r] = a.mca[3 * CSTR + co + r];
+                sB[r] = EPI == 3 ? a.mcb[2 * CSTR + co + r] : 0.f; hB[r] = EPI == 3 ? a.mcb[3 * CSTR + co + r] : 0.f;
             }
-        if (STATS) {
+        }
+        if constexpr (EPI >= 2) {
+            // y (and y') of this lane's pixels, 8 row tiles at a time with all loads issued before the first use
+            typedef typename std::conditional<sizeof(T) == 4, float4, uint2>::type Raw;
+            constexpr int UB = 8;
+#pragma unroll
+            for (int mb = 0; mb < MT; mb += UB) {
+                Raw yr[UB], y2r[UB];
+#pragma unroll
+                for (int u = 0; u < UB; ++u)
+                    if (mb + u < MT) {
+                        const size_t row = rows[mb + u] > 0 ? rows[mb + u] : 0;
+                        yr[u] = *reinterpret_cast<const Raw *>(static_cast<const T *>(a.my) + row * COUT + co);
+                        if (EPI == 3) y2r[u] = *reinterpret_cast<const Raw *>(static_cast<const T *>(a.my2) + row * COUT + co);
+                    }
+#pragma unroll
+                for (int u = 0; u < UB; ++u)
+                    if (mb + u < MT) {
+                        const int mt = mb + u;
+                        if (rows[mt] >= 0) {
+                            float v[4] = {acc[j][mt][0], acc[j][mt][1], acc[j][mt][2], acc[j][mt][3]};
+                            float yv[4], y2v[4] = {0.f, 0.f, 0.f, 0.f};
+                            load4<T>(reinterpret_cast<const T *>(&yr[u]), yv);
+                            if (EPI == 3) load4<T>(reinterpret_cast<const T *>(&y2r[u]), y2v);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                float act = sA[r] * yv[r] + hA[r];              // (the mask kernel's expression, in its order)
+                                if (EPI == 3) act += sB[r] * y2v[r] + hB[r];
+                                v[r] = act > 0.f ? v[r] : 0.f;
+                                s[r] += v[r]; ss[r] += v[r] * yv[r];
+                                if (EPI == 3) s3[r] += v[r] * y2v[r];
+                            }
+                            store4<T>(out + (size_t)rows[mt] * COUT + co, v);
+                        }
+                    }
+            }
+        } else {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                if (rows[mt] >= 0) {
+                    const float v[4] = {acc[j][mt][0], acc[j][mt][1], acc[j][mt][2], acc[j][mt][3]};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { s[r] += v[r]; ss[r] += v[r] * v[r]; }
+                    store4<T>(out + (size_t)rows[mt] * COUT + co, v);
+                }
+        }
+        if constexpr (EPI >= 1) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
 #pragma unroll
-                for (int m = 1; m < 16; m <<= 1) { s[r] += __shfl_xor(s[r], m, 64); ss[r] += __shfl_xor(ss[r], m, 64); }
-                if (cq == 0) { red[(wave * 2 + 0) * 32 + j * 16 + 4 * g + r] = s[r]; red[(wave * 2 + 1) * 32 + j * 16 + 4 * g + r] = ss[r]; }
+                for (int m = 1; m < 16; m <<= 1) {
+                    s[r] += __shfl_xor(s[r], m, 64); ss[r] += __shfl_xor(ss[r], m, 64);
+                    if (EPI == 3) s3[r] += __shfl_xor(s3[r], m, 64);
+                }
+                if (cq == 0) {
+                    red[(wave * NS_ + 0) * 32 + j * 16 + 4 * g + r] = s[r]; red[(wave * NS_ + 1) * 32 + j * 16 + 4 * g + r] = ss[r];
+                    if (EPI >= 2) red[(wave * NS_ + 2) * 32 + j * 16 + 4 * g + r] = s3[r];
+                }
             }
         }
     }
-    if (STATS) {
+    if constexpr (EPI >= 1) {
         __syncthreads();
-        for (int t = tid; t < 2 * COUT; t += NT) {
+        for (int t = tid; t < NS_ * COUT; t += NT) {
             const int which = t / COUT, c = t - which * COUT, ngc = c / (16 * NTW), cc = c % (16 * NTW);
             float v = 0.f;
 #pragma unroll
-            for (int mq = 0; mq < MQ; ++mq) v += red[((mq * NG + ngc) * 2 + which) * 32 + cc];
+            for (int mq = 0; mq < MQ; ++mq) v += red[((mq * NG + ngc) * NS_ + which) * 32 + cc];
             stats[which * COUT + c] = v;
         }
         __syncthreads();
@@ -402,21 +460,22 @@ __device__ __forceinline__ void conv_epilogue(const f32x4 (&acc)[NTW][MT], T *ou
 // waves of a column group stream the same weight fragments from L2; timing with the weight loads removed showed those loads
 // are what the loop waits for (128 -> 128: -18 %, 128 -> 64: -36 %, 64 -> 64: -46 %), so NTW = 1 (half the redundancy, twice the
 // LDS image reads per wave, which have room) is the default.
-template <typename T, int CIN, int COUT, int SECOND, int PRO, int CIN2, int MM, int NTW>
+template <typename T, int CIN, int COUT, int SECOND, int PRO, int EPI, int MM, int NTW>
 __global__ __launch_bounds__(NT, MM == MAXM ? 2 : 4) void drn_conv_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int ROWS_PAD = MM * 16;
     constexpr int NG = COUT / (16 * NTW), MQ = 8 / NG, MT = (MM + MQ - 1) / MQ;
     static_assert(NG >= 1 && NG <= 8 && NG * MQ == 8, "wave grid");
     static_assert(SECOND == 0 || SECOND == 1 || SECOND == 3, "see above");
-    constexpr bool STATS = PRO != PRO_DY;
+    static_assert(EPI >= 0 && EPI <= 3 && (SECOND != 1 || EPI == 1), "epilogue kind");
+    constexpr int NSTAT = EPI >= 2 ? 3 : 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, cq = lane & 15;
     const Geom &g = a.g;
     const int NM = (g.RT + 15) / 16;
     const Img<T, CIN> img(g.th, g.tw);
     T *tileA = reinterpret_cast<T *>(smem);
-    float *red = reinterpret_cast<float *>(tileA + g.F * img.slote);   // [8][2][32]
-    int *rowg = reinterpret_cast<int *>(red + 8 * 2 * 32), *rowc = rowg + ROWS_PAD, *cellsrc = rowc + ROWS_PAD;
+    float *red = reinterpret_cast<float *>(tileA + g.F * img.slote);   // [8][3][32]
+    int *rowg = reinterpret_cast<int *>(red + 8 * 3 * 32), *rowc = rowg + ROWS_PAD, *cellsrc = rowc + ROWS_PAD;
     int *cellpos = cellsrc + g.F * g.HPt;
 
     build_row_tables(g, blockIdx.x, ROWS_PAD, rowg, rowc, tid);
@@ -464,16 +523,16 @@ __global__ __launch_bounds__(NT, MM == MAXM ? 2 : 4) void drn_conv_kernel(const 
         conv_accum<T, CIN, 9, NTW, MT>(acc, tileA, w9, hidx, nm, img.rowe, lane);
     }
     if (!(a.dbg & 4))
-    conv_epilogue<T, COUT, NTW, MT, STATS>(acc, static_cast<T *>(a.out), STATS ? a.stats + (size_t)blockIdx.x * 2 * COUT : nullptr, red,
-                                           rowg, mt0, nm, ng, lane, wave, tid);
+    conv_epilogue<T, COUT, NTW, MT, EPI>(acc, static_cast<T *>(a.out), EPI ? a.stats + (size_t)blockIdx.x * NSTAT * COUT : nullptr, red,
+                                         rowg, mt0, nm, ng, lane, wave, tid, a);
     if (SECOND == 1) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int j = 0; j < NTW; ++j) acc[j][mt] = zero;
         conv_accum<T, CIN, 1, NTW, MT>(acc, tileA, w1, hidx, nm, img.rowe, lane);
-        conv_epilogue<T, COUT, NTW, MT, STATS>(acc, static_cast<T *>(a.out2), a.stats2 + (size_t)blockIdx.x * 2 * COUT, red, rowg, mt0,
-                                               nm, ng, lane, wave, tid);
+        conv_epilogue<T, COUT, NTW, MT, EPI>(acc, static_cast<T *>(a.out2), a.stats2 + (size_t)blockIdx.x * 2 * COUT, red, rowg, mt0,
+                                             nm, ng, lane, wave, tid, a);
     }
 }
 
@@ -987,7 +1046,7 @@ size_t conv_image_bytes(int dtype, int t, int F, int C) {
     return (size_t)F * ((size_t)(t + 2) * rowb + spb);
 }
 size_t conv_lds(int dtype, int t, int F, int CIN, int CIN2, int mm = MAXM) {
-    return conv_image_bytes(dtype, t, F, CIN) + (CIN2 ? conv_image_bytes(dtype, t, F, CIN2) : 0) + 8 * 2 * 32 * 4 + 2 * mm * 16 * 4 +
+    return conv_image_bytes(dtype, t, F, CIN) + (CIN2 ? conv_image_bytes(dtype, t, F, CIN2) : 0) + 8 * 3 * 32 * 4 + 2 * mm * 16 * 4 +
            (size_t)F * (t + 2) * (t + 2) * 4 +
            (size_t)F * (t + 2) * (t + 2) * 4;
 }
@@ -1101,13 +1160,13 @@ int bn_consume(const Ctx &c, int i, int k) {
     return 0;
 }
 
-template <typename T, int CIN, int COUT, int SECOND, int PRO, int CIN2, int MM, int NTW>
+template <typename T, int CIN, int COUT, int SECOND, int PRO, int EPI, int MM, int NTW>
 int run_conv_mm(const Ctx &c, const ConvArgs &proto, int *nblocks, int t, int F) {
     ConvArgs a = proto;
     { static const int dbg = [] { const char *e = getenv("MIVIT_DRN_DBG"); return e ? atoi(e) : 0; }(); a.dbg = dbg; }
     a.g = make_geom(c.dtype, c.N, c.P, F);
     const size_t lds = conv_lds(c.dtype, t, F, CIN, 0, MM);
-    auto kern = drn_conv_kernel<T, CIN, COUT, SECOND, PRO, CIN2, MM, NTW>;
+    auto kern = drn_conv_kernel<T, CIN, COUT, SECOND, PRO, EPI, MM, NTW>;
     RC(set_lds(kern, lds));
     const int blocks = ceil_div(a.g.units, F);
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(NT), lds, c.s, a);
@@ -1116,7 +1175,7 @@ int run_conv_mm(const Ctx &c, const ConvArgs &proto, int *nblocks, int t, int F)
     return 0;
 }
 
-template <typename T, int CIN, int COUT, int SECOND, int PRO, int CIN2>
+template <typename T, int CIN, int COUT, int SECOND, int PRO, int EPI>
 int run_conv(const Ctx &c, const ConvArgs &proto, int *nblocks) {
     // one workgroup per CU with as many frames as fit: half-size groups, two co-resident per CU (MM = MAXM / 2, <= 80 KB,
     // <= 128 VGPRs), measured 4-5 % slower at 9 x 9 (bf16) and 20 % slower in fp32 -- the weights are re-streamed per group
@@ -1126,8 +1185,8 @@ int run_conv(const Ctx &c, const ConvArgs &proto, int *nblocks) {
     // measured (B=1024 bf16, us under the profiler, NTW 2 -> 1): 128->128 992 -> 910, 128->64 890 -> 660, 64->64 501 -> 390,
     // 64->32 405 -> 319; whole step 13.44 -> 12.75 ms with NTW = 1 everywhere (MIVIT_DRN_NTW=2 selects the old wave tile)
     static const int ntw = [] { const char *e = getenv("MIVIT_DRN_NTW"); return e ? atoi(e) : 1; }();
-    if (ntw == 2) return run_conv_mm<T, CIN, COUT, SECOND, PRO, CIN2, MAXM, 2>(c, proto, nblocks, t, F);
-    return run_conv_mm<T, CIN, COUT, SECOND, PRO, CIN2, MAXM, 1>(c, proto, nblocks, t, F);
+    if (ntw == 2) return run_conv_mm<T, CIN, COUT, SECOND, PRO, EPI, MAXM, 2>(c, proto, nblocks, t, F);
+    return run_conv_mm<T, CIN, COUT, SECOND, PRO, EPI, MAXM, 1>(c, proto, nblocks, t, F);
 }
 
 template <typename T>
@@ -1163,7 +1222,7 @@ int forward_t(const Ctx &c, const float *x, float *tokens) {
         a = ConvArgs{};
         a.A = TileSrc{c.y(0), nullptr, c.fco(0), nullptr};
         a.W = at(c.ws, c.w.wf[1]); a.W2 = at(c.ws, c.w.wf[3]); a.out = c.y(1); a.out2 = c.y(3); a.stats = part; a.stats2 = part_b;
-        RC((run_conv<T, 32, 64, 1, PRO_ACT1, 32>(c, a, &nb)));
+        RC((run_conv<T, 32, 64, 1, PRO_ACT1, 1>(c, a, &nb)));
         RC(bn_produce(c, 1, 0, part, nb)); RC(bn_produce(c, 3, 1, part_b, nb));
     }
     if (c.in(2)) {   // block 1: conv2 (64->64) from relu(BN1(y11))
@@ -1171,7 +1230,7 @@ int forward_t(const Ctx &c, const float *x, float *tokens) {
         a = ConvArgs{};
         a.A = TileSrc{c.y(1), nullptr, c.fco(1), nullptr};
         a.W = at(c.ws, c.w.wf[2]); a.out = c.y(2); a.stats = part;
-        RC((run_conv<T, 64, 64, 0, PRO_ACT1, 64>(c, a, &nb)));
+        RC((run_conv<T, 64, 64, 0, PRO_ACT1, 1>(c, a, &nb)));
         RC(bn_produce(c, 2, 0, part, nb));
     }
     if (c.in(3)) {   // block 2: conv1 (64->128) + skip from o1 = relu(BN2(y12) + BN3(y1s))
@@ -1179,7 +1238,7 @@ int forward_t(const Ctx &c, const float *x, float *tokens) {
         a = ConvArgs{};
         a.A = TileSrc{c.y(2), c.y(3), c.fco(2), c.fco(3)};
         a.W = at(c.ws, c.w.wf[4]); a.W2 = at(c.ws, c.w.wf[6]); a.out = c.y(4); a.out2 = c.y(6); a.stats = part; a.stats2 = part_b;
-        RC((run_conv<T, 64, 128, 1, PRO_ACT2, 64>(c, a, &nb)));
+        RC((run_conv<T, 64, 128, 1, PRO_ACT2, 1>(c, a, &nb)));
         RC(bn_produce(c, 4, 0, part, nb)); RC(bn_produce(c, 6, 1, part_b, nb));
     }
     if (c.in(4)) {   // block 2: conv2 (128->128)
@@ -1187,7 +1246,7 @@ int forward_t(const Ctx &c, const float *x, float *tokens) {
         a = ConvArgs{};
         a.A = TileSrc{c.y(4), nullptr, c.fco(4), nullptr};
         a.W = at(c.ws, c.w.wf[5]); a.out = c.y(5); a.stats = part;
-        RC((run_conv<T, 128, 128, 0, PRO_ACT1, 128>(c, a, &nb)));
+        RC((run_conv<T, 128, 128, 0, PRO_ACT1, 1>(c, a, &nb)));
         RC(bn_produce(c, 5, 0, part, nb));
     }
     if (!c.in(5)) return 0;
@@ -1299,10 +1358,10 @@ int backward_t(const Ctx &c, const float *x, const float *dtokens, const mivit_d
         RC((run_wgrad<T, 128, 128, 9, PRO_ACT1>(c, a21, dy22, gr->conv[5].weight)));
         RC((run_wgrad<T, 64, 128, 1, PRO_ACT2>(c, o1, dy2s, gr->conv[6].weight)));
         a = ConvArgs{};
-        a.A = dy22; a.W = at(c.ws, c.w.wd[5]); a.out = X2;                                   // d a21 -> X2
-        RC((run_conv<T, 128, 128, 0, PRO_DY, 128>(c, a, nullptr)));
-        // ---- BatchNorm 4 (block 2 conv1): g21 in place in X2
-        RC((run_mask<T, 128, false, false>(c, X2, 4, 4, X2, &nb)));
+        // d a21, masked by a21's ReLU in the epilogue -> g21 in X2, with the sums for BatchNorm 4 (block 2 conv1)
+        a.A = dy22; a.W = at(c.ws, c.w.wd[5]); a.out = X2;
+        a.my = c.y(4); a.mca = c.fco(4); a.stats = c.part();
+        RC((run_conv<T, 128, 128, 0, PRO_DY, 2>(c, a, &nb)));
         RC(bwd_produce(c, 128, nb));
     }
     if (c.in(2)) {
@@ -1311,12 +1370,12 @@ int backward_t(const Ctx &c, const float *x, const float *dtokens, const mivit_d
         a = ConvArgs{};
         // d o1 -> X3 [R,64]: the 3x3 pass, then the skip's 1x1 pass adds to it
         a.A = dy21; a.W = at(c.ws, c.w.wd[4]); a.out = X3;
-        RC((run_conv<T, 128, 64, 0, PRO_DY, 128>(c, a, nullptr)));
+        RC((run_conv<T, 128, 64, 0, PRO_DY, 0>(c, a, nullptr)));
+        // ... whose epilogue applies block 1's output ReLU -> g1 in X3, with the sums for BatchNorm 2 (conv2) and 3 (skip)
         a = ConvArgs{};
         a.A = dy2s; a.W2 = at(c.ws, c.w.wd[6]); a.out = X3;
-        RC((run_conv<T, 128, 64, 3, PRO_DY, 128>(c, a, nullptr)));
-        // ---- block 1 output: g1 in place in X3 ; BatchNorm 2 (conv2) and 3 (skip)
-        RC((run_mask<T, 64, true, false>(c, X3, 2, 3, X3, &nb)));
+        a.my = c.y(2); a.my2 = c.y(3); a.mca = c.fco(2); a.mcb = c.fco(3); a.stats = c.part();
+        RC((run_conv<T, 128, 64, 3, PRO_DY, 3>(c, a, &nb)));
         RC(bwd_produce(c, 64, nb));
     }
     if (c.in(3)) {
@@ -1324,9 +1383,9 @@ int backward_t(const Ctx &c, const float *x, const float *dtokens, const mivit_d
         RC((run_wgrad<T, 64, 64, 9, PRO_ACT1>(c, a11, dy12, gr->conv[2].weight)));
         RC((run_wgrad<T, 32, 64, 1, PRO_ACT1>(c, a0, dy1s, gr->conv[3].weight)));
         a = ConvArgs{};
-        a.A = dy12; a.W = at(c.ws, c.w.wd[2]); a.out = X1;                                   // d a11 -> X1 [R,64]
-        RC((run_conv<T, 64, 64, 0, PRO_DY, 64>(c, a, nullptr)));
-        RC((run_mask<T, 64, false, false>(c, X1, 1, 1, X1, &nb)));
+        a.A = dy12; a.W = at(c.ws, c.w.wd[2]); a.out = X1;                                   // d a11, masked -> g11 in X1 [R,64]
+        a.my = c.y(1); a.mca = c.fco(1); a.stats = c.part();
+        RC((run_conv<T, 64, 64, 0, PRO_DY, 2>(c, a, &nb)));
         RC(bwd_produce(c, 64, nb));
     }
     if (c.in(4)) {
@@ -1334,11 +1393,11 @@ int backward_t(const Ctx &c, const float *x, const float *dtokens, const mivit_d
         RC((run_wgrad<T, 32, 64, 9, PRO_ACT1>(c, a0, dy11, gr->conv[1].weight)));
         a = ConvArgs{};
         a.A = dy11; a.W = at(c.ws, c.w.wd[1]); a.out = X2;                                     // d a0 -> X2 [R,32]
-        RC((run_conv<T, 64, 32, 0, PRO_DY, 64>(c, a, nullptr)));
+        RC((run_conv<T, 64, 32, 0, PRO_DY, 0>(c, a, nullptr)));
         a = ConvArgs{};
-        a.A = dy1s; a.W2 = at(c.ws, c.w.wd[3]); a.out = X2;
-        RC((run_conv<T, 64, 32, 3, PRO_DY, 64>(c, a, nullptr)));
-        RC((run_mask<T, 32, false, false>(c, X2, 0, 0, X2, &nb)));
+        a.A = dy1s; a.W2 = at(c.ws, c.w.wd[3]); a.out = X2;                                    // + skip term, masked -> g0
+        a.my = c.y(0); a.mca = c.fco(0); a.stats = c.part();
+        RC((run_conv<T, 64, 32, 3, PRO_DY, 2>(c, a, &nb)));
         RC(bwd_produce(c, 32, nb));
     }
     if (c.in(5)) {   // first convolution's weight gradient
