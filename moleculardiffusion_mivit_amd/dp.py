@@ -60,14 +60,18 @@ def broadcast_parameters(model, src: int = 0, group=None):
         dist.broadcast(b, src=src, group=group)
 
 
-def attach(model, group=None, broadcast: bool = True, sync_batchnorm: bool = False):
+def attach(model, group=None, broadcast: bool = True, sync_batchnorm=None):
     """Make `model` (a GeneralTransformer) data-parallel over `group`: gradients produced by its backward are
     averaged across ranks, overlapped stage by stage.  Parameters outside the arena (external embeddings) are
     averaged by `finish_external_grads` after backward.  `sync_batchnorm`: a DeepResNet embedding normalises with
-    the statistics of the whole job's minibatch instead of the rank's shard."""
+    the statistics of the whole job's minibatch instead of the rank's shard -- what the
+    reference's single device computes, hence the default (None = on whenever the embedding has BatchNorm; False
+    keeps per-rank statistics, as stock DDP does; True insists and raises for embeddings without BatchNorm)."""
     if broadcast:
         broadcast_parameters(model, 0, group)
     emb = getattr(model, "embedding", None)
+    if sync_batchnorm is None:
+        sync_batchnorm = hasattr(emb, "sync_batchnorm")
     if sync_batchnorm:
         if not hasattr(emb, "sync_batchnorm"):
             raise ValueError("sync_batchnorm=True needs a DeepResNetEmbedding (the only embedding with BatchNorm)")
