@@ -481,7 +481,7 @@ __global__ __launch_bounds__(NT, MM == MAXM ? 2 : 4) void drn_conv_kernel(const 
     build_row_tables(g, blockIdx.x, ROWS_PAD, rowg, rowc, tid);
     build_cell_tables(g, blockIdx.x, cellsrc, cellpos, Img<T, CIN>::CS, img.rowe, img.slote, tid, SECOND == 3);
     __syncthreads();
-    if (!(a.dbg & 1)) fill_image<T, CIN, PRO>(tileA, a.A, g, cellsrc, cellpos, tid);
+    if (!(a.dbg & 1)) fill_image<T, CIN, PRO, (MM == MAXM ? 8 : 4)>(tileA, a.A, g, cellsrc, cellpos, tid);
     __syncthreads();
 
     const int ng = wave % NG, mq = wave / NG, per = (NM + MQ - 1) / MQ, mt0 = mq * per;
@@ -1186,6 +1186,14 @@ int run_conv(const Ctx &c, const ConvArgs &proto, int *nblocks) {
     // 64->32 405 -> 319; whole step 13.44 -> 12.75 ms with NTW = 1 everywhere (MIVIT_DRN_NTW=2 selects the old wave tile)
     static const int ntw = [] { const char *e = getenv("MIVIT_DRN_NTW"); return e ? atoi(e) : 1; }();
     if (ntw == 2) return run_conv_mm<T, CIN, COUT, SECOND, PRO, EPI, MAXM, 2>(c, proto, nblocks, t, F);
+    if constexpr (SECOND == 3 && sizeof(T) == 2) {
+        // the 1x1 skip pass is memory-bound and its weights are 16 KB: half-size groups, two workgroups per CU (<= 80 KB,
+        // <= 128 VGPRs), so one group's fill runs under the other's epilogue (bf16 step 12.34 -> 12.04 ms; fp32: no gain)
+        static const int half3 = [] { const char *e = getenv("MIVIT_DRN_SKIP_HALF"); return e ? atoi(e) : 1; }();
+        constexpr int MMH = MAXM / 2;
+        const int Fh = slots_fit(t, [&](int f) { return conv_lds(c.dtype, t, f, CIN, 0, MMH); }, MMH, (size_t)80 * 1024);
+        if (half3 && Fh >= 1) return run_conv_mm<T, CIN, COUT, SECOND, PRO, EPI, MMH, 1>(c, proto, nblocks, t, Fh);
+    }
     return run_conv_mm<T, CIN, COUT, SECOND, PRO, EPI, MAXM, 1>(c, proto, nblocks, t, F);
 }
 
