@@ -85,6 +85,21 @@ def cpu_baseline(seconds=12.0):
                       f"train step, oracle/mivit_oracle.py on torch CPU fp32"}
 
 
+def launch_ranks(n):
+    """Start `n` ranks of this script (one per GPU) under torch.distributed.run and wait for them."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC (RCCL needs it on this pool)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -100,16 +115,30 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: this process has not touched the GPU (importing torch does not) and never
+        # will -- it starts the N ranks through torch.distributed.run as a CHILD process, relays their output (rank 0
+        # prints the JSON line) and exits with the children's return code.
+        sys.exit(launch_ranks(args.gpus))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            print(f"bench.py: --gpus {args.gpus} needs the torch.distributed.run launcher (WORLD_SIZE=1 here)",
-                  file=sys.stderr)
-            sys.exit(2)
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(2)
     import torch.distributed as dist
     # rehearsal knobs (not used by the driver): several ranks on ONE GPU over gloo, to exercise the launcher path
     if os.environ.get("MIVIT_BENCH_SHARE_GPU") == "1":
         local = 0
     backend = os.environ.get("MIVIT_DIST_BACKEND", "nccl")       # "nccl" IS RCCL on ROCm
+    if os.environ.get("MIVIT_BENCH_DRY") == "1":
+        # launcher rehearsal without a GPU (tests/test_bench_launcher.py): rendezvous over gloo, one collective, one line
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo")
+        tt = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        dist.all_reduce(tt)
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": dist.get_world_size(), "rank_sum": float(tt.item()),
+                              "steps": args.steps, "warmup": args.warmup}), flush=True)
+        dist.destroy_process_group()
+        return
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
@@ -234,7 +263,8 @@ def main():
                 pass
         line = {
             "metric": "training image-sequences/sec", "value": round(seqs / dt, 1), "unit": "sequences/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
+            "n_gpus": world, "rccl_ranks": (dist.get_world_size() if world > 1 and backend == "nccl" else 0),
+            "dist_backend": (backend if world > 1 else None), "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision,
             "data": "synthetic",
             "config": {"workload": "PSFNoise 32-frame 64x64 sequences, MiViT depth=4 dim=128 heads=4 hidden=256, linear "

@@ -23,6 +23,11 @@
 
 namespace {
 
+#ifdef MIVIT_DRN_PHASE_TIMING
+#define DRN_DBG(a) ((a).dbg)
+#else
+#define DRN_DBG(a) 0
+#endif
 constexpr int NT = 512, MAXM = 22;          // 8 waves; <= 352 output pixels (22 MFMA row tiles) per workgroup
 constexpr int CSTR = 128;                   // stride of the per-channel coefficient tables
 template <typename T> constexpr int vec_el() { return 16 / (int)sizeof(T); }
@@ -481,7 +486,7 @@ __global__ __launch_bounds__(NT, MM == MAXM ? 2 : 4) void drn_conv_kernel(const 
     build_row_tables(g, blockIdx.x, ROWS_PAD, rowg, rowc, tid);
     build_cell_tables(g, blockIdx.x, cellsrc, cellpos, Img<T, CIN>::CS, img.rowe, img.slote, tid, SECOND == 3);
     __syncthreads();
-    if (!(a.dbg & 1)) fill_image<T, CIN, PRO, (MM == MAXM ? 8 : 4)>(tileA, a.A, g, cellsrc, cellpos, tid);
+    if (!(DRN_DBG(a) & 1)) fill_image<T, CIN, PRO, (MM == MAXM ? 8 : 4)>(tileA, a.A, g, cellsrc, cellpos, tid);
     __syncthreads();
 
     const int ng = wave % NG, mq = wave / NG, per = (NM + MQ - 1) / MQ, mt0 = mq * per;
@@ -503,7 +508,7 @@ __global__ __launch_bounds__(NT, MM == MAXM ? 2 : 4) void drn_conv_kernel(const 
         w1[j] = static_cast<const T *>(a.W2) + co * CIN;
     }
 
-    if (a.dbg & 2) {
+    if (DRN_DBG(a) & 2) {
     } else if (SECOND == 3) {
         // start from what the 3x3 pass left in out (all loads of the lane issued together), add the 1x1 convolution
         const int gq = lane >> 4;
@@ -522,7 +527,7 @@ __global__ __launch_bounds__(NT, MM == MAXM ? 2 : 4) void drn_conv_kernel(const 
     } else {
         conv_accum<T, CIN, 9, NTW, MT>(acc, tileA, w9, hidx, nm, img.rowe, lane);
     }
-    if (!(a.dbg & 4))
+    if (!(DRN_DBG(a) & 4))
     conv_epilogue<T, COUT, NTW, MT, EPI>(acc, static_cast<T *>(a.out), EPI ? a.stats + (size_t)blockIdx.x * NSTAT * COUT : nullptr, red,
                                          rowg, mt0, nm, ng, lane, wave, tid, a);
     if (SECOND == 1) {
@@ -1163,7 +1168,11 @@ int bn_consume(const Ctx &c, int i, int k) {
 template <typename T, int CIN, int COUT, int SECOND, int PRO, int EPI, int MM, int NTW>
 int run_conv_mm(const Ctx &c, const ConvArgs &proto, int *nblocks, int t, int F) {
     ConvArgs a = proto;
+    // a launcher variant whose tile does not fit its LDS / row-tile budget must report it, never divide by it
+    MIVIT_CHECK(F >= 1 && F * t * t <= MM * 16, "deepresnet conv %d->%d: no frame slot fits (tile %d, %d row tiles, F=%d)", CIN, COUT, t, MM, F);
+#ifdef MIVIT_DRN_PHASE_TIMING   // phase-timing build only (results are wrong with a switch set): never defined in the shipped library
     { static const int dbg = [] { const char *e = getenv("MIVIT_DRN_DBG"); return e ? atoi(e) : 0; }(); a.dbg = dbg; }
+#endif
     a.g = make_geom(c.dtype, c.N, c.P, F);
     const size_t lds = conv_lds(c.dtype, t, F, CIN, 0, MM);
     auto kern = drn_conv_kernel<T, CIN, COUT, SECOND, PRO, EPI, MM, NTW>;
@@ -1318,6 +1327,7 @@ int run_wgrad(const Ctx &c, const TileSrc &A, const TileSrc &D, float *dW) {
     int t, nt;
     choose_tile(c.dtype, c.P, &t, &nt);
     const int F = slots_fit(t, [&](int f) { return wgrad_lds(c.dtype, t, f, CIN, COUT / CSPLIT); });
+    MIVIT_CHECK(F >= 1, "deepresnet wgrad %d->%d: no frame slot fits LDS (tile %d)", CIN, COUT, t);
     a.g = make_geom(c.dtype, c.N, c.P, F);
     a.ngroups = ceil_div(a.g.units, F);
     a.A = A; a.D = D; a.slab = static_cast<float *>(at(c.ws, c.w.slab));

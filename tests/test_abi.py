@@ -165,3 +165,35 @@ def test_datasets():
     assert len(d) == 4 and torch.equal(d[1][1], ft[1])
     xb, fb, yb = next(iter(torch.utils.data.DataLoader(d, batch_size=2)))
     assert xb.shape == (2, 3, 2) and fb.shape == (2, 2) and yb.shape == (2, 1)
+
+
+@pytest.mark.parametrize("P", [0, 5000])
+@pytest.mark.parametrize("staged", [False, True])
+def test_deepresnet_entries_reject_unsupported_frames_without_crashing(P, staged):
+    """A frame side the convolution tiling cannot serve (no frame slot fits a workgroup) must come back as an error
+    string -- the launchers divide by the slot count, so every entry checks it first (round-1 record: a host SIGFPE
+    from an experimental half-size launcher that skipped the check).  No kernel is launched: validation comes first."""
+    from moleculardiffusion_mivit_amd import _native as N
+    fake = 0x1000                                   # never dereferenced: the shape check precedes every launch
+    prm, gr = N.DeepResNetParams(), N.DeepResNetGrads()
+    for i in range(7):
+        prm.conv[i] = N.ConvBn(fake, fake, fake, None, None)
+        gr.conv[i] = N.ConvBnGrad(fake, fake, fake)
+    prm.fc_weight = prm.fc_bias = gr.fc_weight = gr.fc_bias = fake
+    vp = ctypes.c_void_p
+    assert N.lib.mivit_deepresnet_train_supported(N.BF16, P) == 0
+    assert N.lib.mivit_deepresnet_train_workspace_bytes(N.BF16, 4, P, 64) == 0
+    if staged:
+        rc_f = N.lib.mivit_deepresnet_train_fwd_stage(N.BF16, ctypes.addressof(prm), vp(fake), 4, P, 64, 0.1, 1e-5, vp(fake),
+                                                      vp(fake), 1 << 30, 1, vp(fake), vp(fake), None)
+        rc_b = N.lib.mivit_deepresnet_train_bwd_stage(N.BF16, ctypes.addressof(prm), vp(fake), vp(fake), 4, P, 64, 1e-5,
+                                                      ctypes.addressof(gr), vp(fake), 1 << 30, 1, vp(fake), vp(fake), None)
+    else:
+        rc_f = N.lib.mivit_deepresnet_train_fwd(N.BF16, ctypes.addressof(prm), vp(fake), 4, P, 64, 0.1, 1e-5, vp(fake),
+                                                vp(fake), 1 << 30, None)
+        rc_b = N.lib.mivit_deepresnet_train_bwd(N.BF16, ctypes.addressof(prm), vp(fake), vp(fake), 4, P, 64, 1e-5,
+                                                ctypes.addressof(gr), vp(fake), 1 << 30, None)
+    assert rc_f != 0 and rc_b != 0
+    assert "unsupported frame side" in N.last_error()
+    with pytest.raises(N.MivitError):
+        N.check(rc_b, "mivit_deepresnet_train_bwd")
