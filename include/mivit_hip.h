@@ -111,6 +111,30 @@ size_t mivit_wgrad_bf16_workspace_bytes(int M, int N, int K);
 int mivit_wgrad_bf16(const void *dy, int64_t lddy, const void *x, int64_t ldx, int M, int N, int K, float *dW, float *db,
                      void *workspace, size_t workspace_bytes, void *stream);
 
+/* Fused forward of the two halves of the post-norm encoder layer (helpers/models.py:97-108), bf16 mode, model width
+ * E = 128, feed-forward width F = 256, 4 heads of 32 (the PSFNoise 32x64x64 configuration); csrc/fused_fwd.hip.
+ * LayerNorm outputs travel NORMALISED: n = (z - mean) * rstd (bf16) with rstd per row (fp32); a consumer applies the
+ * producing LayerNorm's affine while loading, x = gamma_in * n_in + beta_in (gamma_in = beta_in = NULL: n_in is x).
+ *   attn_block_fwd: z = x + out_proj(softmax(q k^T / sqrt(32)) v), q|k|v = x Wqkv^T + bqkv   (models.py:33-59,100-102)
+ *                   one wavefront per sequence of S <= 64 tokens, weights resident in LDS, q/k/v, probabilities and
+ *                   the context never leave registers.  ctx [B*S, E] (the out-projection's input) is written for the
+ *                   weight gradient.
+ *   mlp_block_fwd : z = x + fc2(act(fc1 x))                                                     (models.py:72-77,104-106)
+ *                   one wavefront per 32 rows, the hidden activations never leave registers.
+ * Both: n_out = LNhat(z) (bf16), rstd[rows] (fp32).  Optional outputs (NULL = skip), for the unfused backward kernels:
+ * x_out = gamma_out * n_out + beta_out, z_out, mean, qkv_out [B*S, 3E], h_out / u_out [M, F] (post- / pre-activation).
+ * Weights are bf16 copies in the reference's [out, in] layout; biases and LayerNorm vectors fp32.
+ * mivit_fused_layer_supported tells whether a model shape can use them. */
+int mivit_fused_layer_supported(int dtype, int embed_dim, int hidden_dim, int num_heads, int tokens);
+int mivit_attn_block_fwd(const void *n_in, const float *gamma_in, const float *beta_in, const void *Wqkv_bf16,
+                         const float *bqkv, const void *Wo_bf16, const float *bo, const float *gamma_out,
+                         const float *beta_out, int B, int S, void *ctx, void *n_out, float *rstd, void *x_out,
+                         void *z_out, float *mean, void *qkv_out, void *stream);
+int mivit_mlp_block_fwd(const void *n_in, const float *gamma_in, const float *beta_in, const void *W1_bf16,
+                        const float *b1, const void *W2_bf16, const float *b2, const float *gamma_out,
+                        const float *beta_out, int M, int act, void *n_out, float *rstd, void *x_out, void *z_out,
+                        float *mean, void *h_out, void *u_out, void *stream);
+
 /* DeepResNetEmbedding in inference mode (helpers/models.py:230-257; ResidualBlock :202-228): conv3x3(1->32)+BN+ReLU,
  * ResidualBlock(32->64), ResidualBlock(64->128), global average pool, Linear(128->E), fused in one kernel that keeps F
  * whole frames in LDS.  Eval-mode BatchNorm is folded by the caller: conv weights are pre-scaled by

@@ -1,0 +1,531 @@
+// Fused forward kernels of the post-norm encoder layer, bf16 mode, E = 128 / F = 256 / head dim 32 (the PSFNoise
+// 32x64x64 configuration: reference helpers/models.py:97-108 TransformerEncoderLayerWithSkip, :33-59 attention,
+// :72-77 feed-forward):
+//
+//   attn_block_fwd :  n1 = LNhat( x + out_proj(attention(q_proj x, k_proj x, v_proj x)) )      one wave per SEQUENCE
+//   mlp_block_fwd  :  n2 = LNhat( x1 + fc2(act(fc1 x1)) )                                      one wave per 32 ROWS
+//
+// Both read their input ONCE and write the normalised output ONCE (+ the attention context, which the out-projection's
+// weight gradient needs).  Everything between lives in registers:
+//   * the layer weights sit in LDS for the lifetime of a persistent workgroup (one per CU, 8 waves), as MFMA operand
+//     images with a conflict-free row pitch;
+//   * a product is computed TRANSPOSED (weights as the MFMA row operand, activation rows as the column operand):
+//     the accumulator of Y^T (lane = activation row, registers = 4 consecutive output features) IS the column operand
+//     of the next product, once the next weight image is stored with the matching permutation of its contraction
+//     index (inside each block of 32: slot 8g+j <- k = 4g+j, slot 8g+4+j <- k = 16+4g+j).  QKV -> scores -> softmax
+//     -> PV -> out-projection -> residual -> LayerNorm, and FC1 -> activation -> FC2 -> residual -> LayerNorm, never
+//     touch LDS or HBM in between; V is computed un-transposed so that its accumulator (lane = head feature,
+//     registers = keys) is the operand of P V with the same key permutation as the probabilities.
+//   * LayerNorm outputs are stored NORMALISED (xhat = (z - mean) * rstd, bf16) with rstd per row; the consumer applies
+//     the affine (gamma * xhat + beta) while loading.  The backward needs exactly xhat and rstd, so neither the
+//     pre-norm sum nor the mean is kept.
+// Optional outputs (x = gamma * xhat + beta, the pre-norm sum z, q|k|v, h) serve the unfused backward kernels.
+#include "common.h"
+#include "stream_prims.h"
+#include <stdlib.h>
+#include <algorithm>
+
+#define RC(call) do { int rc_ = (call); if (rc_) return rc_; } while (0)
+
+namespace {
+
+constexpr int E = 128, F = 256, H = 4, DH = 32;
+constexpr int LDE = E + 16;          // LDS row pitch (elements) of a [*, 128] operand image: 288 B = 18 x 16 B
+constexpr int LDF = F + 16;          // ... of a [*, 256] image: 544 B = 34 x 16 B   (pitch = 2 mod 16 units: conflict-free b128)
+constexpr int NWAVES = 8, NTHREADS = NWAVES * 64;
+
+__device__ __forceinline__ bf16x8 pack8(const f32x4 a, const f32x4 b) {
+    bf16x8 f;
+    f[0] = (__bf16)a[0]; f[1] = (__bf16)a[1]; f[2] = (__bf16)a[2]; f[3] = (__bf16)a[3];
+    f[4] = (__bf16)b[0]; f[5] = (__bf16)b[1]; f[6] = (__bf16)b[2]; f[7] = (__bf16)b[3];
+    return f;
+}
+__device__ __forceinline__ float x4_sum(float v) {   // across the 4 lane groups (same lane & 15)
+    v += __shfl_xor(v, 16, 64);
+    return v + __shfl_xor(v, 32, 64);
+}
+__device__ __forceinline__ float x4_max(float v) {
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ f32x4 ld4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
+__device__ __forceinline__ bf16x8 lds_frag(const bf16 *p) { return *reinterpret_cast<const bf16x8 *>(p); }
+
+// 4 consecutive bf16 -> fp32 / fp32 -> 4 consecutive bf16 (8-byte global accesses)
+__device__ __forceinline__ f32x4 load4_bf16(const bf16 *p) {
+    const uint2 v = *reinterpret_cast<const uint2 *>(p);
+    return f32x4{__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
+                 __uint_as_float(v.y & 0xffff0000u)};
+}
+__device__ __forceinline__ void store4_bf16(bf16 *p, const f32x4 v) {
+    uint2 o;
+    o.x = (uint32_t)from_f32<bf16>(v[0]).v | ((uint32_t)from_f32<bf16>(v[1]).v << 16);
+    o.y = (uint32_t)from_f32<bf16>(v[2]).v | ((uint32_t)from_f32<bf16>(v[3]).v << 16);
+    *reinterpret_cast<uint2 *>(p) = o;
+}
+
+// natural [rows][K] bf16 weight block (row pitch ldw elements) -> LDS operand image with pitch LD
+template <int K, int LD>
+__device__ __forceinline__ void stage_natural(bf16 *img, const bf16 *W, int rows, int tid) {
+    for (int i = tid; i < rows * (K / 8); i += NTHREADS) {
+        const int r = i / (K / 8), c = i - r * (K / 8);
+        *reinterpret_cast<uint4 *>(img + r * LD + c * 8) = *reinterpret_cast<const uint4 *>(W + (int64_t)r * K + c * 8);
+    }
+}
+// the same with the contraction index permuted inside each block of 32 so that the 16-byte chunk g of block p holds
+// k = 32p + 4g + {0..3} and k = 32p + 16 + 4g + {0..3}: the operand that meets a packed accumulator pair
+template <int K, int LD>
+__device__ __forceinline__ void stage_permuted(bf16 *img, const bf16 *W, int rows, int tid) {
+    for (int i = tid; i < rows * (K / 8); i += NTHREADS) {
+        const int r = i / (K / 8), c = i - r * (K / 8), p = c >> 2, g = c & 3;
+        const uint2 lo = *reinterpret_cast<const uint2 *>(W + (int64_t)r * K + 32 * p + 4 * g);
+        const uint2 hi = *reinterpret_cast<const uint2 *>(W + (int64_t)r * K + 32 * p + 16 + 4 * g);
+        *reinterpret_cast<uint4 *>(img + r * LD + c * 8) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+    }
+}
+__device__ __forceinline__ void stage_vec(float *dst, const float *src, int n, float fill, int tid) {
+    for (int i = tid; i < n; i += NTHREADS) dst[i] = src ? src[i] : fill;
+}
+
+// column-operand fragments of 16 activation rows: lane (row = lane & 15, g) holds k = 32 ks + 8 g + 0..7 of
+// x = gamma * n + beta (rows beyond `rows_valid` are zero)
+__device__ __forceinline__ void load_x_frags(bf16x8 (&xf)[4], const bf16 *nin, int64_t row, bool valid, const float *gam,
+                                             const float *bet, bool affine, int g) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        uint4 raw = make_uint4(0u, 0u, 0u, 0u);
+        if (valid) raw = *reinterpret_cast<const uint4 *>(nin + row * E + ks * 32 + 8 * g);
+        if (affine) {
+            const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+            const f32x4 g0 = ld4(gam + ks * 32 + 8 * g), g1 = ld4(gam + ks * 32 + 8 * g + 4);
+            const f32x4 b0 = ld4(bet + ks * 32 + 8 * g), b1 = ld4(bet + ks * 32 + 8 * g + 4);
+            f32x4 lo, hi;
+            lo[0] = __uint_as_float(w[0] << 16); lo[1] = __uint_as_float(w[0] & 0xffff0000u);
+            lo[2] = __uint_as_float(w[1] << 16); lo[3] = __uint_as_float(w[1] & 0xffff0000u);
+            hi[0] = __uint_as_float(w[2] << 16); hi[1] = __uint_as_float(w[2] & 0xffff0000u);
+            hi[2] = __uint_as_float(w[3] << 16); hi[3] = __uint_as_float(w[3] & 0xffff0000u);
+            lo = valid ? lo * g0 + b0 : f32x4{0.f, 0.f, 0.f, 0.f};
+            hi = valid ? hi * g1 + b1 : f32x4{0.f, 0.f, 0.f, 0.f};
+            xf[ks] = pack8(lo, hi);
+        } else {
+            xf[ks] = __builtin_bit_cast(bf16x8, raw);
+        }
+    }
+}
+
+// ---- shared epilogue: z^T accumulators (8 feature tiles of one 16-row block) + residual -> LayerNorm -> stores ----
+struct LnOut {
+    bf16 *nout; float *rstd;          // normalised output + 1/std per row (always)
+    bf16 *xout;                       // optional: gamma * nhat + beta
+    bf16 *zout; float *mean;          // optional: pre-norm sum and mean (unfused backward)
+};
+__device__ __forceinline__ void residual_ln_store(f32x4 (&z)[8], const bf16 *nin, int64_t row, bool valid, const float *gin,
+                                                  const float *bin, bool affine_in, const float *gout, const float *bout,
+                                                  const LnOut &o, int g) {
+    float s = 0.f;
+#pragma unroll
+    for (int et = 0; et < 8; ++et) {
+        f32x4 x = valid ? load4_bf16(nin + row * E + 16 * et + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (affine_in) x = x * ld4(gin + 16 * et + 4 * g) + ld4(bin + 16 * et + 4 * g);
+        z[et] += x;
+        s += z[et][0] + z[et][1] + z[et][2] + z[et][3];
+    }
+    const float mu = x4_sum(s) * (1.f / E);
+    float q = 0.f;
+#pragma unroll
+    for (int et = 0; et < 8; ++et)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float d = z[et][j] - mu; q += d * d; }
+    const float rs = rsqrtf(x4_sum(q) * (1.f / E) + 1e-5f);
+    if (!valid) return;
+#pragma unroll
+    for (int et = 0; et < 8; ++et) {
+        const int c = 16 * et + 4 * g;
+        if (o.zout) store4_bf16(o.zout + row * E + c, z[et]);
+        f32x4 nh;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) nh[j] = (z[et][j] - mu) * rs;
+        store4_bf16(o.nout + row * E + c, nh);
+        if (o.xout) store4_bf16(o.xout + row * E + c, nh * ld4(gout + c) + ld4(bout + c));
+    }
+    if (g == 0) {
+        o.rstd[row] = rs;
+        if (o.mean) o.mean[row] = mu;
+    }
+}
+
+// ================================================================================================================
+// MLP block
+// ================================================================================================================
+struct MlpFwdArgs {
+    const bf16 *nin; const float *gin, *bin;      // input rows [M, E] (normalised; affine gin/bin, or null = identity)
+    const bf16 *W1; const float *b1;              // fc1 [F, E] bf16 copy, bias fp32
+    const bf16 *W2; const float *b2;              // fc2 [E, F]
+    const float *gout, *bout;                     // this sub-layer's LayerNorm affine (only for xout)
+    int M, act;
+    LnOut o;
+    bf16 *hout, *uout;                            // optional: post-activation h [M, F] and pre-activation (GELU backward)
+};
+
+constexpr int MLP_LDS_W1 = F * LDE * 2, MLP_LDS_W2 = E * LDF * 2;
+constexpr int MLP_VEC = E * 5 + F;               // gin, bin, b2, gout, bout [E] + b1 [F]
+constexpr int MLP_LDS = MLP_LDS_W1 + MLP_LDS_W2 + MLP_VEC * 4;
+static_assert(MLP_LDS <= 160 * 1024, "LDS budget");
+
+template <int NR>
+__global__ __launch_bounds__(NTHREADS) void mlp_block_fwd_kernel(const MlpFwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16 *W1i = reinterpret_cast<bf16 *>(smem);
+    bf16 *W2i = reinterpret_cast<bf16 *>(smem + MLP_LDS_W1);
+    float *vec = reinterpret_cast<float *>(smem + MLP_LDS_W1 + MLP_LDS_W2);
+    float *gin = vec, *bin = vec + E, *b2 = vec + 2 * E, *gout = vec + 3 * E, *bout = vec + 4 * E, *b1 = vec + 5 * E;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, cq = lane & 15;
+    stage_natural<E, LDE>(W1i, a.W1, F, tid);
+    stage_permuted<F, LDF>(W2i, a.W2, E, tid);
+    stage_vec(gin, a.gin, E, 1.f, tid); stage_vec(bin, a.bin, E, 0.f, tid); stage_vec(b2, a.b2, E, 0.f, tid);
+    stage_vec(gout, a.gout, E, 1.f, tid); stage_vec(bout, a.bout, E, 0.f, tid); stage_vec(b1, a.b1, F, 0.f, tid);
+    __syncthreads();
+    const bool affine_in = a.gin != nullptr;
+    const int ntiles = (a.M + 16 * NR - 1) / (16 * NR);
+    for (int tile = blockIdx.x * NWAVES + wave; tile < ntiles; tile += gridDim.x * NWAVES) {
+        const int64_t row0 = (int64_t)tile * 16 * NR;
+        bf16x8 xf[NR][4];
+#pragma unroll
+        for (int rb = 0; rb < NR; ++rb) {
+            const int64_t row = row0 + rb * 16 + cq;
+            load_x_frags(xf[rb], a.nin, row, row < a.M, gin, bin, affine_in, g);
+        }
+        f32x4 fa[8][NR];
+#pragma unroll
+        for (int et = 0; et < 8; ++et) {
+            const f32x4 bv = ld4(b2 + 16 * et + 4 * g);
+#pragma unroll
+            for (int rb = 0; rb < NR; ++rb) fa[et][rb] = bv;
+        }
+#pragma unroll 2
+        for (int p = 0; p < F / 32; ++p) {
+            // h^T for hidden units 32p .. 32p+31 (two feature tiles), all NR row blocks
+            f32x4 ha[2][NR];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const f32x4 bv = ld4(b1 + 32 * p + 16 * t + 4 * g);
+#pragma unroll
+                for (int rb = 0; rb < NR; ++rb) ha[t][rb] = bv;
+            }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const bf16x8 w = lds_frag(W1i + (32 * p + 16 * t + cq) * LDE + ks * 32 + 8 * g);
+#pragma unroll
+                    for (int rb = 0; rb < NR; ++rb) ha[t][rb] = mma(w, xf[rb][ks], ha[t][rb]);
+                }
+            bf16x8 hf[NR];
+#pragma unroll
+            for (int rb = 0; rb < NR; ++rb) {
+                const int64_t row = row0 + rb * 16 + cq;
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    if (a.uout && row < a.M) store4_bf16(a.uout + row * F + 32 * p + 16 * t + 4 * g, ha[t][rb]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) ha[t][rb][j] = act_fwd(a.act, ha[t][rb][j]);
+                    if (a.hout && row < a.M) store4_bf16(a.hout + row * F + 32 * p + 16 * t + 4 * g, ha[t][rb]);
+                }
+                hf[rb] = pack8(ha[0][rb], ha[1][rb]);
+            }
+            // f^T += W2[:, block p (permuted)] h^T
+#pragma unroll
+            for (int et = 0; et < 8; ++et) {
+                const bf16x8 w = lds_frag(W2i + (16 * et + cq) * LDF + p * 32 + 8 * g);
+#pragma unroll
+                for (int rb = 0; rb < NR; ++rb) fa[et][rb] = mma(w, hf[rb], fa[et][rb]);
+            }
+        }
+#pragma unroll
+        for (int rb = 0; rb < NR; ++rb) {
+            const int64_t row = row0 + rb * 16 + cq;
+            f32x4 z[8];
+#pragma unroll
+            for (int et = 0; et < 8; ++et) z[et] = fa[et][rb];
+            residual_ln_store(z, a.nin, row, row < a.M, gin, bin, affine_in, gout, bout, a.o, g);
+        }
+    }
+}
+
+// ================================================================================================================
+// attention block
+// ================================================================================================================
+struct AttnFwdArgs {
+    const bf16 *nin; const float *gin, *bin;      // input tokens [B*S, E]
+    const bf16 *Wqkv; const float *bqkv;          // [3E, E] (q | k | v rows), [3E]
+    const bf16 *Wo; const float *bo;              // [E, E]
+    const float *gout, *bout;
+    int B, S;
+    bf16 *ctx;                                    // [B*S, E] attention output before the out-projection (kept: dW_o needs it)
+    LnOut o;
+    bf16 *qkvout;                                 // optional [B*S, 3E] (unfused attention backward)
+};
+
+constexpr int ATT_LDS_WQKV = 3 * E * LDE * 2, ATT_LDS_WO = E * LDE * 2;
+constexpr int ATT_VEC = E * 5 + 3 * E;           // gin, bin, bo, gout, bout + bqkv
+constexpr int ATT_LDS = ATT_LDS_WQKV + ATT_LDS_WO + ATT_VEC * 4;
+static_assert(ATT_LDS <= 160 * 1024, "LDS budget");
+
+template <int NT>      // row tiles per sequence: S <= 16 * NT
+__global__ __launch_bounds__(NTHREADS) void attn_block_fwd_kernel(const AttnFwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NP = (NT + 1) / 2;
+    bf16 *Wq = reinterpret_cast<bf16 *>(smem);
+    bf16 *Wo = reinterpret_cast<bf16 *>(smem + ATT_LDS_WQKV);
+    float *vec = reinterpret_cast<float *>(smem + ATT_LDS_WQKV + ATT_LDS_WO);
+    float *gin = vec, *bin = vec + E, *bo = vec + 2 * E, *gout = vec + 3 * E, *bout = vec + 4 * E, *bqkv = vec + 5 * E;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, cq = lane & 15;
+    stage_natural<E, LDE>(Wq, a.Wqkv, 3 * E, tid);
+    stage_permuted<E, LDE>(Wo, a.Wo, E, tid);
+    stage_vec(gin, a.gin, E, 1.f, tid); stage_vec(bin, a.bin, E, 0.f, tid); stage_vec(bo, a.bo, E, 0.f, tid);
+    stage_vec(gout, a.gout, E, 1.f, tid); stage_vec(bout, a.bout, E, 0.f, tid); stage_vec(bqkv, a.bqkv, 3 * E, 0.f, tid);
+    __syncthreads();
+    const bool affine_in = a.gin != nullptr;
+    const int S = a.S;
+    const float scale = 0.17677669529663687f;       // 1 / sqrt(32)
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+
+    for (int b = blockIdx.x * NWAVES + wave; b < a.B; b += gridDim.x * NWAVES) {
+        const int64_t base = (int64_t)b * S;
+        bf16x8 xf[NT][4];
+#pragma unroll
+        for (int rt = 0; rt < NT; ++rt) load_x_frags(xf[rt], a.nin, base + rt * 16 + cq, rt * 16 + cq < S, gin, bin, affine_in, g);
+        bf16x8 cf[H][NT];                            // context, as the column operand of the out-projection
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- q^T, k^T (lane = token, registers = 4 head features), one after the other (register budget) ----
+            bf16x8 qf[NT], kf[NT];
+#pragma unroll
+            for (int which = 0; which < 2; ++which) {
+                f32x4 pa[2][NT];
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const f32x4 bb = ld4(bqkv + which * E + h * DH + 16 * dt + 4 * g);
+#pragma unroll
+                    for (int rt = 0; rt < NT; ++rt) pa[dt][rt] = bb;
+                }
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) {
+                        const bf16x8 w = lds_frag(Wq + (which * E + h * DH + 16 * dt + cq) * LDE + ks * 32 + 8 * g);
+#pragma unroll
+                        for (int rt = 0; rt < NT; ++rt) pa[dt][rt] = mma(w, xf[rt][ks], pa[dt][rt]);
+                    }
+#pragma unroll
+                for (int rt = 0; rt < NT; ++rt) {
+                    if (which == 0) qf[rt] = pack8(pa[0][rt], pa[1][rt]);
+                    else kf[rt] = pack8(pa[0][rt], pa[1][rt]);
+                    if (a.qkvout && rt * 16 + cq < S) {
+                        bf16 *dst = a.qkvout + (base + rt * 16 + cq) * (3 * E) + which * E + h * DH + 4 * g;
+                        store4_bf16(dst, pa[0][rt]); store4_bf16(dst + 16, pa[1][rt]);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- v (lane = head feature, registers = 4 tokens): the operand of P V with keys as contraction index ----
+            bf16x8 vr[NP][2];
+            {
+                f32x4 va[NT][2];
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const float bv = bqkv[2 * E + h * DH + 16 * dt + cq];
+#pragma unroll
+                    for (int rt = 0; rt < NT; ++rt) va[rt][dt] = f32x4{bv, bv, bv, bv};
+                }
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) {
+                        const bf16x8 wv = lds_frag(Wq + (2 * E + h * DH + 16 * dt + cq) * LDE + ks * 32 + 8 * g);
+#pragma unroll
+                        for (int rt = 0; rt < NT; ++rt) va[rt][dt] = mma(xf[rt][ks], wv, va[rt][dt]);
+                    }
+#pragma unroll
+                for (int p = 0; p < NP; ++p)
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) vr[p][dt] = pack8(va[2 * p][dt], (2 * p + 1 < NT) ? va[2 * p + 1][dt] : zero);
+                if (a.qkvout) {
+#pragma unroll
+                    for (int rt = 0; rt < NT; ++rt)
+#pragma unroll
+                        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const int tok = rt * 16 + 4 * g + j;
+                                if (tok < S) a.qkvout[(base + tok) * (3 * E) + 2 * E + h * DH + 16 * dt + cq] = from_f32<bf16>(va[rt][dt][j]);
+                            }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- scores, softmax, P V per query tile ----
+#pragma unroll
+            for (int it = 0; it < NT; ++it) {
+                f32x4 st[NT];                        // S^T tile: lane = query it*16 + cq, registers = keys 16 j + 4 g + r
+                float m = -INFINITY;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    st[j] = mma(kf[j], qf[it], zero);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        st[j][r] = (j * 16 + 4 * g + r < S) ? st[j][r] * scale : -INFINITY;
+                        m = fmaxf(m, st[j][r]);
+                    }
+                }
+                m = x4_max(m);
+                float sum = 0.f;
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float e = (j * 16 + 4 * g + r < S) ? __expf(st[j][r] - m) : 0.f;
+                        st[j][r] = e;
+                        sum += e;
+                    }
+                const float inv = 1.f / x4_sum(sum);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) st[j] *= inv;
+                f32x4 ot[2] = {zero, zero};          // O^T: lane = query, registers = head features 16 dt + 4 g + r
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    const bf16x8 pf = pack8(st[2 * p], (2 * p + 1 < NT) ? st[2 * p + 1] : zero);
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) ot[dt] = mma(vr[p][dt], pf, ot[dt]);
+                }
+                cf[h][it] = pack8(ot[0], ot[1]);
+                if (it * 16 + cq < S) {
+                    bf16 *dst = a.ctx + (base + it * 16 + cq) * E + h * DH + 4 * g;
+                    store4_bf16(dst, ot[0]); store4_bf16(dst + 16, ot[1]);
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- out-projection (+ bias), residual, LayerNorm ----
+        f32x4 oa[8][NT];
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt) {
+            const f32x4 bv = ld4(bo + 16 * nt + 4 * g);
+#pragma unroll
+            for (int rt = 0; rt < NT; ++rt) oa[nt][rt] = bv;
+        }
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt) {
+                const bf16x8 w = lds_frag(Wo + (16 * nt + cq) * LDE + h * 32 + 8 * g);
+#pragma unroll
+                for (int rt = 0; rt < NT; ++rt) oa[nt][rt] = mma(w, cf[h][rt], oa[nt][rt]);
+            }
+            __builtin_amdgcn_sched_barrier(0);      // keeps the weight-fragment reads of later heads from piling up
+        }
+#pragma unroll
+        for (int rt = 0; rt < NT; ++rt) {
+            f32x4 z[8];
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt) z[nt] = oa[nt][rt];
+            residual_ln_store(z, a.nin, base + rt * 16 + cq, rt * 16 + cq < S, gin, bin, affine_in, gout, bout, a.o, g);
+        }
+    }
+}
+
+bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+template <typename Kern>
+int set_lds(Kern k, int bytes) {
+    MIVIT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    return 0;
+}
+
+}  // namespace
+
+bool fused_layer_supported(int dtype, int E_, int F_, int H_, int S) {
+    static const bool off = getenv("MIVIT_NO_FUSED_LAYER") != nullptr;
+    return !off && dtype == MIVIT_BF16 && E_ == E && F_ == F && H_ == H && S >= 1 && S <= 64;
+}
+
+int launch_mlp_block_fwd(const void *nin, const float *gin, const float *bin, const void *W1, const float *b1, const void *W2,
+                         const float *b2, const float *gout, const float *bout, int M, int act, void *nout, float *rstd,
+                         void *xout, void *zout, float *mean, void *hout, void *uout, hipStream_t s) {
+    MIVIT_CHECK(nin && W1 && b1 && W2 && b2 && nout && rstd && M > 0, "mlp_block_fwd: null pointer / empty problem");
+    MIVIT_CHECK((gin == nullptr) == (bin == nullptr), "mlp_block_fwd: input affine needs both gamma and beta");
+    MIVIT_CHECK(!xout || (gout && bout), "mlp_block_fwd: xout needs the LayerNorm affine");
+    MIVIT_CHECK(aligned16(nin) && aligned16(W1) && aligned16(W2) && aligned16(nout) && aligned16(xout) && aligned16(zout) &&
+                aligned16(hout) && aligned16(uout), "mlp_block_fwd: pointers must be 16-byte aligned");
+    MlpFwdArgs a{};
+    a.nin = static_cast<const bf16 *>(nin); a.gin = gin; a.bin = bin;
+    a.W1 = static_cast<const bf16 *>(W1); a.b1 = b1; a.W2 = static_cast<const bf16 *>(W2); a.b2 = b2;
+    a.gout = gout; a.bout = bout; a.M = M; a.act = act;
+    a.o = LnOut{static_cast<bf16 *>(nout), rstd, static_cast<bf16 *>(xout), static_cast<bf16 *>(zout), mean};
+    a.hout = static_cast<bf16 *>(hout); a.uout = static_cast<bf16 *>(uout);
+    constexpr int NR = 2;
+    auto kern = mlp_block_fwd_kernel<NR>;
+    RC(set_lds(kern, MLP_LDS));
+    const int ntiles = ceil_div(M, 16 * NR);
+    const int grid = std::min(256, ceil_div(ntiles, NWAVES));
+    ProfScope prof(s);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), MLP_LDS, s, a);
+    MIVIT_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_attn_block_fwd(const void *nin, const float *gin, const float *bin, const void *Wqkv, const float *bqkv,
+                          const void *Wo, const float *bo, const float *gout, const float *bout, int B, int S, void *ctx,
+                          void *nout, float *rstd, void *xout, void *zout, float *mean, void *qkvout, hipStream_t s) {
+    MIVIT_CHECK(nin && Wqkv && bqkv && Wo && bo && ctx && nout && rstd && B > 0, "attn_block_fwd: null pointer / empty problem");
+    MIVIT_CHECK(S >= 1 && S <= 64, "attn_block_fwd: %d tokens per sequence (supported: 1..64)", S);
+    MIVIT_CHECK((gin == nullptr) == (bin == nullptr), "attn_block_fwd: input affine needs both gamma and beta");
+    MIVIT_CHECK(!xout || (gout && bout), "attn_block_fwd: xout needs the LayerNorm affine");
+    MIVIT_CHECK(aligned16(nin) && aligned16(Wqkv) && aligned16(Wo) && aligned16(ctx) && aligned16(nout) && aligned16(xout) &&
+                aligned16(zout) && aligned16(qkvout), "attn_block_fwd: pointers must be 16-byte aligned");
+    AttnFwdArgs a{};
+    a.nin = static_cast<const bf16 *>(nin); a.gin = gin; a.bin = bin;
+    a.Wqkv = static_cast<const bf16 *>(Wqkv); a.bqkv = bqkv; a.Wo = static_cast<const bf16 *>(Wo); a.bo = bo;
+    a.gout = gout; a.bout = bout; a.B = B; a.S = S; a.ctx = static_cast<bf16 *>(ctx);
+    a.o = LnOut{static_cast<bf16 *>(nout), rstd, static_cast<bf16 *>(xout), static_cast<bf16 *>(zout), mean};
+    a.qkvout = static_cast<bf16 *>(qkvout);
+    const int grid = std::min(256, ceil_div(B, NWAVES));
+    const int nt = ceil_div(S, 16);
+    ProfScope prof(s);
+#define ATT_LAUNCH(NT_)                                                                          \
+    do {                                                                                         \
+        auto kern = attn_block_fwd_kernel<NT_>;                                                  \
+        RC(set_lds(kern, ATT_LDS));                                                              \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), ATT_LDS, s, a);                     \
+    } while (0)
+    switch (nt) {
+        case 1: ATT_LAUNCH(1); break;
+        case 2: ATT_LAUNCH(2); break;
+        case 3: ATT_LAUNCH(3); break;
+        default: ATT_LAUNCH(4); break;
+    }
+#undef ATT_LAUNCH
+    MIVIT_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- operator-level C-ABI (tests, external callers) ----
+extern "C" int mivit_fused_layer_supported(int dtype, int embed_dim, int hidden_dim, int num_heads, int tokens) {
+    return fused_layer_supported(dtype, embed_dim, hidden_dim, num_heads, tokens) ? 1 : 0;
+}
+extern "C" int mivit_mlp_block_fwd(const void *n_in, const float *gamma_in, const float *beta_in, const void *W1_bf16,
+                                   const float *b1, const void *W2_bf16, const float *b2, const float *gamma_out,
+                                   const float *beta_out, int M, int act, void *n_out, float *rstd, void *x_out, void *z_out,
+                                   float *mean, void *h_out, void *u_out, void *stream) {
+    prof_set_tag(MIVIT_PROF_OP);
+    return launch_mlp_block_fwd(n_in, gamma_in, beta_in, W1_bf16, b1, W2_bf16, b2, gamma_out, beta_out, M, act, n_out, rstd,
+                                x_out, z_out, mean, h_out, u_out, static_cast<hipStream_t>(stream));
+}
+extern "C" int mivit_attn_block_fwd(const void *n_in, const float *gamma_in, const float *beta_in, const void *Wqkv_bf16,
+                                    const float *bqkv, const void *Wo_bf16, const float *bo, const float *gamma_out,
+                                    const float *beta_out, int B, int S, void *ctx, void *n_out, float *rstd, void *x_out,
+                                    void *z_out, float *mean, void *qkv_out, void *stream) {
+    prof_set_tag(MIVIT_PROF_OP);
+    return launch_attn_block_fwd(n_in, gamma_in, beta_in, Wqkv_bf16, bqkv, Wo_bf16, bo, gamma_out, beta_out, B, S, ctx, n_out,
+                                 rstd, x_out, z_out, mean, qkv_out, static_cast<hipStream_t>(stream));
+}

@@ -338,3 +338,56 @@ def deepresnet_infer(x, dtype, eps, running, params, chunk_frames: int = 8192):
         N.check(N.lib.mivit_deepresnet_infer(code, ctypes.addressof(prm), _p(x[f0:f0 + m]), m, p, e, float(eps), _p(out[f0:f0 + m]),
                                              _p(ws), ws.numel(), _s(x)), "mivit_deepresnet_infer")
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# fused encoder-layer blocks (csrc/fused_fwd.hip), bf16 mode, E = 128 / F = 256 / 4 heads
+# ---------------------------------------------------------------------------------------------------------------
+def fused_layer_supported(embed_dim: int, hidden_dim: int, num_heads: int, tokens: int) -> bool:
+    return bool(N.lib.mivit_fused_layer_supported(N.BF16, embed_dim, hidden_dim, num_heads, tokens))
+
+
+def _f32(t):
+    return None if t is None else t.contiguous().float()
+
+
+@torch.no_grad()
+def attn_block_fwd(n_in, gamma_in, beta_in, Wqkv, bqkv, Wo, bo, gamma_out, beta_out, extras=False):
+    """n_in [B,S,E] bf16 (normalised tokens; x = gamma_in * n_in + beta_in, or n_in itself when gamma_in is None);
+    Wqkv [3E,E] / Wo [E,E] bf16; returns dict(n, rstd, ctx[, x, z, mean, qkv]) -- reference models.py:33-59,100-102."""
+    _gpu(n_in, Wqkv, Wo)
+    B, S, E = n_in.shape
+    n_in = n_in.contiguous()
+    dev = n_in.device
+    out = {"n": torch.empty(B, S, E, dtype=torch.bfloat16, device=dev), "rstd": torch.empty(B, S, device=dev),
+           "ctx": torch.empty(B, S, E, dtype=torch.bfloat16, device=dev)}
+    if extras:
+        out.update(x=torch.empty_like(out["n"]), z=torch.empty_like(out["n"]), mean=torch.empty(B, S, device=dev),
+                   qkv=torch.empty(B, S, 3 * E, dtype=torch.bfloat16, device=dev))
+    gi, bi, go, bo_ = _f32(gamma_in), _f32(beta_in), _f32(gamma_out), _f32(beta_out)
+    bq, bo2 = _f32(bqkv), _f32(bo)
+    N.check(N.lib.mivit_attn_block_fwd(_p(n_in), _p(gi), _p(bi), _p(Wqkv.contiguous()), _p(bq), _p(Wo.contiguous()), _p(bo2),
+                                       _p(go), _p(bo_), B, S, _p(out["ctx"]), _p(out["n"]), _p(out["rstd"]), _p(out.get("x")),
+                                       _p(out.get("z")), _p(out.get("mean")), _p(out.get("qkv")), _s(n_in)),
+            "mivit_attn_block_fwd")
+    return out
+
+
+@torch.no_grad()
+def mlp_block_fwd(n_in, gamma_in, beta_in, W1, b1, W2, b2, gamma_out, beta_out, act=N.ACT_RELU, extras=False):
+    """n_in [M,E] bf16; W1 [F,E], W2 [E,F] bf16; returns dict(n, rstd[, x, z, mean, h, u]) -- models.py:72-77,104-106."""
+    _gpu(n_in, W1, W2)
+    M, E = n_in.shape
+    Fh = W1.shape[0]
+    n_in = n_in.contiguous()
+    dev = n_in.device
+    out = {"n": torch.empty(M, E, dtype=torch.bfloat16, device=dev), "rstd": torch.empty(M, device=dev)}
+    if extras:
+        out.update(x=torch.empty_like(out["n"]), z=torch.empty_like(out["n"]), mean=torch.empty(M, device=dev),
+                   h=torch.empty(M, Fh, dtype=torch.bfloat16, device=dev), u=torch.empty(M, Fh, dtype=torch.bfloat16, device=dev))
+    gi, bi, go, bo_ = _f32(gamma_in), _f32(beta_in), _f32(gamma_out), _f32(beta_out)
+    b1f, b2f = _f32(b1), _f32(b2)
+    N.check(N.lib.mivit_mlp_block_fwd(_p(n_in), _p(gi), _p(bi), _p(W1.contiguous()), _p(b1f), _p(W2.contiguous()), _p(b2f),
+                                      _p(go), _p(bo_), M, act, _p(out["n"]), _p(out["rstd"]), _p(out.get("x")), _p(out.get("z")),
+                                      _p(out.get("mean")), _p(out.get("h")), _p(out.get("u")), _s(n_in)), "mivit_mlp_block_fwd")
+    return out

@@ -1,0 +1,150 @@
+"""Fused encoder-layer block kernels (csrc/fused_fwd.hip, csrc/fused_bwd.hip) against plain torch fp32 arithmetic
+of reference helpers/models.py:33-59 (attention), :72-77 (feed-forward), :97-108 (post-norm wiring), evaluated on the
+bf16-rounded operands the kernels see.  Tolerance 3e-2 relative (bf16 operands, fp32 accumulate) on every output;
+small-integer cases are exact."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+E, FH, H = 128, 256, 4
+
+
+def _rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def _mk(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def _bf(t):
+    return t.to(torch.bfloat16)
+
+
+ACTS = {1: F.relu, 2: F.leaky_relu, 3: F.gelu}
+
+
+def _ln_hat(z):
+    mu = z.mean(-1, keepdim=True)
+    var = ((z - mu) ** 2).mean(-1, keepdim=True)
+    rstd = torch.rsqrt(var + 1e-5)
+    return (z - mu) * rstd, mu.squeeze(-1), rstd.squeeze(-1)
+
+
+@pytest.mark.parametrize("M", [1, 33, 264, 1000, 4097])
+@pytest.mark.parametrize("act", [1, 2, 3])
+@pytest.mark.parametrize("affine", [False, True])
+def test_mlp_block_fwd(M, act, affine):
+    from moleculardiffusion_mivit_amd import ops
+    n_in = _bf(_mk((M, E), 1))
+    gi, bi = (1.0 + 0.3 * _mk((E,), 2), 0.2 * _mk((E,), 3)) if affine else (None, None)
+    W1, b1 = _bf(_mk((FH, E), 4, 1 / math.sqrt(E))), 0.1 * _mk((FH,), 5)
+    W2, b2 = _bf(_mk((E, FH), 6, 1 / math.sqrt(FH))), 0.1 * _mk((E,), 7)
+    go, bo = 1.0 + 0.3 * _mk((E,), 8), 0.2 * _mk((E,), 9)
+    x = n_in.float() * gi + bi if affine else n_in.float()
+    xb = _bf(x).float()                       # the MFMA operand is the bf16-rounded x; the residual uses fp32 x
+    u = F.linear(xb, W1.float(), b1)
+    h = ACTS[act](u)
+    z = x + F.linear(_bf(h).float(), W2.float(), b2)
+    nh, mu, rstd = _ln_hat(z)
+    out = ops.mlp_block_fwd(n_in.cuda(), gi.cuda() if affine else None, bi.cuda() if affine else None, W1.cuda(), b1.cuda(),
+                            W2.cuda(), b2.cuda(), go.cuda(), bo.cuda(), act=act, extras=True)
+    torch.cuda.synchronize()
+    assert _rel(out["u"].float(), u) < 2e-2
+    assert _rel(out["h"].float(), h) < 2e-2
+    assert _rel(out["z"].float(), z) < 2e-2
+    assert _rel(out["n"].float(), nh) < 3e-2
+    assert _rel(out["x"].float(), nh * go + bo) < 3e-2
+    assert _rel(out["rstd"], rstd) < 1e-2
+    assert float((out["mean"].cpu() - mu).abs().max()) < 2e-2
+    lean = ops.mlp_block_fwd(n_in.cuda(), gi.cuda() if affine else None, bi.cuda() if affine else None, W1.cuda(), b1.cuda(),
+                             W2.cuda(), b2.cuda(), go.cuda(), bo.cuda(), act=act)
+    assert torch.equal(lean["n"], out["n"]) and torch.equal(lean["rstd"], out["rstd"])
+
+
+def test_mlp_block_fwd_exact_integers():
+    """Small-integer operands: every product and sum is exact in bf16 / fp32, so a wrong fragment layout or a wrong
+    permutation of the hidden index shows as an exact mismatch in h and z."""
+    from moleculardiffusion_mivit_amd import ops
+    M = 200
+    n_in = ((torch.arange(M * E).reshape(M, E) * 7 + 3) % 5 - 2).float()
+    W1 = (((torch.arange(FH * E).reshape(FH, E) * 11 + 1) % 23) == 0).float() * (((torch.arange(FH * E).reshape(FH, E)) % 3) - 1.0)
+    W2 = (((torch.arange(E * FH).reshape(E, FH) * 5 + 2) % 29) == 0).float() * (((torch.arange(E * FH).reshape(E, FH)) % 5) - 2.0)
+    b1 = ((torch.arange(FH) % 7) - 3).float()
+    b2 = ((torch.arange(E) % 5) - 2).float()
+    u = F.linear(n_in, W1, b1)
+    h = F.relu(u)
+    z = n_in + F.linear(h, W2, b2)
+    assert float(u.abs().max()) <= 256 and float(z.abs().max()) <= 256        # exactly representable in bf16
+    ones, zeros = torch.ones(E), torch.zeros(E)
+    out = ops.mlp_block_fwd(_bf(n_in).cuda(), None, None, _bf(W1).cuda(), b1.cuda(), _bf(W2).cuda(), b2.cuda(), ones.cuda(),
+                            zeros.cuda(), act=1, extras=True)
+    torch.cuda.synchronize()
+    assert torch.equal(out["u"].float().cpu(), u)
+    assert torch.equal(out["h"].float().cpu(), h)
+    assert torch.equal(out["z"].float().cpu(), z)
+
+
+def _attn_ref(x, xb, Wqkv, bqkv, Wo, bo, S):
+    B = x.shape[0]
+    qkv = F.linear(xb, Wqkv.float(), bqkv)
+    q, k, v = [_bf(t).float().view(B, S, H, 32).transpose(1, 2) for t in qkv.split(E, dim=-1)]
+    p = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(32.0), dim=-1)
+    ctx = (_bf(p).float() @ v).transpose(1, 2).reshape(B, S, E)
+    z = x + F.linear(_bf(ctx).float(), Wo.float(), bo)
+    return qkv, ctx, z
+
+
+@pytest.mark.parametrize("B,S", [(1, 1), (3, 7), (2, 16), (5, 17), (9, 31), (64, 33), (3, 48), (2, 61), (2, 64), (300, 33)])
+@pytest.mark.parametrize("affine", [False, True])
+def test_attn_block_fwd(B, S, affine):
+    from moleculardiffusion_mivit_amd import ops
+    n_in = _bf(_mk((B, S, E), 11))
+    gi, bi = (1.0 + 0.3 * _mk((E,), 12), 0.2 * _mk((E,), 13)) if affine else (None, None)
+    Wqkv, bqkv = _bf(_mk((3 * E, E), 14, 1.5 / math.sqrt(E))), 0.1 * _mk((3 * E,), 15)
+    Wo, bo = _bf(_mk((E, E), 16, 1 / math.sqrt(E))), 0.1 * _mk((E,), 17)
+    go, bo2 = 1.0 + 0.3 * _mk((E,), 18), 0.2 * _mk((E,), 19)
+    x = n_in.float() * gi + bi if affine else n_in.float()
+    qkv, ctx, z = _attn_ref(x, _bf(x).float(), Wqkv, bqkv, Wo, bo, S)
+    nh, mu, rstd = _ln_hat(z)
+    dv = lambda t: None if t is None else t.cuda()
+    out = ops.attn_block_fwd(n_in.cuda(), dv(gi), dv(bi), Wqkv.cuda(), bqkv.cuda(), Wo.cuda(), bo.cuda(), go.cuda(), bo2.cuda(),
+                             extras=True)
+    torch.cuda.synchronize()
+    assert _rel(out["qkv"].float(), qkv) < 2e-2
+    assert _rel(out["ctx"].float(), ctx) < 3e-2
+    assert _rel(out["z"].float(), z) < 3e-2
+    assert _rel(out["n"].float(), nh) < 3e-2
+    assert _rel(out["x"].float(), nh * go + bo2) < 3e-2
+    assert _rel(out["rstd"], rstd) < 2e-2
+    lean = ops.attn_block_fwd(n_in.cuda(), dv(gi), dv(bi), Wqkv.cuda(), bqkv.cuda(), Wo.cuda(), bo.cuda(), go.cuda(), bo2.cuda())
+    assert torch.equal(lean["n"], out["n"]) and torch.equal(lean["ctx"], out["ctx"])
+
+
+def test_attn_block_fwd_uniform_softmax_exact():
+    """Zero q/k weights -> uniform probabilities 1/S; with S a power of two and small-integer v, ctx is exact."""
+    from moleculardiffusion_mivit_amd import ops
+    B, S = 4, 32
+    n_in = ((torch.arange(B * S * E).reshape(B, S, E) * 5 + 1) % 7 - 3).float()
+    Wqkv = torch.zeros(3 * E, E)
+    idx = torch.arange(E)
+    Wqkv[2 * E + idx, (idx * 37 + 5) % E] = 1.0            # v = a column permutation of x
+    Wqkv[2 * E + idx, (idx * 11 + 3) % E] += 2.0
+    Wo = torch.zeros(E, E)
+    Wo[idx, (idx * 13 + 7) % E] = 1.0
+    bqkv, bo = torch.zeros(3 * E), torch.zeros(E)
+    v = F.linear(n_in, Wqkv[2 * E:])
+    ctx = v.mean(dim=1, keepdim=True).expand(B, S, E)
+    z = n_in + F.linear(ctx, Wo)
+    out = ops.attn_block_fwd(_bf(n_in).cuda(), None, None, _bf(Wqkv).cuda(), bqkv.cuda(), _bf(Wo).cuda(), bo.cuda(),
+                             torch.ones(E).cuda(), torch.zeros(E).cuda(), extras=True)
+    torch.cuda.synchronize()
+    assert torch.equal(out["qkv"].float().cpu()[..., 2 * E:], v)
+    assert _rel(out["ctx"].float(), ctx) < 8e-3           # 1/32 * sum of bf16-exact integers, rounded to bf16 once
+    assert _rel(out["z"].float(), z) < 8e-3
