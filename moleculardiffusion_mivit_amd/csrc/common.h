@@ -331,6 +331,8 @@ int launch_batch_colsum(int dtype, const void *x, int B, int S, int E, int s0, i
 int launch_convert(int src_is_f32, const void *src, int64_t lds_, int dst_dtype_is_f32, void *dst, int64_t ldd,
                    int rows, int cols, int accumulate, hipStream_t s, int dtype16 = MIVIT_BF16);
 int launch_fill_zero(void *p, size_t bytes, hipStream_t s);
+// dW[n][k] = dW[n][k] * gamma[k] + db[n] * beta[k]  (weight gradient taken against normalised inputs, see misc.hip)
+int launch_affine_fixup(float *dW, const float *db, const float *gamma, const float *beta, int N, int K, hipStream_t s);
 
 // in-library kernel timing (misc.hip): the engine sets the category, launch sites bracket their main kernel
 void prof_set_tag(int tag);

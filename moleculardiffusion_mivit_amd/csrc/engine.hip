@@ -10,6 +10,15 @@
 #include <string>
 #include <vector>
 
+// fused encoder-layer blocks (fused_fwd.hip)
+bool fused_layer_supported(int dtype, int E, int F, int H, int S);
+int launch_attn_block_fwd(const void *nin, const float *gin, const float *bin, const void *Wqkv, const float *bqkv,
+                          const void *Wo, const float *bo, const float *gout, const float *bout, int B, int S, void *ctx,
+                          void *nout, float *rstd, void *xout, void *zout, float *mean, void *qkvout, hipStream_t s);
+int launch_mlp_block_fwd(const void *nin, const float *gin, const float *bin, const void *W1, const float *b1, const void *W2,
+                         const float *b2, const float *gout, const float *bout, int M, int act, void *nout, float *rstd,
+                         void *xout, void *zout, float *mean, void *hout, void *uout, hipStream_t s);
+
 struct ParamInfo {
     std::string name;
     int64_t offset, numel;
@@ -60,6 +69,7 @@ struct Ws {
     struct L { size_t qkv, ctx, z1, x1, h, u, z2, x2, mean1, rstd1, mean2, rstd2; };
     std::vector<L> layer;
     size_t xF, meanF, rstdF, pooled, fp_h, fp_out, head_in, hh;
+    size_t xL;           // fused layer blocks: x = gamma * xhat + beta of the LAST layer (input of the final norm)
     // backward temporaries
     size_t dout_t, d_hh, d_head_in, d_pool_c, d_fp_h, dxa, dxb, dF, dctx, dqkv, wgrad, ln, colsum;
     size_t wgrad_bytes, ln_bytes, colsum_bytes;
@@ -78,15 +88,26 @@ Ws make_ws(const mivit_plan *p, int B, int T, bool bwd) {
     w.emb = take(Mt * E * ts); w.mean0 = take(Mt * 4); w.rstd0 = take(Mt * 4);
     w.x0 = take(M * E * ts);
     const int nsets = bwd ? L : 1;
+    const bool fused = L > 0 && fused_layer_supported(c.dtype, E, F, c.num_heads, S);
     for (int l = 0; l < nsets; ++l) {
         Ws::L s;
-        s.qkv = take(M * 3 * E * ts); s.ctx = take(M * E * ts); s.z1 = take(M * E * ts); s.x1 = take(M * E * ts);
-        s.h = take(M * F * ts); s.u = c.activation == MIVIT_ACT_GELU ? take(M * F * ts) : 0;
-        s.z2 = take(M * E * ts); s.x2 = take(M * E * ts);
-        s.mean1 = take(M * 4); s.rstd1 = take(M * 4); s.mean2 = take(M * 4); s.rstd2 = take(M * 4);
+        if (fused) {
+            // fused layer blocks: z1 / z2 hold the NORMALISED sub-layer outputs (xhat, bf16), rstd1 / rstd2 their 1/std;
+            // q|k|v and h are kept only for the backward; no pre-norm sums, no means, no x copies
+            s.qkv = bwd ? take(M * 3 * E * ts) : 0; s.ctx = take(M * E * ts); s.z1 = take(M * E * ts); s.x1 = 0;
+            s.h = bwd ? take(M * F * ts) : 0; s.u = bwd && c.activation == MIVIT_ACT_GELU ? take(M * F * ts) : 0;
+            s.z2 = take(M * E * ts); s.x2 = 0;
+            s.mean1 = s.mean2 = 0; s.rstd1 = take(M * 4); s.rstd2 = take(M * 4);
+        } else {
+            s.qkv = take(M * 3 * E * ts); s.ctx = take(M * E * ts); s.z1 = take(M * E * ts); s.x1 = take(M * E * ts);
+            s.h = take(M * F * ts); s.u = c.activation == MIVIT_ACT_GELU ? take(M * F * ts) : 0;
+            s.z2 = take(M * E * ts); s.x2 = take(M * E * ts);
+            s.mean1 = take(M * 4); s.rstd1 = take(M * 4); s.mean2 = take(M * 4); s.rstd2 = take(M * 4);
+        }
         w.layer.push_back(s);
     }
     for (int l = nsets; l < L; ++l) w.layer.push_back(w.layer[0]);
+    w.xL = fused ? take(M * E * ts) : 0;
     w.xF = c.use_regression_token ? 0 : take(M * E * ts);
     w.meanF = take(M * 4); w.rstdF = take(M * 4);
     w.pooled = take((size_t)B * E * ts);
@@ -423,6 +444,30 @@ static int forward_impl(const mivit_plan *plan, const float *params, const float
                                  c.use_pos_encoding ? P + plan->pos : nullptr, s));
     // 4. encoder layers (post-norm, models.py:97-108)
     const void *xin = at(ws, w.x0);
+    const bool fused = c.num_layers > 0 && fused_layer_supported(dt, E, F, H, S);
+    if (fused) {
+        // fused layer blocks (fused_fwd.hip): the layers hand each other NORMALISED tokens, the consumer applies the producing
+        // LayerNorm's affine (folded into its weights); training keeps q|k|v and h for the backward kernels, inference
+        // nothing; only the last block materialises x for the final norm
+        const float *gin = nullptr, *bin = nullptr;
+        const void *nin = xin;
+        for (int l = 0; l < c.num_layers; ++l) {
+            const LayerParams &lp = plan->layers[l];
+            const Ws::L &b = w.layer[l];
+            const bool last = l + 1 == c.num_layers;
+            prof_set_tag(MIVIT_PROF_ATTN_FWD);
+            RC(launch_attn_block_fwd(nin, gin, bin, WT(lp.qkv_w), P + lp.qkv_b, WT(lp.out_w), P + lp.out_b, P + lp.n1_w,
+                                     P + lp.n1_b, B, S, at(ws, b.ctx), at(ws, b.z1), static_cast<float *>(at(ws, b.rstd1)),
+                                     nullptr, nullptr, nullptr, need_backward ? at(ws, b.qkv) : nullptr, s));
+            prof_set_tag(MIVIT_PROF_LINEAR_FWD);
+            RC(launch_mlp_block_fwd(at(ws, b.z1), P + lp.n1_w, P + lp.n1_b, WT(lp.fc1_w), P + lp.fc1_b, WT(lp.fc2_w), P + lp.fc2_b,
+                                    P + lp.n2_w, P + lp.n2_b, M, c.activation, at(ws, b.z2), static_cast<float *>(at(ws, b.rstd2)),
+                                    last ? at(ws, w.xL) : nullptr, nullptr, nullptr, need_backward ? at(ws, b.h) : nullptr,
+                                    need_backward && c.activation == MIVIT_ACT_GELU ? at(ws, b.u) : nullptr, s));
+            nin = at(ws, b.z2); gin = P + lp.n2_w; bin = P + lp.n2_b;
+        }
+        xin = at(ws, w.xL);
+    } else
     for (int l = 0; l < c.num_layers; ++l) {
         const LayerParams &lp = plan->layers[l];
         const Ws::L &b = w.layer[l];
@@ -524,7 +569,8 @@ static int backward_impl(const mivit_plan *plan, const float *params, const floa
         if (st == 0) {
             // ---- head + final norm ----
             const int Hh = c.head_hidden, Hin = plan->head_in, O = c.output_dim;
-            const void *xL = L > 0 ? at(ws, w.layer[L - 1].x2) : at(ws, w.x0);
+            const bool fusedL = L > 0 && fused_layer_supported(dt, E, F, H, S);
+            const void *xL = L > 0 ? (fusedL ? at(ws, w.xL) : at(ws, w.layer[L - 1].x2)) : at(ws, w.x0);
             const void *head_in = c.fusion == MIVIT_FUSION_LATE ? at(ws, w.head_in) : at(ws, w.pooled);
             const void *dy = dout;
             if (!f32) { RC(launch_convert(1, dout, O, 0, at(ws, w.dout_t), O, B, O, 0, s, dt)); dy = at(ws, w.dout_t); }
@@ -561,10 +607,13 @@ static int backward_impl(const mivit_plan *plan, const float *params, const floa
             const int l = L - st;
             const LayerParams &lp = plan->layers[l];
             const Ws::L &b = w.layer[l];
-            const void *xin = l > 0 ? at(ws, w.layer[l - 1].x2) : at(ws, w.x0);
+            // fused layer blocks: z1 / z2 hold xhat (no means), the Linear inputs x1 / x_in exist only as xhat of the
+            // producing norm: their weight gradients are taken against xhat and corrected by launch_affine_fixup
+            const bool fz = fused_layer_supported(dt, E, F, H, S);
+            const void *xin = l > 0 ? (fz ? at(ws, w.layer[l - 1].z2) : at(ws, w.layer[l - 1].x2)) : at(ws, w.x0);
             LayerNormBwdArgs n2 = {};
             n2.dtype = dt; n2.dy = at(ws, w.dxa); n2.lddy = E; n2.z = at(ws, b.z2); n2.ldz = E; n2.gamma = P + lp.n2_w;
-            n2.mean = static_cast<const float *>(at(ws, b.mean2)); n2.rstd = static_cast<const float *>(at(ws, b.rstd2));
+            n2.mean = fz ? nullptr : static_cast<const float *>(at(ws, b.mean2)); n2.rstd = static_cast<const float *>(at(ws, b.rstd2));
             n2.M = M; n2.E = E; n2.dz = at(ws, w.dxb); n2.lddz = E; n2.dgamma = G + lp.n2_w; n2.dbeta = G + lp.n2_b;
             n2.ws = at(ws, w.ln); n2.ws_bytes = w.ln_bytes;
             bool cs = false;
@@ -572,12 +621,13 @@ static int backward_impl(const mivit_plan *plan, const float *params, const floa
             RC(lin_wgrad(dt, at(ws, w.dxb), E, at(ws, b.h), 0, F, M, E, F, G + lp.fc2_w, cs ? G + lp.fc2_b : nullptr, wg, wgb, s));
             RC(lin_dgrad(dt, at(ws, w.dxb), E, WT(lp.fc2_w), M, E, F, c.activation,
                          c.activation == MIVIT_ACT_GELU ? at(ws, b.u) : at(ws, b.h), F, nullptr, 0, at(ws, w.dF), F, 0, s));
-            RC(lin_wgrad(dt, at(ws, w.dF), F, at(ws, b.x1), 0, E, M, F, E, G + lp.fc1_w, G + lp.fc1_b, wg, wgb, s));
+            RC(lin_wgrad(dt, at(ws, w.dF), F, fz ? at(ws, b.z1) : at(ws, b.x1), 0, E, M, F, E, G + lp.fc1_w, G + lp.fc1_b, wg, wgb, s));
+            if (fz) RC(launch_affine_fixup(G + lp.fc1_w, G + lp.fc1_b, P + lp.n1_w, P + lp.n1_b, F, E, s));
             RC(lin_dgrad(dt, at(ws, w.dF), F, WT(lp.fc1_w), M, F, E, MIVIT_ACT_NONE, nullptr, 0, at(ws, w.dxb), E,
                          at(ws, w.dxa), E, 0, s));                                                // dxa = d(x1)
             LayerNormBwdArgs n1 = n2;
             n1.dy = at(ws, w.dxa); n1.z = at(ws, b.z1); n1.gamma = P + lp.n1_w;
-            n1.mean = static_cast<const float *>(at(ws, b.mean1)); n1.rstd = static_cast<const float *>(at(ws, b.rstd1));
+            n1.mean = fz ? nullptr : static_cast<const float *>(at(ws, b.mean1)); n1.rstd = static_cast<const float *>(at(ws, b.rstd1));
             n1.dz = at(ws, w.dxb); n1.dgamma = G + lp.n1_w; n1.dbeta = G + lp.n1_b;
             RC(ln_bwd_bias(n1, G + lp.out_b, &cs, s));                                            // dxb = d(z1), out_proj.bias grad
             RC(lin_wgrad(dt, at(ws, w.dxb), E, at(ws, b.ctx), 0, E, M, E, E, G + lp.out_w, cs ? G + lp.out_b : nullptr, wg, wgb, s));
@@ -585,6 +635,8 @@ static int backward_impl(const mivit_plan *plan, const float *params, const floa
                          at(ws, w.dctx), E, 0, s));
             prof_set_tag(MIVIT_PROF_ATTN_BWD); RC(launch_attention_bwd(dt, at(ws, b.qkv), at(ws, w.dctx), B, S, H, Dh, at(ws, w.dqkv), s));
             RC(lin_wgrad(dt, at(ws, w.dqkv), 3 * E, xin, 0, E, M, 3 * E, E, G + lp.qkv_w, G + lp.qkv_b, wg, wgb, s));
+            if (fz && l > 0)
+                RC(launch_affine_fixup(G + lp.qkv_w, G + lp.qkv_b, P + plan->layers[l - 1].n2_w, P + plan->layers[l - 1].n2_b, 3 * E, E, s));
             RC(lin_dgrad(dt, at(ws, w.dqkv), 3 * E, WT(lp.qkv_w), M, 3 * E, E, MIVIT_ACT_NONE, nullptr, 0, at(ws, w.dxb),
                          E, at(ws, w.dxa), E, 0, s));                                             // dxa = d(x_in)
         } else {

@@ -33,6 +33,7 @@ constexpr int E = 128, F = 256, H = 4, DH = 32;
 constexpr int LDE = E + 16;          // LDS row pitch (elements) of a [*, 128] operand image: 288 B = 18 x 16 B
 constexpr int LDF = F + 16;          // ... of a [*, 256] image: 544 B = 34 x 16 B   (pitch = 2 mod 16 units: conflict-free b128)
 constexpr int NWAVES = 8, NTHREADS = NWAVES * 64;
+constexpr float QSCALE = 0.17677669529663687f * 1.4426950408889634f;      // 1/sqrt(32) * log2(e), folded into the q projection
 
 __device__ __forceinline__ bf16x8 pack8(const f32x4 a, const f32x4 b) {
     bf16x8 f;
@@ -58,16 +59,15 @@ __device__ __forceinline__ f32x4 load4_bf16(const bf16 *p) {
                  __uint_as_float(v.y & 0xffff0000u)};
 }
 __device__ __forceinline__ void store4_bf16(bf16 *p, const f32x4 v) {
-    uint2 o;
-    o.x = (uint32_t)from_f32<bf16>(v[0]).v | ((uint32_t)from_f32<bf16>(v[1]).v << 16);
-    o.y = (uint32_t)from_f32<bf16>(v[2]).v | ((uint32_t)from_f32<bf16>(v[3]).v << 16);
-    *reinterpret_cast<uint2 *>(p) = o;
+    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+    const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};      // two v_cvt_pk_bf16_f32
+    *reinterpret_cast<bf16x4 *>(p) = o;
 }
 
 // natural [rows][K] bf16 weight block (row pitch ldw elements) -> LDS operand image with pitch LD
 template <int K, int LD>
-__device__ __forceinline__ void stage_natural(bf16 *img, const bf16 *W, int rows, int tid) {
-    for (int i = tid; i < rows * (K / 8); i += NTHREADS) {
+__device__ __forceinline__ void stage_natural(bf16 *img, const bf16 *W, int rows, int tid, int nthr = NTHREADS) {
+    for (int i = tid; i < rows * (K / 8); i += nthr) {
         const int r = i / (K / 8), c = i - r * (K / 8);
         *reinterpret_cast<uint4 *>(img + r * LD + c * 8) = *reinterpret_cast<const uint4 *>(W + (int64_t)r * K + c * 8);
     }
@@ -75,61 +75,83 @@ __device__ __forceinline__ void stage_natural(bf16 *img, const bf16 *W, int rows
 // the same with the contraction index permuted inside each block of 32 so that the 16-byte chunk g of block p holds
 // k = 32p + 4g + {0..3} and k = 32p + 16 + 4g + {0..3}: the operand that meets a packed accumulator pair
 template <int K, int LD>
-__device__ __forceinline__ void stage_permuted(bf16 *img, const bf16 *W, int rows, int tid) {
-    for (int i = tid; i < rows * (K / 8); i += NTHREADS) {
+__device__ __forceinline__ void stage_permuted(bf16 *img, const bf16 *W, int rows, int tid, int nthr = NTHREADS) {
+    for (int i = tid; i < rows * (K / 8); i += nthr) {
         const int r = i / (K / 8), c = i - r * (K / 8), p = c >> 2, g = c & 3;
         const uint2 lo = *reinterpret_cast<const uint2 *>(W + (int64_t)r * K + 32 * p + 4 * g);
         const uint2 hi = *reinterpret_cast<const uint2 *>(W + (int64_t)r * K + 32 * p + 16 + 4 * g);
         *reinterpret_cast<uint4 *>(img + r * LD + c * 8) = make_uint4(lo.x, lo.y, hi.x, hi.y);
     }
 }
-__device__ __forceinline__ void stage_vec(float *dst, const float *src, int n, float fill, int tid) {
-    for (int i = tid; i < n; i += NTHREADS) dst[i] = src ? src[i] : fill;
+__device__ __forceinline__ void stage_vec(float *dst, const float *src, int n, float fill, int tid, int nthr = NTHREADS) {
+    for (int i = tid; i < n; i += nthr) dst[i] = src ? src[i] : fill;
 }
 
-// column-operand fragments of 16 activation rows: lane (row = lane & 15, g) holds k = 32 ks + 8 g + 0..7 of
-// x = gamma * n + beta (rows beyond `rows_valid` are zero)
-__device__ __forceinline__ void load_x_frags(bf16x8 (&xf)[4], const bf16 *nin, int64_t row, bool valid, const float *gam,
-                                             const float *bet, bool affine, int g) {
+// column-operand fragments of 16 activation rows: lane (row = lane & 15, g) holds k = 32 ks + 8 g + 0..7.
+// load_raw issues the four 16-byte loads (zeros for rows that do not exist); the registers ARE the MFMA operands.
+__device__ __forceinline__ void load_raw(uint4 (&raw)[4], const bf16 *nin, int64_t row, bool valid, int g) {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-        uint4 raw = make_uint4(0u, 0u, 0u, 0u);
-        if (valid) raw = *reinterpret_cast<const uint4 *>(nin + row * E + ks * 32 + 8 * g);
-        if (affine) {
-            const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
-            const f32x4 g0 = ld4(gam + ks * 32 + 8 * g), g1 = ld4(gam + ks * 32 + 8 * g + 4);
-            const f32x4 b0 = ld4(bet + ks * 32 + 8 * g), b1 = ld4(bet + ks * 32 + 8 * g + 4);
-            f32x4 lo, hi;
-            lo[0] = __uint_as_float(w[0] << 16); lo[1] = __uint_as_float(w[0] & 0xffff0000u);
-            lo[2] = __uint_as_float(w[1] << 16); lo[3] = __uint_as_float(w[1] & 0xffff0000u);
-            hi[0] = __uint_as_float(w[2] << 16); hi[1] = __uint_as_float(w[2] & 0xffff0000u);
-            hi[2] = __uint_as_float(w[3] << 16); hi[3] = __uint_as_float(w[3] & 0xffff0000u);
-            lo = valid ? lo * g0 + b0 : f32x4{0.f, 0.f, 0.f, 0.f};
-            hi = valid ? hi * g1 + b1 : f32x4{0.f, 0.f, 0.f, 0.f};
-            xf[ks] = pack8(lo, hi);
-        } else {
-            xf[ks] = __builtin_bit_cast(bf16x8, raw);
-        }
+        raw[ks] = make_uint4(0u, 0u, 0u, 0u);
+        if (valid) raw[ks] = *reinterpret_cast<const uint4 *>(nin + row * E + ks * 32 + 8 * g);
     }
 }
+__device__ __forceinline__ bf16x8 as_frag(const uint4 &u) { return __builtin_bit_cast(bf16x8, u); }
+// The producing LayerNorm's affine is FOLDED into the consuming weights while they are staged (once per workgroup):
+//   (gamma * n + beta) W^T + b  =  n (W * gamma)^T + (b + W beta)
+// so the projections run on the raw normalised rows exactly as loaded -- no per-element affine, no copy.
+template <int K, int LD>
+__device__ __forceinline__ void stage_folded(bf16 *img, const bf16 *W, int rows, const float *gam, int tid, int nthr = NTHREADS,
+                                             int rs_rows = 0, float rs_val = 1.f) {      // rows < rs_rows are scaled by rs_val
+    for (int i = tid; i < rows * (K / 8); i += nthr) {
+        const int r = i / (K / 8), c = i - r * (K / 8);
+        const float rsc = r < rs_rows ? rs_val : 1.f;
+        float v[8];
+        load16(W + (int64_t)r * K + c * 8, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= gam[c * 8 + e] * rsc;
+        store16(img + r * LD + c * 8, v);
+    }
+}
+// dst[r] = b[r] + sum_k W[r][k] beta[k]   (beta == nullptr: plain copy)
+template <int K>
+__device__ __forceinline__ void fold_bias(float *dst, const float *b, const bf16 *W, int rows, const float *bet, bool fold, int tid,
+                                          int nthr = NTHREADS, int rs_rows = 0, float rs_val = 1.f) {
+    for (int r = tid; r < rows; r += nthr) {
+        float acc = b ? b[r] : 0.f;
+        if (fold) {
+            for (int c = 0; c < K / 8; ++c) {
+                float v[8];
+                load16(W + (int64_t)r * K + c * 8, v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc += v[e] * bet[c * 8 + e];
+            }
+        }
+        dst[r] = r < rs_rows ? acc * rs_val : acc;
+    }
+}
+// The residual needs the input rows in the ACCUMULATOR layout (lane = row, registers = 4 consecutive features), the
+// fragments hold them in the operand layout.  The matrix pipe transposes for free: n^T tile et = I n^T with a constant
+// 0/1 row operand that picks features 16 et .. 16 et + 15 out of the 32-wide block ks = et / 2 (exact: one product per
+// output); the affine of the residual is then 4 FMAs per tile.  idfrag(par) is that operand for et of parity par.
+__device__ __forceinline__ bf16x8 idfrag(int par, int cq, int g) {
+    bf16x8 f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = (g == 2 * par + (cq >> 3) && j == (cq & 7)) ? (__bf16)1.0f : (__bf16)0.0f;
+    return f;
+}
 
-// ---- shared epilogue: z^T accumulators (8 feature tiles of one 16-row block) + residual -> LayerNorm -> stores ----
+// ---- shared epilogue: z^T accumulators (8 feature tiles of one 16-row block, residual included) -> LayerNorm -> stores ----
 struct LnOut {
     bf16 *nout; float *rstd;          // normalised output + 1/std per row (always)
     bf16 *xout;                       // optional: gamma * nhat + beta
     bf16 *zout; float *mean;          // optional: pre-norm sum and mean (unfused backward)
 };
-__device__ __forceinline__ void residual_ln_store(f32x4 (&z)[8], const bf16 *nin, int64_t row, bool valid, const float *gin,
-                                                  const float *bin, bool affine_in, const float *gout, const float *bout,
-                                                  const LnOut &o, int g) {
+__device__ __forceinline__ void ln_store(f32x4 (&z)[8], int64_t row, bool valid, const float *gout, const float *bout,
+                                         const LnOut &o, int g) {
     float s = 0.f;
 #pragma unroll
-    for (int et = 0; et < 8; ++et) {
-        f32x4 x = valid ? load4_bf16(nin + row * E + 16 * et + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
-        if (affine_in) x = x * ld4(gin + 16 * et + 4 * g) + ld4(bin + 16 * et + 4 * g);
-        z[et] += x;
-        s += z[et][0] + z[et][1] + z[et][2] + z[et][3];
-    }
+    for (int et = 0; et < 8; ++et) s += z[et][0] + z[et][1] + z[et][2] + z[et][3];
     const float mu = x4_sum(s) * (1.f / E);
     float q = 0.f;
 #pragma unroll
@@ -172,7 +194,7 @@ constexpr int MLP_VEC = E * 5 + F;               // gin, bin, b2, gout, bout [E]
 constexpr int MLP_LDS = MLP_LDS_W1 + MLP_LDS_W2 + MLP_VEC * 4;
 static_assert(MLP_LDS <= 160 * 1024, "LDS budget");
 
-template <int NR>
+template <int NR, int ACT, bool EXTRAS>      // EXTRAS: the optional h / pre-activation outputs are compiled in
 __global__ __launch_bounds__(NTHREADS) void mlp_block_fwd_kernel(const MlpFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16 *W1i = reinterpret_cast<bf16 *>(smem);
@@ -180,27 +202,49 @@ __global__ __launch_bounds__(NTHREADS) void mlp_block_fwd_kernel(const MlpFwdArg
     float *vec = reinterpret_cast<float *>(smem + MLP_LDS_W1 + MLP_LDS_W2);
     float *gin = vec, *bin = vec + E, *b2 = vec + 2 * E, *gout = vec + 3 * E, *bout = vec + 4 * E, *b1 = vec + 5 * E;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, cq = lane & 15;
-    stage_natural<E, LDE>(W1i, a.W1, F, tid);
-    stage_permuted<F, LDF>(W2i, a.W2, E, tid);
-    stage_vec(gin, a.gin, E, 1.f, tid); stage_vec(bin, a.bin, E, 0.f, tid); stage_vec(b2, a.b2, E, 0.f, tid);
-    stage_vec(gout, a.gout, E, 1.f, tid); stage_vec(bout, a.bout, E, 0.f, tid); stage_vec(b1, a.b1, F, 0.f, tid);
-    __syncthreads();
     const bool affine_in = a.gin != nullptr;
+    stage_vec(gin, a.gin, E, 1.f, tid); stage_vec(bin, a.bin, E, 0.f, tid);
+    stage_vec(gout, a.gout, E, 1.f, tid); stage_vec(bout, a.bout, E, 0.f, tid);
+    __syncthreads();
+    if (affine_in) stage_folded<E, LDE>(W1i, a.W1, F, gin, tid); else stage_natural<E, LDE>(W1i, a.W1, F, tid);
+    stage_permuted<F, LDF>(W2i, a.W2, E, tid);
+    fold_bias<E>(b1, a.b1, a.W1, F, bin, affine_in, tid);
+    for (int i = tid; i < E; i += NTHREADS) b2[i] = a.b2[i] + bin[i];          // fc2 bias + the residual's beta
+    __syncthreads();
     const int ntiles = (a.M + 16 * NR - 1) / (16 * NR);
-    for (int tile = blockIdx.x * NWAVES + wave; tile < ntiles; tile += gridDim.x * NWAVES) {
+    const bf16x8 id0 = idfrag(0, cq, g), id1 = idfrag(1, cq, g);
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    int tile = blockIdx.x * NWAVES + wave;
+    const int tstride = gridDim.x * NWAVES;
+    uint4 nx[NR][4];
+    if (tile < ntiles) {
+#pragma unroll
+        for (int rb = 0; rb < NR; ++rb) {
+            const int64_t row = (int64_t)tile * 16 * NR + rb * 16 + cq;
+            load_raw(nx[rb], a.nin, row, row < a.M, g);
+        }
+    }
+    for (; tile < ntiles; tile += tstride) {
         const int64_t row0 = (int64_t)tile * 16 * NR;
         bf16x8 xf[NR][4];
 #pragma unroll
-        for (int rb = 0; rb < NR; ++rb) {
-            const int64_t row = row0 + rb * 16 + cq;
-            load_x_frags(xf[rb], a.nin, row, row < a.M, gin, bin, affine_in, g);
+        for (int rb = 0; rb < NR; ++rb)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) xf[rb][ks] = as_frag(nx[rb][ks]);
+        {                                        // next tile's rows: in flight while this one computes (unconditional --
+            const int nxt = min(tile + tstride, ntiles - 1);          // a clamped re-read on the last round -- so the
+#pragma unroll                                                       // registers are dead until here)
+            for (int rb = 0; rb < NR; ++rb) {
+                const int64_t row = (int64_t)nxt * 16 * NR + rb * 16 + cq;
+                load_raw(nx[rb], a.nin, row, row < a.M, g);
+            }
         }
         f32x4 fa[8][NR];
 #pragma unroll
         for (int et = 0; et < 8; ++et) {
-            const f32x4 bv = ld4(b2 + 16 * et + 4 * g);
+            const f32x4 bv = ld4(b2 + 16 * et + 4 * g), gv = ld4(gin + 16 * et + 4 * g);
 #pragma unroll
-            for (int rb = 0; rb < NR; ++rb) fa[et][rb] = bv;
+            for (int rb = 0; rb < NR; ++rb) fa[et][rb] = bv + gv * mma((et & 1) ? id1 : id0, xf[rb][et >> 1], zero);   // bias + residual
         }
 #pragma unroll 2
         for (int p = 0; p < F / 32; ++p) {
@@ -226,10 +270,10 @@ __global__ __launch_bounds__(NTHREADS) void mlp_block_fwd_kernel(const MlpFwdArg
                 const int64_t row = row0 + rb * 16 + cq;
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    if (a.uout && row < a.M) store4_bf16(a.uout + row * F + 32 * p + 16 * t + 4 * g, ha[t][rb]);
+                    if (EXTRAS && a.uout && row < a.M) store4_bf16(a.uout + row * F + 32 * p + 16 * t + 4 * g, ha[t][rb]);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) ha[t][rb][j] = act_fwd(a.act, ha[t][rb][j]);
-                    if (a.hout && row < a.M) store4_bf16(a.hout + row * F + 32 * p + 16 * t + 4 * g, ha[t][rb]);
+                    for (int j = 0; j < 4; ++j) ha[t][rb][j] = act_fwd(ACT, ha[t][rb][j]);
+                    if (EXTRAS && a.hout && row < a.M) store4_bf16(a.hout + row * F + 32 * p + 16 * t + 4 * g, ha[t][rb]);
                 }
                 hf[rb] = pack8(ha[0][rb], ha[1][rb]);
             }
@@ -247,7 +291,7 @@ __global__ __launch_bounds__(NTHREADS) void mlp_block_fwd_kernel(const MlpFwdArg
             f32x4 z[8];
 #pragma unroll
             for (int et = 0; et < 8; ++et) z[et] = fa[et][rb];
-            residual_ln_store(z, a.nin, row, row < a.M, gin, bin, affine_in, gout, bout, a.o, g);
+            ln_store(z, row, row < a.M, gout, bout, a.o, g);
         }
     }
 }
@@ -271,8 +315,10 @@ constexpr int ATT_VEC = E * 5 + 3 * E;           // gin, bin, bo, gout, bout + b
 constexpr int ATT_LDS = ATT_LDS_WQKV + ATT_LDS_WO + ATT_VEC * 4;
 static_assert(ATT_LDS <= 160 * 1024, "LDS budget");
 
-template <int NT>      // row tiles per sequence: S <= 16 * NT
-__global__ __launch_bounds__(NTHREADS) void attn_block_fwd_kernel(const AttnFwdArgs a) {
+// NT row tiles per sequence (S <= 16 NT); EXTRAS: the optional q|k|v output is compiled in; NW waves per workgroup
+// (one workgroup per CU: 8 waves share the register file two per SIMD, 4 waves own a whole SIMD's 512 registers each)
+template <int NT, bool EXTRAS, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_block_fwd_kernel(const AttnFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NP = (NT + 1) / 2;
     bf16 *Wq = reinterpret_cast<bf16 *>(smem);
@@ -280,21 +326,34 @@ __global__ __launch_bounds__(NTHREADS) void attn_block_fwd_kernel(const AttnFwdA
     float *vec = reinterpret_cast<float *>(smem + ATT_LDS_WQKV + ATT_LDS_WO);
     float *gin = vec, *bin = vec + E, *bo = vec + 2 * E, *gout = vec + 3 * E, *bout = vec + 4 * E, *bqkv = vec + 5 * E;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, cq = lane & 15;
-    stage_natural<E, LDE>(Wq, a.Wqkv, 3 * E, tid);
-    stage_permuted<E, LDE>(Wo, a.Wo, E, tid);
-    stage_vec(gin, a.gin, E, 1.f, tid); stage_vec(bin, a.bin, E, 0.f, tid); stage_vec(bo, a.bo, E, 0.f, tid);
-    stage_vec(gout, a.gout, E, 1.f, tid); stage_vec(bout, a.bout, E, 0.f, tid); stage_vec(bqkv, a.bqkv, 3 * E, 0.f, tid);
-    __syncthreads();
     const bool affine_in = a.gin != nullptr;
+    stage_vec(gin, a.gin, E, 1.f, tid, NW * 64); stage_vec(bin, a.bin, E, 0.f, tid, NW * 64);
+    stage_vec(gout, a.gout, E, 1.f, tid, NW * 64); stage_vec(bout, a.bout, E, 0.f, tid, NW * 64);
+    __syncthreads();
+    // q rows carry 1/sqrt(head dim) * log2(e): the scores come out of the MFMA ready for exp2
+    stage_folded<E, LDE>(Wq, a.Wqkv, 3 * E, gin, tid, NW * 64, E, QSCALE);
+    stage_permuted<E, LDE>(Wo, a.Wo, E, tid, NW * 64);
+    fold_bias<E>(bqkv, a.bqkv, a.Wqkv, 3 * E, bin, affine_in, tid, NW * 64, E, QSCALE);
+    for (int i = tid; i < E; i += NW * 64) bo[i] = a.bo[i] + bin[i];          // out-projection bias + the residual's beta
+    __syncthreads();
     const int S = a.S;
-    const float scale = 0.17677669529663687f;       // 1 / sqrt(32)
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 
-    for (int b = blockIdx.x * NWAVES + wave; b < a.B; b += gridDim.x * NWAVES) {
+    const bf16x8 id0 = idfrag(0, cq, g), id1 = idfrag(1, cq, g);
+    const int bstride = gridDim.x * NW;
+    int b = blockIdx.x * NW + wave;
+    uint4 nx[NT][4];
+    if (b < a.B) {
+#pragma unroll
+        for (int rt = 0; rt < NT; ++rt) load_raw(nx[rt], a.nin, (int64_t)b * S + rt * 16 + cq, rt * 16 + cq < S, g);
+    }
+    for (; b < a.B; b += bstride) {
         const int64_t base = (int64_t)b * S;
         bf16x8 xf[NT][4];
 #pragma unroll
-        for (int rt = 0; rt < NT; ++rt) load_x_frags(xf[rt], a.nin, base + rt * 16 + cq, rt * 16 + cq < S, gin, bin, affine_in, g);
+        for (int rt = 0; rt < NT; ++rt)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) xf[rt][ks] = as_frag(nx[rt][ks]);
         bf16x8 cf[H][NT];                            // context, as the column operand of the out-projection
 #pragma unroll
         for (int h = 0; h < H; ++h) {
@@ -322,9 +381,10 @@ __global__ __launch_bounds__(NTHREADS) void attn_block_fwd_kernel(const AttnFwdA
                 for (int rt = 0; rt < NT; ++rt) {
                     if (which == 0) qf[rt] = pack8(pa[0][rt], pa[1][rt]);
                     else kf[rt] = pack8(pa[0][rt], pa[1][rt]);
-                    if (a.qkvout && rt * 16 + cq < S) {
+                    if (EXTRAS && a.qkvout && rt * 16 + cq < S) {          // (q leaves unscaled, as the reference's q_proj output)
                         bf16 *dst = a.qkvout + (base + rt * 16 + cq) * (3 * E) + which * E + h * DH + 4 * g;
-                        store4_bf16(dst, pa[0][rt]); store4_bf16(dst + 16, pa[1][rt]);
+                        const float us = which == 0 ? 1.f / QSCALE : 1.f;
+                        store4_bf16(dst, pa[0][rt] * us); store4_bf16(dst + 16, pa[1][rt] * us);
                     }
                 }
             }
@@ -351,32 +411,39 @@ __global__ __launch_bounds__(NTHREADS) void attn_block_fwd_kernel(const AttnFwdA
                 for (int p = 0; p < NP; ++p)
 #pragma unroll
                     for (int dt = 0; dt < 2; ++dt) vr[p][dt] = pack8(va[2 * p][dt], (2 * p + 1 < NT) ? va[2 * p + 1][dt] : zero);
-                if (a.qkvout) {
+                if (EXTRAS && a.qkvout) {         // v^T once more (lane = token): 8-byte row stores instead of 2-byte scatters
 #pragma unroll
-                    for (int rt = 0; rt < NT; ++rt)
+                    for (int dt = 0; dt < 2; ++dt) {
+                        f32x4 vt[NT];
+                        const f32x4 bb = ld4(bqkv + 2 * E + h * DH + 16 * dt + 4 * g);
 #pragma unroll
-                        for (int dt = 0; dt < 2; ++dt)
+                        for (int rt = 0; rt < NT; ++rt) vt[rt] = bb;
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                const int tok = rt * 16 + 4 * g + j;
-                                if (tok < S) a.qkvout[(base + tok) * (3 * E) + 2 * E + h * DH + 16 * dt + cq] = from_f32<bf16>(va[rt][dt][j]);
-                            }
+                        for (int ks = 0; ks < 4; ++ks) {
+                            const bf16x8 wv = lds_frag(Wq + (2 * E + h * DH + 16 * dt + cq) * LDE + ks * 32 + 8 * g);
+#pragma unroll
+                            for (int rt = 0; rt < NT; ++rt) vt[rt] = mma(wv, xf[rt][ks], vt[rt]);
+                        }
+#pragma unroll
+                        for (int rt = 0; rt < NT; ++rt)
+                            if (rt * 16 + cq < S) store4_bf16(a.qkvout + (base + rt * 16 + cq) * (3 * E) + 2 * E + h * DH + 16 * dt + 4 * g, vt[rt]);
+                    }
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
             // ---- scores, softmax, P V per query tile ----
 #pragma unroll
             for (int it = 0; it < NT; ++it) {
-                f32x4 st[NT];                        // S^T tile: lane = query it*16 + cq, registers = keys 16 j + 4 g + r
+                f32x4 st[NT];                        // S^T tile (log2 units): lane = query it*16 + cq, registers = keys 16 j + 4 g + r
                 float m = -INFINITY;
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
                     st[j] = mma(kf[j], qf[it], zero);
+                    if (j == NT - 1) {               // only the last key tile can hold keys that do not exist
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        st[j][r] = (j * 16 + 4 * g + r < S) ? st[j][r] * scale : -INFINITY;
-                        m = fmaxf(m, st[j][r]);
+                        for (int r = 0; r < 4; ++r) st[j][r] = (j * 16 + 4 * g + r < S) ? st[j][r] : -INFINITY;
                     }
+                    m = fmaxf(m, fmaxf(fmaxf(st[j][0], st[j][1]), fmaxf(st[j][2], st[j][3])));
                 }
                 m = x4_max(m);
                 float sum = 0.f;
@@ -384,11 +451,10 @@ __global__ __launch_bounds__(NTHREADS) void attn_block_fwd_kernel(const AttnFwdA
                 for (int j = 0; j < NT; ++j)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float e = (j * 16 + 4 * g + r < S) ? __expf(st[j][r] - m) : 0.f;
-                        st[j][r] = e;
-                        sum += e;
+                        st[j][r] = __builtin_amdgcn_exp2f(st[j][r] - m);      // exp2(-inf) = 0 for the masked keys
+                        sum += st[j][r];
                     }
-                const float inv = 1.f / x4_sum(sum);
+                const float inv = __builtin_amdgcn_rcpf(x4_sum(sum));
 #pragma unroll
                 for (int j = 0; j < NT; ++j) st[j] *= inv;
                 f32x4 ot[2] = {zero, zero};          // O^T: lane = query, registers = head features 16 dt + 4 g + r
@@ -406,13 +472,19 @@ __global__ __launch_bounds__(NTHREADS) void attn_block_fwd_kernel(const AttnFwdA
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        // ---- out-projection (+ bias), residual, LayerNorm ----
+        // ---- out-projection (+ bias) + residual (identity product on the input fragments), LayerNorm ----
         f32x4 oa[8][NT];
 #pragma unroll
         for (int nt = 0; nt < 8; ++nt) {
-            const f32x4 bv = ld4(bo + 16 * nt + 4 * g);
+            const f32x4 bv = ld4(bo + 16 * nt + 4 * g), gv = ld4(gin + 16 * nt + 4 * g);
 #pragma unroll
-            for (int rt = 0; rt < NT; ++rt) oa[nt][rt] = bv;
+            for (int rt = 0; rt < NT; ++rt) oa[nt][rt] = bv + gv * mma((nt & 1) ? id1 : id0, xf[rt][nt >> 1], zero);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {                                        // next sequence's rows: in flight under the out-projection and the epilogue
+            const int nb = min(b + bstride, a.B - 1);                 // (unconditional, after the last use of this sequence's
+#pragma unroll                                                       //  fragments: the same registers)
+            for (int rt = 0; rt < NT; ++rt) load_raw(nx[rt], a.nin, (int64_t)nb * S + rt * 16 + cq, rt * 16 + cq < S, g);
         }
 #pragma unroll
         for (int h = 0; h < H; ++h) {
@@ -429,7 +501,7 @@ __global__ __launch_bounds__(NTHREADS) void attn_block_fwd_kernel(const AttnFwdA
             f32x4 z[8];
 #pragma unroll
             for (int nt = 0; nt < 8; ++nt) z[nt] = oa[nt][rt];
-            residual_ln_store(z, a.nin, base + rt * 16 + cq, rt * 16 + cq < S, gin, bin, affine_in, gout, bout, a.o, g);
+            ln_store(z, base + rt * 16 + cq, rt * 16 + cq < S, gout, bout, a.o, g);
         }
     }
 }
@@ -464,12 +536,25 @@ int launch_mlp_block_fwd(const void *nin, const float *gin, const float *bin, co
     a.o = LnOut{static_cast<bf16 *>(nout), rstd, static_cast<bf16 *>(xout), static_cast<bf16 *>(zout), mean};
     a.hout = static_cast<bf16 *>(hout); a.uout = static_cast<bf16 *>(uout);
     constexpr int NR = 2;
-    auto kern = mlp_block_fwd_kernel<NR>;
-    RC(set_lds(kern, MLP_LDS));
     const int ntiles = ceil_div(M, 16 * NR);
     const int grid = std::min(256, ceil_div(ntiles, NWAVES));
+    const bool extras = hout || uout;
     ProfScope prof(s);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), MLP_LDS, s, a);
+#define MLP_LAUNCH(ACT_, EX_)                                                                    \
+    do {                                                                                         \
+        auto kern = mlp_block_fwd_kernel<NR, ACT_, EX_>;                                         \
+        RC(set_lds(kern, MLP_LDS));                                                              \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), MLP_LDS, s, a);                     \
+    } while (0)
+#define MLP_ACT(ACT_) do { if (extras) MLP_LAUNCH(ACT_, true); else MLP_LAUNCH(ACT_, false); } while (0)
+    switch (act) {
+        case MIVIT_ACT_RELU: MLP_ACT(MIVIT_ACT_RELU); break;
+        case MIVIT_ACT_LEAKY_RELU: MLP_ACT(MIVIT_ACT_LEAKY_RELU); break;
+        case MIVIT_ACT_GELU: MLP_ACT(MIVIT_ACT_GELU); break;
+        default: MLP_ACT(MIVIT_ACT_NONE); break;
+    }
+#undef MLP_ACT
+#undef MLP_LAUNCH
     MIVIT_LAUNCH_CHECK();
     return 0;
 }
@@ -489,14 +574,21 @@ int launch_attn_block_fwd(const void *nin, const float *gin, const float *bin, c
     a.gout = gout; a.bout = bout; a.B = B; a.S = S; a.ctx = static_cast<bf16 *>(ctx);
     a.o = LnOut{static_cast<bf16 *>(nout), rstd, static_cast<bf16 *>(xout), static_cast<bf16 *>(zout), mean};
     a.qkvout = static_cast<bf16 *>(qkvout);
-    const int grid = std::min(256, ceil_div(B, NWAVES));
     const int nt = ceil_div(S, 16);
+    static const int nw_env = [] { const char *e = getenv("MIVIT_ATTN_BLOCK_WAVES"); return e ? atoi(e) : 0; }();
+    const int nw = nw_env == 8 || nw_env == 4 ? nw_env : (nt >= 3 ? 4 : 8);
+    const int grid = std::min(256, ceil_div(B, nw));
     ProfScope prof(s);
+#define ATT_LAUNCH3(NT_, EX_, NW_)                                                               \
+    do {                                                                                         \
+        auto kern = attn_block_fwd_kernel<NT_, EX_, NW_>;                                        \
+        RC(set_lds(kern, ATT_LDS));                                                              \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(NW_ * 64), ATT_LDS, s, a);                     \
+    } while (0)
 #define ATT_LAUNCH(NT_)                                                                          \
     do {                                                                                         \
-        auto kern = attn_block_fwd_kernel<NT_>;                                                  \
-        RC(set_lds(kern, ATT_LDS));                                                              \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), ATT_LDS, s, a);                     \
+        if (qkvout) { if (nw == 8) ATT_LAUNCH3(NT_, true, 8); else ATT_LAUNCH3(NT_, true, 4); }  \
+        else { if (nw == 8) ATT_LAUNCH3(NT_, false, 8); else ATT_LAUNCH3(NT_, false, 4); }       \
     } while (0)
     switch (nt) {
         case 1: ATT_LAUNCH(1); break;
@@ -505,6 +597,7 @@ int launch_attn_block_fwd(const void *nin, const float *gin, const float *bin, c
         default: ATT_LAUNCH(4); break;
     }
 #undef ATT_LAUNCH
+#undef ATT_LAUNCH3
     MIVIT_LAUNCH_CHECK();
     return 0;
 }

@@ -438,3 +438,22 @@ int launch_fill_zero(void *p, size_t bytes, hipStream_t s) {
     MIVIT_HIP(hipMemsetAsync(p, 0, bytes, s));
     return 0;
 }
+
+// Weight gradient of a Linear whose input was handed over NORMALISED (x = gamma * n + beta applied by the consumer while
+// loading, fused layer blocks): the weight-gradient kernel contracted dy with n, so
+//   dW = dy^T (n diag(gamma) + 1 beta^T) = (dy^T n) diag(gamma) + db beta^T,   db = column sums of dy
+namespace {
+__global__ __launch_bounds__(256) void affine_fixup_kernel(float *dW, const float *db, const float *gamma, const float *beta,
+                                                           int N, int K) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N * K) return;
+    const int n = i / K, k = i - n * K;
+    dW[i] = dW[i] * gamma[k] + db[n] * beta[k];
+}
+}  // namespace
+int launch_affine_fixup(float *dW, const float *db, const float *gamma, const float *beta, int N, int K, hipStream_t s) {
+    MIVIT_CHECK(dW && db && gamma && beta && N > 0 && K > 0, "affine_fixup: null pointer / empty problem");
+    hipLaunchKernelGGL(affine_fixup_kernel, dim3(ceil_div(N * K, 256)), dim3(256), 0, s, dW, db, gamma, beta, N, K);
+    MIVIT_LAUNCH_CHECK();
+    return 0;
+}

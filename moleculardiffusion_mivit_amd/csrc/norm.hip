@@ -92,7 +92,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwd a) {
     for (int r = blockIdx.x * 4 + wave; r < a.M; r += gridDim.x * 4) {
         const int64_t dr = map_row(r, a.rows_per_seq, a.in_seq_stride, a.in_row_off);
         const int64_t zr = map_row(r, a.z_rows, a.z_stride, a.z_off);
-        const float mu = a.mean[r], rs = a.rstd[r];
+        const bool hat = a.mean == nullptr;          // z already holds the normalised rows (fused layer blocks)
+        const float mu = hat ? 0.f : a.mean[r], rs = a.rstd[r];
         float xh[EPL], g[EPL];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -100,7 +101,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwd a) {
             const int c = lane + 64 * i;
             const bool ok = c < a.E;
             const float d = ok ? to_f32(dy[dr * a.lddy + c]) : 0.f;
-            xh[i] = ok ? (to_f32(z[zr * a.ldz + c]) - mu) * rs : 0.f;
+            xh[i] = ok ? (hat ? to_f32(z[zr * a.ldz + c]) : (to_f32(z[zr * a.ldz + c]) - mu) * rs) : 0.f;
             g[i] = d * gam[i];
             accg[i] += d * xh[i];
             accb[i] += d;
@@ -224,7 +225,8 @@ __global__ __launch_bounds__(256) void ln_bwd_vec(const LnBwd a, const int LPR) 
         const bool valid = r < a.M;
         const int64_t dr = map_row(valid ? r : 0, a.rows_per_seq, a.in_seq_stride, a.in_row_off);
         const int64_t zr = map_row(valid ? r : 0, a.z_rows, a.z_stride, a.z_off);
-        const float mu = valid ? a.mean[r] : 0.f, rs = valid ? a.rstd[r] : 0.f;
+        const bool hat = a.mean == nullptr;          // z already holds the normalised rows (fused layer blocks)
+        const float mu = (valid && !hat) ? a.mean[r] : 0.f, rs = valid ? a.rstd[r] : 0.f;
         float xh[NV][V], g[NV][V];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -240,7 +242,7 @@ __global__ __launch_bounds__(256) void ln_bwd_vec(const LnBwd a, const int LPR) 
             }
 #pragma unroll
             for (int e = 0; e < V; ++e) {
-                xh[n][e] = (zz[e] - mu) * rs;
+                xh[n][e] = hat ? zz[e] : (zz[e] - mu) * rs;
                 g[n][e] = d[e] * gam[n][e];
                 accg[n][e] += d[e] * xh[n][e];
                 accb[n][e] += d[e];

@@ -1,0 +1,54 @@
+"""Micro-benchmark of the fused encoder-layer block kernels at the headline shape (B sequences of 33 tokens, E=128).
+    python scripts/bench_fused.py [B]
+Prints microseconds per launch, achieved HBM GB/s on the algorithmic bytes and MFMA TFLOP/s on the algorithmic FLOPs."""
+import math
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from moleculardiffusion_mivit_amd import ops  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+S, E, FH = 33, 128, 256
+dev = "cuda"
+g = torch.Generator(device=dev).manual_seed(0)
+rn = lambda *s, sc=1.0: torch.randn(*s, device=dev, generator=g) * sc
+n_in = rn(B, S, E).bfloat16()
+gi, bi = 1 + 0.1 * rn(E), 0.1 * rn(E)
+Wqkv, bqkv = rn(3 * E, E, sc=1 / math.sqrt(E)).bfloat16(), 0.1 * rn(3 * E)
+Wo, bo = rn(E, E, sc=1 / math.sqrt(E)).bfloat16(), 0.1 * rn(E)
+W1, b1 = rn(FH, E, sc=1 / math.sqrt(E)).bfloat16(), 0.1 * rn(FH)
+W2, b2 = rn(E, FH, sc=1 / math.sqrt(FH)).bfloat16(), 0.1 * rn(E)
+M = B * S
+
+
+def timeit(fn, n=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / n * 1e3
+
+
+U = M * E * 2
+cases = {
+    "attn_block_fwd lean": (lambda: ops.attn_block_fwd(n_in, gi, bi, Wqkv, bqkv, Wo, bo, gi, bi), 3 * U,
+                            M * (8 * E * E + 4 * S * E)),
+    "attn_block_fwd +legacy outputs": (lambda: ops.attn_block_fwd(n_in, gi, bi, Wqkv, bqkv, Wo, bo, gi, bi, extras=True), 8 * U,
+                                       M * (8 * E * E + 4 * S * E)),
+    "mlp_block_fwd lean": (lambda: ops.mlp_block_fwd(n_in.view(M, E), gi, bi, W1, b1, W2, b2, gi, bi), 2 * U, M * 4 * E * FH),
+    "mlp_block_fwd +legacy outputs": (lambda: ops.mlp_block_fwd(n_in.view(M, E), gi, bi, W1, b1, W2, b2, gi, bi, extras=True),
+                                      8 * U, M * 4 * E * FH),
+}
+if hasattr(ops, "mlp_block_bwd"):
+    pass
+for name, (fn, byt, fl) in cases.items():
+    us = timeit(fn)
+    print(f"{name:34s} {us:9.1f} us   {byt / us / 1e3:8.1f} GB/s   {fl / us / 1e6:8.1f} TFLOP/s", flush=True)
