@@ -135,6 +135,18 @@ int mivit_mlp_block_fwd(const void *n_in, const float *gamma_in, const float *be
                         const float *beta_out, int M, int act, void *n_out, float *rstd, void *x_out, void *z_out,
                         float *mean, void *h_out, void *u_out, void *stream);
 
+/* Fused backward of the feed-forward block (autograd of models.py:72-77,104-106 in the layout above), csrc/fused_bwd.hip:
+ * in : dy = dL/dx2 [M,E] bf16 (x2 = gamma2 * n2 + beta2), n2 / rstd2 = LN2's normalised output and 1/std, n1 = LN1's
+ *      normalised output (the block input is x1 = gamma1 * n1 + beta1), the bf16 weight copies and fc1's bias;
+ * out: dx1 = dL/dx1 [M,E] bf16;  dW1 [F,E], db1 [F], dW2 [E,F], db2 [E], dgamma2 [E], dbeta2 [E] fp32 (overwritten).
+ * The hidden activations are recomputed; h, dh and the pre-norm gradient never reach HBM (three row reads, one row write).
+ * Deterministic (per-workgroup slabs + fixed-order reduction).  workspace: mivit_mlp_block_bwd_workspace_bytes(M). */
+size_t mivit_mlp_block_bwd_workspace_bytes(int M);
+int mivit_mlp_block_bwd(const void *dy, const void *n2, const float *rstd2, const float *gamma2, const void *n1,
+                        const float *gamma1, const float *beta1, const void *W1_bf16, const float *b1, const void *W2_bf16,
+                        int M, int act, void *dx1, float *dW1, float *db1, float *dW2, float *db2, float *dgamma2,
+                        float *dbeta2, void *workspace, size_t workspace_bytes, void *stream);
+
 /* DeepResNetEmbedding in inference mode (helpers/models.py:230-257; ResidualBlock :202-228): conv3x3(1->32)+BN+ReLU,
  * ResidualBlock(32->64), ResidualBlock(64->128), global average pool, Linear(128->E), fused in one kernel that keeps F
  * whole frames in LDS.  Eval-mode BatchNorm is folded by the caller: conv weights are pre-scaled by

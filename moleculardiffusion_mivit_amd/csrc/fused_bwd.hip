@@ -1,0 +1,345 @@
+// Fused backward of the feed-forward half of the post-norm encoder layer, bf16 mode, E = 128 / F = 256
+// (reference helpers/models.py:72-77 FeedForward, :104-106 x = LN2(x1 + ff(x1)); autograd of that block):
+//
+//   in : dy = dL/dx2 (x2 = gamma2 * n2 + beta2), n2 = xhat of LN2, rstd2, n1 = xhat of LN1 (x1 = gamma1 * n1 + beta1)
+//   out: dx1 = dL/dx1,  dW1, db1, dW2, db2, dgamma2, dbeta2
+//
+// reading dy, n2, n1 ONCE and writing dx1 ONCE: the hidden activations h, their gradient dh and dz2 (the gradient of
+// the pre-norm sum) never reach HBM -- h is recomputed from n1.  One persistent workgroup per CU (4 waves, each owning a
+// SIMD's whole register file) walks 32-row tiles:
+//   phase 0 (all threads, element-wise): LayerNorm backward dy, n2 -> dz2 (LDS image DZ), n1 -> LDS image X; the
+//            column sums for dgamma2 / dbeta2 / db2 stay in registers; next tile's rows are already in flight.
+//   phase 1 (wave w owns hidden units 64w .. 64w+63; its slices of fc1 and fc2^T live in REGISTERS):
+//            u = n1 W1'^T + b1' (W1' = W1 * gamma1, b1' = b1 + W1 beta1: the LayerNorm affine is folded),
+//            dh = (dz2 W2) * act'(u) -- both un-transposed, so the accumulators (lane = hidden unit, registers = rows)
+//            ARE the row-contraction operands of the weight gradients:  dW1 += dh^T n1,  dW2 += dz2^T h, whose other
+//            operand is a transposing LDS read (ds_read_b64_tr_b16) of X / DZ.  128 + 128 accumulator registers per
+//            lane hold the wave's [64 x 128] and [128 x 64] gradient blocks for the whole launch.  dh -> LDS image DH.
+//   phase 2 (wave w owns input features 32w .. 32w+31): dx1^T = W1^T dh^T + dz2^T from an LDS image of W1^T.
+// dW1 is taken against n1; the caller corrects it with launch_affine_fixup (dW1 * gamma1 + db1 beta1^T).
+// Per-workgroup partial gradients go to slabs; a deterministic slab reduction finishes them (no atomics).
+#include "common.h"
+#include "stream_prims.h"
+#include <stdlib.h>
+#include <algorithm>
+
+#define RC(call) do { int rc_ = (call); if (rc_) return rc_; } while (0)
+
+namespace {
+
+constexpr int E = 128, F = 256;
+constexpr int NW = 4, NT = NW * 64, R = 32;          // waves per workgroup, threads, rows per tile
+constexpr int LDE = E + 16, LDF = F + 16;            // LDS row pitches (elements): conflict-free b128 and transposing reads
+
+constexpr int OFF_W1T = 0;                           // [E][LDF]  W1^T: row = input feature k, contraction index n contiguous
+constexpr int OFF_X = OFF_W1T + E * LDF * 2;         // [R][LDE]  n1 rows
+constexpr int OFF_DZ = OFF_X + R * LDE * 2;          // [R][LDE]  dz2 rows
+constexpr int OFF_DH = OFF_DZ + R * LDE * 2;         // [R][LDF]  dh rows
+constexpr int OFF_VEC = OFF_DH + R * LDF * 2;        // b1' [F] fp32
+constexpr int OFF_ACC = OFF_VEC + F * 4;             // [6][NT] float4: running column sums of the element-wise phase (dgamma2, dbeta2, db2)
+constexpr int OFF_STG = OFF_ACC + 6 * NT * 16;        // [6][NW][64] x 16 B: next tile's dy / n2 / n1 chunks, landed by LDS-DMA (thread-private slots)
+constexpr int LDS_BYTES = OFF_STG + 6 * NT * 16;
+static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+
+// slab layout per workgroup (floats)
+constexpr int SL_W1 = 0, SL_W2 = SL_W1 + F * E, SL_B1 = SL_W2 + E * F, SL_B2 = SL_B1 + F, SL_G2 = SL_B2 + E, SL_BE2 = SL_G2 + E,
+              SL_TOTAL = SL_BE2 + E;
+
+struct MlpBwdArgs {
+    const bf16 *dy, *n2; const float *rstd2, *gamma2;
+    const bf16 *n1; const float *gamma1, *beta1;
+    const bf16 *W1; const float *b1; const bf16 *W2;
+    int M;
+    bf16 *dx1;
+    float *slabs;          // [gridDim.x][SL_TOTAL]
+};
+
+__device__ __forceinline__ bf16x8 pack8(const f32x4 a, const f32x4 b) {
+    bf16x8 f;
+    f[0] = (__bf16)a[0]; f[1] = (__bf16)a[1]; f[2] = (__bf16)a[2]; f[3] = (__bf16)a[3];
+    f[4] = (__bf16)b[0]; f[5] = (__bf16)b[1]; f[6] = (__bf16)b[2]; f[7] = (__bf16)b[3];
+    return f;
+}
+__device__ __forceinline__ float x4_sum(float v) { v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64); }
+__device__ __forceinline__ float g16_sum(float v) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ bf16x8 lds_frag(const bf16 *p) { return *reinterpret_cast<const bf16x8 *>(p); }
+__device__ __forceinline__ void unpack8(const uint4 &u, float (&v)[8]) {
+    const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+}
+
+template <int ACT>
+__global__ __launch_bounds__(NT) void mlp_block_bwd_kernel(const MlpBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16 *W1T = reinterpret_cast<bf16 *>(smem + OFF_W1T);
+    bf16 *X = reinterpret_cast<bf16 *>(smem + OFF_X), *DZ = reinterpret_cast<bf16 *>(smem + OFF_DZ), *DH = reinterpret_cast<bf16 *>(smem + OFF_DH);
+    float *b1f = reinterpret_cast<float *>(smem + OFF_VEC);
+    f32x4 *cacc = reinterpret_cast<f32x4 *>(smem + OFF_ACC);
+    uint4 *stg = reinterpret_cast<uint4 *>(smem + OFF_STG);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, cq = lane & 15, q = cq >> 2, pp = cq & 3;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+
+    // ---- one-time staging ----
+    // W1^T image: W1T[k][n] = W1[n][k]
+    for (int i = tid; i < F * (E / 8); i += NT) {
+        const int n = i / (E / 8), c = i - n * (E / 8);
+        const uint4 v = *reinterpret_cast<const uint4 *>(a.W1 + (int64_t)n * E + c * 8);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) W1T[(c * 8 + e) * LDF + n].v = (uint16_t)((e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xffffu));
+    }
+    // b1' = b1 + W1 beta1
+    for (int n = tid; n < F; n += NT) {
+        float acc = a.b1[n];
+        for (int c = 0; c < E / 8; ++c) {
+            float v[8];
+            load16(a.W1 + (int64_t)n * E + c * 8, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc += v[e] * a.beta1[c * 8 + e];
+        }
+        b1f[n] = acc;
+    }
+    // register-resident operands of this wave's hidden units n = 64 wave + 16 nt + cq:
+    //   w1f[nt][ks]: W1'[n][32ks + 8g .. +7]          (column operand of u = n1 W1'^T)
+    //   w2f[nt][ks]: W2[32ks + 8g .. +7][n]           (column operand of dh = dz2 W2)
+    bf16x8 w1f[4][4], w2f[4][4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int n = 64 * wave + 16 * nt + cq;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            float v[8];
+            load16(a.W1 + (int64_t)n * E + ks * 32 + 8 * g, v);
+            f32x4 lo, hi;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { lo[e] = v[e] * a.gamma1[ks * 32 + 8 * g + e]; hi[e] = v[4 + e] * a.gamma1[ks * 32 + 8 * g + 4 + e]; }
+            w1f[nt][ks] = pack8(lo, hi);
+            bf16x8 t;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t[e] = __builtin_bit_cast(__bf16, a.W2[(int64_t)(ks * 32 + 8 * g + e) * F + n].v);
+            w2f[nt][ks] = t;
+        }
+    }
+    // this thread's slice of the element-wise phase: columns 8c .. 8c+7 of rows r0 and r0 + 16 of the tile
+    const int c = tid & 15, r0 = tid >> 4;
+    float gam2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) gam2[e] = a.gamma2[8 * c + e];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) cacc[i * NT + tid] = f32x4{0.f, 0.f, 0.f, 0.f};       // (thread-private slots: no barrier needed)
+    f32x4 dW1[4][8], dW2[8][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { dW1[i][j] = zero; dW2[j][i] = zero; }
+    float db1[4] = {0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+
+    const int ntiles = (a.M + R - 1) / R;
+    int tile = blockIdx.x;
+    // next tile's rows travel global -> LDS by DMA into slots only this thread reads back: no registers held across the
+    // compute phases, no barrier -- the issuing wave's vmcnt wait is the only ordering needed
+    float prs[2];
+    auto prefetch = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int64_t row = min((int64_t)t * R + r0 + 16 * i, (int64_t)a.M - 1);
+            const int64_t o = row * E + 8 * c;
+            dma16(a.dy + o, stg + (3 * i + 0) * NT + wave * 64);
+            dma16(a.n2 + o, stg + (3 * i + 1) * NT + wave * 64);
+            dma16(a.n1 + o, stg + (3 * i + 2) * NT + wave * 64);
+            prs[i] = ((int64_t)t * R + r0 + 16 * i < a.M) ? a.rstd2[row] : 0.f;
+        }
+    };
+    if (tile < ntiles) prefetch(tile);
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int64_t row0 = (int64_t)tile * R;
+        // ---------------- phase 0: LayerNorm backward (element-wise), images X and DZ ----------------
+        {
+            float sg[8], sb[8], sz[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sg[e] = sb[e] = sz[e] = 0.f;
+            wait_vm<0>();
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                float d[8], nh[8], gdy[8];
+                const bool ok = row0 + r0 + 16 * i < a.M;          // rows past the end were clamped to a real row: cancel them
+                const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
+                const uint4 pdy = ok ? stg[(3 * i + 0) * NT + tid] : z4, pn2 = stg[(3 * i + 1) * NT + tid];
+                const uint4 pn1 = ok ? stg[(3 * i + 2) * NT + tid] : z4;
+                unpack8(pdy, d); unpack8(pn2, nh);
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    gdy[e] = d[e] * gam2[e];
+                    s1 += gdy[e]; s2 += gdy[e] * nh[e];
+                    sg[e] += d[e] * nh[e]; sb[e] += d[e];
+                }
+                s1 = g16_sum(s1) * (1.f / E); s2 = g16_sum(s2) * (1.f / E);
+                float dz[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { dz[e] = prs[i] * (gdy[e] - s1 - nh[e] * s2); sz[e] += dz[e]; }
+                store16(DZ + (r0 + 16 * i) * LDE + 8 * c, dz);
+                *reinterpret_cast<uint4 *>(X + (r0 + 16 * i) * LDE + 8 * c) = pn1;
+            }
+            cacc[0 * NT + tid] += f32x4{sg[0], sg[1], sg[2], sg[3]}; cacc[1 * NT + tid] += f32x4{sg[4], sg[5], sg[6], sg[7]};
+            cacc[2 * NT + tid] += f32x4{sb[0], sb[1], sb[2], sb[3]}; cacc[3 * NT + tid] += f32x4{sb[4], sb[5], sb[6], sb[7]};
+            cacc[4 * NT + tid] += f32x4{sz[0], sz[1], sz[2], sz[3]}; cacc[5 * NT + tid] += f32x4{sz[4], sz[5], sz[6], sz[7]};
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the staging slots have been read: they may be refilled
+        prefetch(min(tile + (int)gridDim.x, ntiles - 1));       // next tile's rows: in flight under phases 1 and 2
+        __syncthreads();
+        // ---------------- phase 1: u, dh for this wave's 64 hidden units; dW1, dW2 ----------------
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {             // one 16-wide block of the wave's hidden units at a time (register budget)
+            const float bv = b1f[64 * wave + 16 * nt + cq];
+            f32x4 u[2] = {f32x4{bv, bv, bv, bv}, f32x4{bv, bv, bv, bv}}, dh[2] = {zero, zero};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) {
+                    u[rt] = mma(lds_frag(X + (16 * rt + cq) * LDE + ks * 32 + 8 * g), w1f[nt][ks], u[rt]);
+                    dh[rt] = mma(lds_frag(DZ + (16 * rt + cq) * LDE + ks * 32 + 8 * g), w2f[nt][ks], dh[rt]);
+                }
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float uu = u[rt][j];
+                    dh[rt][j] *= act_bwd(ACT, ACT == MIVIT_ACT_GELU ? uu : act_fwd(ACT, uu));
+                    u[rt][j] = act_fwd(ACT, uu);
+                    db1[nt] += dh[rt][j];
+                    DH[(16 * rt + 4 * g + j) * LDF + 64 * wave + 16 * nt + cq] = from_f32<bf16>(dh[rt][j]);
+                }
+            const bf16x8 hB = pack8(u[0], u[1]), dhB = pack8(dh[0], dh[1]);
+            // weight gradients: the contraction runs over the 32 rows of the tile (slots 0-3 = rows 4g.., slots 4-7 = rows 16+4g..)
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const bf16x8 xb = tr_pair(X + (4 * g + q) * LDE + 16 * t + 4 * pp, X + (16 + 4 * g + q) * LDE + 16 * t + 4 * pp);
+                const bf16x8 zb = tr_pair(DZ + (4 * g + q) * LDE + 16 * t + 4 * pp, DZ + (16 + 4 * g + q) * LDE + 16 * t + 4 * pp);
+                dW1[nt][t] = mma(dhB, xb, dW1[nt][t]);       // [n][k] += dh^T n1
+                dW2[t][nt] = mma(zb, hB, dW2[t][nt]);        // [e][n] += dz2^T h
+            }
+        }
+        __syncthreads();
+        // ---------------- phase 2: dx1^T for this wave's 32 input features ----------------
+        f32x4 dx[2][2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) dx[kt][rt] = zero;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const bf16x8 d0 = lds_frag(DH + cq * LDF + ks * 32 + 8 * g), d1 = lds_frag(DH + (16 + cq) * LDF + ks * 32 + 8 * g);
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                const bf16x8 wa = lds_frag(W1T + (32 * wave + 16 * kt + cq) * LDF + ks * 32 + 8 * g);
+                dx[kt][0] = mma(wa, d0, dx[kt][0]);
+                dx[kt][1] = mma(wa, d1, dx[kt][1]);
+            }
+        }
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            const int64_t row = row0 + 16 * rt + cq;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                const int col = 32 * wave + 16 * kt + 4 * g;
+                const uint2 zr = *reinterpret_cast<const uint2 *>(DZ + (16 * rt + cq) * LDE + col);
+                f32x4 o = dx[kt][rt];
+                o[0] += __uint_as_float(zr.x << 16); o[1] += __uint_as_float(zr.x & 0xffff0000u);
+                o[2] += __uint_as_float(zr.y << 16); o[3] += __uint_as_float(zr.y & 0xffff0000u);
+                if (row < a.M) {
+                    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+                    const bf16x4 ob = {(__bf16)o[0], (__bf16)o[1], (__bf16)o[2], (__bf16)o[3]};
+                    *reinterpret_cast<bf16x4 *>(a.dx1 + row * E + col) = ob;
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---------------- partial gradients -> this workgroup's slab ----------------
+    float *sl = a.slabs + (int64_t)blockIdx.x * SL_TOTAL;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                sl[SL_W1 + (64 * wave + 16 * nt + 4 * g + j) * E + 16 * t + cq] = dW1[nt][t][j];
+                sl[SL_W2 + (16 * t + 4 * g + j) * F + 64 * wave + 16 * nt + cq] = dW2[t][nt][j];
+            }
+        const float s = x4_sum(db1[nt]);
+        if (g == 0) sl[SL_B1 + 64 * wave + 16 * nt + cq] = s;
+    }
+    // column sums of the element-wise phase: thread (c, r0) holds columns 8c .. 8c+7; fold the 16 row-threads of a column
+    __syncthreads();
+    for (int i = tid; i < 3 * E; i += NT) {
+        const int which = i / E, col = i - which * E, cc = col >> 3, e = col & 7;
+        float s = 0.f;
+        for (int rr = 0; rr < 16; ++rr) s += cacc[(2 * which + (e >> 2)) * NT + cc + 16 * rr][e & 3];
+        sl[(which == 0 ? SL_G2 : which == 1 ? SL_BE2 : SL_B2) + col] = s;
+    }
+}
+
+bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+int grid_for(int M) { return std::min(256, ceil_div(M, R)); }
+
+}  // namespace
+
+size_t mlp_block_bwd_ws_bytes(int M) { return align_up((size_t)grid_for(std::max(M, 1)) * SL_TOTAL * sizeof(float), 256); }
+
+// dW1 [F,E] (taken against n1: the caller applies launch_affine_fixup), db1 [F], dW2 [E,F], db2 [E], dgamma2, dbeta2 [E]: overwritten
+int launch_mlp_block_bwd(const void *dy, const void *n2, const float *rstd2, const float *gamma2, const void *n1,
+                         const float *gamma1, const float *beta1, const void *W1, const float *b1, const void *W2, int M, int act,
+                         void *dx1, float *dW1, float *db1, float *dW2, float *db2, float *dgamma2, float *dbeta2, void *ws,
+                         size_t ws_bytes, hipStream_t s) {
+    MIVIT_CHECK(dy && n2 && rstd2 && gamma2 && n1 && gamma1 && beta1 && W1 && b1 && W2 && dx1 && dW1 && db1 && dW2 && db2 &&
+                dgamma2 && dbeta2 && ws && M > 0, "mlp_block_bwd: null pointer / empty problem");
+    MIVIT_CHECK(aligned16(dy) && aligned16(n2) && aligned16(n1) && aligned16(W1) && aligned16(dx1), "mlp_block_bwd: pointers must be 16-byte aligned");
+    MIVIT_CHECK(ws_bytes >= mlp_block_bwd_ws_bytes(M), "mlp_block_bwd: workspace too small");
+    MlpBwdArgs a{static_cast<const bf16 *>(dy), static_cast<const bf16 *>(n2), rstd2, gamma2, static_cast<const bf16 *>(n1), gamma1,
+                 beta1, static_cast<const bf16 *>(W1), b1, static_cast<const bf16 *>(W2), M, static_cast<bf16 *>(dx1),
+                 static_cast<float *>(ws)};
+    const int grid = grid_for(M);
+    {
+        ProfScope prof(s);
+#define BWD_LAUNCH(ACT_)                                                                                         \
+    do {                                                                                                         \
+        auto kern = mlp_block_bwd_kernel<ACT_>;                                                                  \
+        MIVIT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES)); \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), LDS_BYTES, s, a);                                         \
+    } while (0)
+        switch (act) {
+            case MIVIT_ACT_RELU: BWD_LAUNCH(MIVIT_ACT_RELU); break;
+            case MIVIT_ACT_LEAKY_RELU: BWD_LAUNCH(MIVIT_ACT_LEAKY_RELU); break;
+            case MIVIT_ACT_GELU: BWD_LAUNCH(MIVIT_ACT_GELU); break;
+            default: BWD_LAUNCH(MIVIT_ACT_NONE); break;
+        }
+#undef BWD_LAUNCH
+        MIVIT_LAUNCH_CHECK();
+    }
+    const float *sl = static_cast<const float *>(ws);
+    // the slab rows are [dW1 | dW2 | db1 | db2 | dgamma2 | dbeta2]: one strided reduction per output
+    struct { int off, n; float *out; } parts[] = {{SL_W1, F * E, dW1}, {SL_W2, E * F, dW2}, {SL_B1, F, db1}, {SL_B2, E, db2},
+                                                  {SL_G2, E, dgamma2}, {SL_BE2, E, dbeta2}};
+    for (auto &p : parts) RC(launch_slab_reduce_strided(sl + p.off, grid, SL_TOTAL, p.n, p.out, s));
+    return 0;
+}
+
+extern "C" size_t mivit_mlp_block_bwd_workspace_bytes(int M) { return mlp_block_bwd_ws_bytes(M); }
+extern "C" int mivit_mlp_block_bwd(const void *dy, const void *n2, const float *rstd2, const float *gamma2, const void *n1,
+                                   const float *gamma1, const float *beta1, const void *W1_bf16, const float *b1,
+                                   const void *W2_bf16, int M, int act, void *dx1, float *dW1, float *db1, float *dW2, float *db2,
+                                   float *dgamma2, float *dbeta2, void *workspace, size_t workspace_bytes, void *stream) {
+    prof_set_tag(MIVIT_PROF_OP);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    RC(launch_mlp_block_bwd(dy, n2, rstd2, gamma2, n1, gamma1, beta1, W1_bf16, b1, W2_bf16, M, act, dx1, dW1, db1, dW2, db2, dgamma2,
+                            dbeta2, workspace, workspace_bytes, s));
+    return launch_affine_fixup(dW1, db1, gamma1, beta1, F, E, s);       // operator level: dW1 comes back against x1, as autograd's
+}

@@ -92,8 +92,8 @@ namespace {
 
 // out[i] (+)= sum_p part[p * n + i].  Block = 32 element-threads (one float4 each) x 8 part-lanes; every part-lane
 // sums its parts in a fixed order, the 8 lanes are combined through LDS in a fixed order: deterministic.
-__global__ __launch_bounds__(256) void slab_reduce_kernel(const float *part, int nparts, int64_t n, float *out,
-                                                          int accumulate, int vec_ok) {
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float *part, int nparts, int64_t n, int64_t ps, float *out,
+                                                          int accumulate, int vec_ok) {      // ps = distance between parts
     __shared__ float4 red[8][32];
     const int ex = threadIdx.x & 31, pl = threadIdx.x >> 5;
     const int64_t e0 = ((int64_t)blockIdx.x * 32 + ex) * 4;
@@ -102,20 +102,20 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float *part, int
         if (vec_ok) {
             int p = pl;
             for (; p + 24 < nparts; p += 32) {        // 4 independent 16-byte loads in flight per thread
-                const float4 a = *reinterpret_cast<const float4 *>(part + (int64_t)p * n + e0);
-                const float4 b = *reinterpret_cast<const float4 *>(part + (int64_t)(p + 8) * n + e0);
-                const float4 c = *reinterpret_cast<const float4 *>(part + (int64_t)(p + 16) * n + e0);
-                const float4 d = *reinterpret_cast<const float4 *>(part + (int64_t)(p + 24) * n + e0);
+                const float4 a = *reinterpret_cast<const float4 *>(part + (int64_t)p * ps + e0);
+                const float4 b = *reinterpret_cast<const float4 *>(part + (int64_t)(p + 8) * ps + e0);
+                const float4 c = *reinterpret_cast<const float4 *>(part + (int64_t)(p + 16) * ps + e0);
+                const float4 d = *reinterpret_cast<const float4 *>(part + (int64_t)(p + 24) * ps + e0);
                 acc.x += (a.x + b.x) + (c.x + d.x); acc.y += (a.y + b.y) + (c.y + d.y);
                 acc.z += (a.z + b.z) + (c.z + d.z); acc.w += (a.w + b.w) + (c.w + d.w);
             }
             for (; p < nparts; p += 8) {
-                const float4 a = *reinterpret_cast<const float4 *>(part + (int64_t)p * n + e0);
+                const float4 a = *reinterpret_cast<const float4 *>(part + (int64_t)p * ps + e0);
                 acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
             }
         } else {
             for (int p = pl; p < nparts; p += 8) {
-                const float *q = part + (int64_t)p * n + e0;
+                const float *q = part + (int64_t)p * ps + e0;
                 acc.x += q[0];
                 if (e0 + 1 < n) acc.y += q[1];
                 if (e0 + 2 < n) acc.z += q[2];
@@ -329,7 +329,15 @@ int launch_slab_reduce3(const float *p0, float *o0, const float *p1, float *o1, 
 int launch_slab_reduce(const float *part, int nparts, int64_t n, float *out, int accumulate, hipStream_t s) {
     const int blocks = (int)((n + 127) / 128);
     const int vec_ok = (n % 4 == 0) && ((reinterpret_cast<uintptr_t>(part) & 15) == 0);
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, s, part, nparts, n, out, accumulate, vec_ok);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, s, part, nparts, n, n, out, accumulate, vec_ok);
+    MIVIT_LAUNCH_CHECK();
+    return 0;
+}
+// the same for parts that are `stride` floats apart (one field of a per-workgroup record)
+int launch_slab_reduce_strided(const float *part, int nparts, int64_t stride, int64_t n, float *out, hipStream_t s) {
+    const int blocks = (int)((n + 127) / 128);
+    const int vec_ok = (n % 4 == 0) && (stride % 4 == 0) && ((reinterpret_cast<uintptr_t>(part) & 15) == 0);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, s, part, nparts, n, stride, out, 0, vec_ok);
     MIVIT_LAUNCH_CHECK();
     return 0;
 }

@@ -391,3 +391,23 @@ def mlp_block_fwd(n_in, gamma_in, beta_in, W1, b1, W2, b2, gamma_out, beta_out, 
                                       _p(go), _p(bo_), M, act, _p(out["n"]), _p(out["rstd"]), _p(out.get("x")), _p(out.get("z")),
                                       _p(out.get("mean")), _p(out.get("h")), _p(out.get("u")), _s(n_in)), "mivit_mlp_block_fwd")
     return out
+
+
+@torch.no_grad()
+def mlp_block_bwd(dy, n2, rstd2, gamma2, n1, gamma1, beta1, W1, b1, W2, act=N.ACT_RELU):
+    """Backward of the feed-forward block (see include/mivit_hip.h): returns dict(dx1, dW1, db1, dW2, db2, dgamma2, dbeta2)."""
+    _gpu(dy, n2, n1, W1, W2)
+    M, E = dy.shape
+    Fh = W1.shape[0]
+    dev = dy.device
+    out = {"dx1": torch.empty(M, E, dtype=torch.bfloat16, device=dev), "dW1": torch.empty(Fh, E, device=dev),
+           "db1": torch.empty(Fh, device=dev), "dW2": torch.empty(E, Fh, device=dev), "db2": torch.empty(E, device=dev),
+           "dgamma2": torch.empty(E, device=dev), "dbeta2": torch.empty(E, device=dev)}
+    nbytes = N.lib.mivit_mlp_block_bwd_workspace_bytes(M)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    args = [dy.contiguous(), n2.contiguous(), _f32(rstd2), _f32(gamma2), n1.contiguous(), _f32(gamma1), _f32(beta1), W1.contiguous(),
+            _f32(b1), W2.contiguous()]
+    N.check(N.lib.mivit_mlp_block_bwd(*[_p(t) for t in args], M, act, _p(out["dx1"]), _p(out["dW1"]), _p(out["db1"]), _p(out["dW2"]),
+                                      _p(out["db2"]), _p(out["dgamma2"]), _p(out["dbeta2"]), _p(ws), nbytes, _s(dy)),
+            "mivit_mlp_block_bwd")
+    return out

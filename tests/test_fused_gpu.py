@@ -149,3 +149,54 @@ def test_attn_block_fwd_uniform_softmax_exact():
     assert torch.equal(out["qkv"].float().cpu()[..., 2 * E:], v)
     assert _rel(out["ctx"].float(), ctx) < 8e-3           # 1/32 * sum of bf16-exact integers, rounded to bf16 once
     assert _rel(out["z"].float(), z) < 8e-3
+
+
+def _act_grad(act, u):
+    if act == 1:
+        return (u > 0).float()
+    if act == 2:
+        return torch.where(u > 0, torch.ones_like(u), torch.full_like(u, 0.01))
+    return 0.5 * (1 + torch.erf(u / math.sqrt(2.0))) + u * torch.exp(-0.5 * u * u) / math.sqrt(2 * math.pi)
+
+
+@pytest.mark.parametrize("M", [1, 31, 264, 1000, 8200])
+@pytest.mark.parametrize("act", [1, 2, 3])
+def test_mlp_block_bwd(M, act):
+    """Fused feed-forward backward vs the chain rule of x2 = LN2(x1 + fc2(act(fc1 x1))), x1 = gamma1 * n1 + beta1, written
+    out in fp32.  The pre-activations are taken as the kernel forms them (normalised rows times the gamma-folded bf16
+    weights): a ReLU unit whose pre-activation lies within bf16 rounding of zero would otherwise take the other branch in
+    one of the two computations -- the function is discontinuous there."""
+    from moleculardiffusion_mivit_amd import ops
+    n1 = _bf(_mk((M, E), 21)).float()
+    g1, be1 = 1.0 + 0.3 * _mk((E,), 22), 0.2 * _mk((E,), 23)
+    W1, b1 = _bf(_mk((FH, E), 24, 1 / math.sqrt(E))).float(), 0.1 * _mk((FH,), 25)
+    W2, b2 = _bf(_mk((E, FH), 26, 1 / math.sqrt(FH))).float(), 0.1 * _mk((E,), 27)
+    g2, be2 = 1.0 + 0.3 * _mk((E,), 28), 0.2 * _mk((E,), 29)
+    dy = _bf(_mk((M, E), 30)).float()
+    x1 = n1 * g1 + be1
+    u = F.linear(n1, _bf(W1 * g1).float(), b1 + W1 @ be1)
+    h = ACTS[act](u)
+    z2 = x1 + F.linear(h, W2, b2)
+    nh, _, rstd = _ln_hat(z2)
+    gdy = dy * g2
+    dz2 = rstd[:, None] * (gdy - gdy.mean(-1, keepdim=True) - nh * (gdy * nh).mean(-1, keepdim=True))
+    dh = (dz2 @ W2) * _act_grad(act, u)
+    ref = {"dx1": dh @ W1 + dz2, "dW1": dh.t() @ x1, "db1": dh.sum(0), "dW2": dz2.t() @ h, "db2": dz2.sum(0),
+           "dgamma2": (dy * nh).sum(0), "dbeta2": dy.sum(0)}
+    out = ops.mlp_block_bwd(_bf(dy).cuda(), _bf(nh).cuda(), rstd.cuda(), g2.cuda(), _bf(n1).cuda(), g1.cuda(), be1.cuda(),
+                            _bf(W1).cuda(), b1.cuda(), _bf(W2).cuda(), act=act)
+    torch.cuda.synchronize()
+    for k, r in ref.items():
+        assert _rel(out[k].float(), r) < 3e-2, k
+
+
+def test_mlp_block_bwd_is_deterministic():
+    from moleculardiffusion_mivit_amd import ops
+    M = 5000
+    args = [_bf(_mk((M, E), 31)).cuda(), _bf(_mk((M, E), 32)).cuda(), (1 + 0.1 * _mk((M,), 33).abs()).cuda(), (1 + 0.1 * _mk((E,), 34)).cuda(),
+            _bf(_mk((M, E), 35)).cuda(), (1 + 0.1 * _mk((E,), 36)).cuda(), (0.1 * _mk((E,), 37)).cuda(),
+            _bf(_mk((FH, E), 38, 0.1)).cuda(), (0.1 * _mk((FH,), 39)).cuda(), _bf(_mk((E, FH), 40, 0.1)).cuda()]
+    a, b = ops.mlp_block_bwd(*args), ops.mlp_block_bwd(*args)
+    torch.cuda.synchronize()
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
