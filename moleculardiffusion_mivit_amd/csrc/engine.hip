@@ -19,6 +19,12 @@ int launch_mlp_block_fwd(const void *nin, const float *gin, const float *bin, co
                          const float *b2, const float *gout, const float *bout, int M, int act, void *nout, float *rstd,
                          void *xout, void *zout, float *mean, void *hout, void *uout, hipStream_t s);
 
+size_t mlp_block_bwd_ws_bytes(int M);
+int launch_mlp_block_bwd(const void *dy, const void *n2, const float *rstd2, const float *gamma2, const void *n1,
+                         const float *gamma1, const float *beta1, const void *W1, const float *b1, const void *W2, int M, int act,
+                         void *dx1, float *dW1, float *db1, float *dW2, float *db2, float *dgamma2, float *dbeta2, void *ws,
+                         size_t ws_bytes, hipStream_t s);
+
 struct ParamInfo {
     std::string name;
     int64_t offset, numel;
@@ -95,7 +101,7 @@ Ws make_ws(const mivit_plan *p, int B, int T, bool bwd) {
             // fused layer blocks: z1 / z2 hold the NORMALISED sub-layer outputs (xhat, bf16), rstd1 / rstd2 their 1/std;
             // q|k|v and h are kept only for the backward; no pre-norm sums, no means, no x copies
             s.qkv = bwd ? take(M * 3 * E * ts) : 0; s.ctx = take(M * E * ts); s.z1 = take(M * E * ts); s.x1 = 0;
-            s.h = bwd ? take(M * F * ts) : 0; s.u = bwd && c.activation == MIVIT_ACT_GELU ? take(M * F * ts) : 0;
+            s.h = 0; s.u = 0;
             s.z2 = take(M * E * ts); s.x2 = 0;
             s.mean1 = s.mean2 = 0; s.rstd1 = take(M * 4); s.rstd2 = take(M * 4);
         } else {
@@ -130,6 +136,7 @@ Ws make_ws(const mivit_plan *p, int B, int T, bool bwd) {
             if (b > wg) wg = b;
         };
         mx((int)M, 3 * E, E); mx((int)M, E, E); mx((int)M, F, E); mx((int)M, E, F);
+        if (fused) wg = std::max(wg, mlp_block_bwd_ws_bytes((int)M));
         if (c.embedding != MIVIT_EMBED_EXTERNAL) {
             mx((int)Mt, E, c.patch_size * c.patch_size);
             if (embed_dma_supported(c.dtype, (int)Mt, c.patch_size * c.patch_size, E)) {
@@ -462,8 +469,7 @@ static int forward_impl(const mivit_plan *plan, const float *params, const float
             prof_set_tag(MIVIT_PROF_LINEAR_FWD);
             RC(launch_mlp_block_fwd(at(ws, b.z1), P + lp.n1_w, P + lp.n1_b, WT(lp.fc1_w), P + lp.fc1_b, WT(lp.fc2_w), P + lp.fc2_b,
                                     P + lp.n2_w, P + lp.n2_b, M, c.activation, at(ws, b.z2), static_cast<float *>(at(ws, b.rstd2)),
-                                    last ? at(ws, w.xL) : nullptr, nullptr, nullptr, need_backward ? at(ws, b.h) : nullptr,
-                                    need_backward && c.activation == MIVIT_ACT_GELU ? at(ws, b.u) : nullptr, s));
+                                    last ? at(ws, w.xL) : nullptr, nullptr, nullptr, nullptr, nullptr, s));      // (h is recomputed by the fused backward)
             nin = at(ws, b.z2); gin = P + lp.n2_w; bin = P + lp.n2_b;
         }
         xin = at(ws, w.xL);
@@ -617,27 +623,37 @@ static int backward_impl(const mivit_plan *plan, const float *params, const floa
             n2.M = M; n2.E = E; n2.dz = at(ws, w.dxb); n2.lddz = E; n2.dgamma = G + lp.n2_w; n2.dbeta = G + lp.n2_b;
             n2.ws = at(ws, w.ln); n2.ws_bytes = w.ln_bytes;
             bool cs = false;
+            void *dx1 = at(ws, w.dxa), *dz1 = at(ws, w.dxb);      // where d(x1) arrives / where LayerNorm-1's backward puts d(z1)
+            if (fz) {
+                // feed-forward block in one launch (fused_bwd.hip): d(x2) -> d(x1), all six parameter gradients
+                dx1 = at(ws, w.dxb); dz1 = at(ws, w.dF);
+                prof_set_tag(MIVIT_PROF_LINEAR_DGRAD);
+                RC(launch_mlp_block_bwd(at(ws, w.dxa), at(ws, b.z2), static_cast<const float *>(at(ws, b.rstd2)), P + lp.n2_w,
+                                        at(ws, b.z1), P + lp.n1_w, P + lp.n1_b, WT(lp.fc1_w), P + lp.fc1_b, WT(lp.fc2_w), M,
+                                        c.activation, dx1, G + lp.fc1_w, G + lp.fc1_b, G + lp.fc2_w, G + lp.fc2_b, G + lp.n2_w,
+                                        G + lp.n2_b, wg, wgb, s));
+            } else {
             RC(ln_bwd_bias(n2, G + lp.fc2_b, &cs, s));                                            // dxb = d(z2), fc2.bias grad
             RC(lin_wgrad(dt, at(ws, w.dxb), E, at(ws, b.h), 0, F, M, E, F, G + lp.fc2_w, cs ? G + lp.fc2_b : nullptr, wg, wgb, s));
             RC(lin_dgrad(dt, at(ws, w.dxb), E, WT(lp.fc2_w), M, E, F, c.activation,
                          c.activation == MIVIT_ACT_GELU ? at(ws, b.u) : at(ws, b.h), F, nullptr, 0, at(ws, w.dF), F, 0, s));
-            RC(lin_wgrad(dt, at(ws, w.dF), F, fz ? at(ws, b.z1) : at(ws, b.x1), 0, E, M, F, E, G + lp.fc1_w, G + lp.fc1_b, wg, wgb, s));
-            if (fz) RC(launch_affine_fixup(G + lp.fc1_w, G + lp.fc1_b, P + lp.n1_w, P + lp.n1_b, F, E, s));
+            RC(lin_wgrad(dt, at(ws, w.dF), F, at(ws, b.x1), 0, E, M, F, E, G + lp.fc1_w, G + lp.fc1_b, wg, wgb, s));
             RC(lin_dgrad(dt, at(ws, w.dF), F, WT(lp.fc1_w), M, F, E, MIVIT_ACT_NONE, nullptr, 0, at(ws, w.dxb), E,
                          at(ws, w.dxa), E, 0, s));                                                // dxa = d(x1)
+            }
             LayerNormBwdArgs n1 = n2;
-            n1.dy = at(ws, w.dxa); n1.z = at(ws, b.z1); n1.gamma = P + lp.n1_w;
+            n1.dy = dx1; n1.z = at(ws, b.z1); n1.gamma = P + lp.n1_w;
             n1.mean = fz ? nullptr : static_cast<const float *>(at(ws, b.mean1)); n1.rstd = static_cast<const float *>(at(ws, b.rstd1));
-            n1.dz = at(ws, w.dxb); n1.dgamma = G + lp.n1_w; n1.dbeta = G + lp.n1_b;
+            n1.dz = dz1; n1.dgamma = G + lp.n1_w; n1.dbeta = G + lp.n1_b;
             RC(ln_bwd_bias(n1, G + lp.out_b, &cs, s));                                            // dxb = d(z1), out_proj.bias grad
-            RC(lin_wgrad(dt, at(ws, w.dxb), E, at(ws, b.ctx), 0, E, M, E, E, G + lp.out_w, cs ? G + lp.out_b : nullptr, wg, wgb, s));
-            RC(lin_dgrad(dt, at(ws, w.dxb), E, WT(lp.out_w), M, E, E, MIVIT_ACT_NONE, nullptr, 0, nullptr, 0,
+            RC(lin_wgrad(dt, dz1, E, at(ws, b.ctx), 0, E, M, E, E, G + lp.out_w, cs ? G + lp.out_b : nullptr, wg, wgb, s));
+            RC(lin_dgrad(dt, dz1, E, WT(lp.out_w), M, E, E, MIVIT_ACT_NONE, nullptr, 0, nullptr, 0,
                          at(ws, w.dctx), E, 0, s));
             prof_set_tag(MIVIT_PROF_ATTN_BWD); RC(launch_attention_bwd(dt, at(ws, b.qkv), at(ws, w.dctx), B, S, H, Dh, at(ws, w.dqkv), s));
             RC(lin_wgrad(dt, at(ws, w.dqkv), 3 * E, xin, 0, E, M, 3 * E, E, G + lp.qkv_w, G + lp.qkv_b, wg, wgb, s));
             if (fz && l > 0)
                 RC(launch_affine_fixup(G + lp.qkv_w, G + lp.qkv_b, P + plan->layers[l - 1].n2_w, P + plan->layers[l - 1].n2_b, 3 * E, E, s));
-            RC(lin_dgrad(dt, at(ws, w.dqkv), 3 * E, WT(lp.qkv_w), M, 3 * E, E, MIVIT_ACT_NONE, nullptr, 0, at(ws, w.dxb),
+            RC(lin_dgrad(dt, at(ws, w.dqkv), 3 * E, WT(lp.qkv_w), M, 3 * E, E, MIVIT_ACT_NONE, nullptr, 0, dz1,
                          E, at(ws, w.dxa), E, 0, s));                                             // dxa = d(x_in)
         } else {
             // ---- token assembly + embedding; dxa holds d(x0) [B,S,E] ----

@@ -16,7 +16,6 @@
 //            operand is a transposing LDS read (ds_read_b64_tr_b16) of X / DZ.  128 + 128 accumulator registers per
 //            lane hold the wave's [64 x 128] and [128 x 64] gradient blocks for the whole launch.  dh -> LDS image DH.
 //   phase 2 (wave w owns input features 32w .. 32w+31): dx1^T = W1^T dh^T + dz2^T from an LDS image of W1^T.
-// dW1 is taken against n1; the caller corrects it with launch_affine_fixup (dW1 * gamma1 + db1 beta1^T).
 // Per-workgroup partial gradients go to slabs; a deterministic slab reduction finishes them (no atomics).
 #include "common.h"
 #include "stream_prims.h"
@@ -31,12 +30,12 @@ constexpr int E = 128, F = 256;
 constexpr int NW = 4, NT = NW * 64, R = 32;          // waves per workgroup, threads, rows per tile
 constexpr int LDE = E + 16, LDF = F + 16;            // LDS row pitches (elements): conflict-free b128 and transposing reads
 
-constexpr int OFF_W1T = 0;                           // [E][LDF]  W1^T: row = input feature k, contraction index n contiguous
-constexpr int OFF_X = OFF_W1T + E * LDF * 2;         // [R][LDE]  n1 rows
+constexpr int OFF_W1 = 0;                            // [F][LDE]  W1 as stored ([hidden unit][input feature]): serves u (plain reads) and dx1 (transposing reads)
+constexpr int OFF_X = OFF_W1 + F * LDE * 2;          // [R][LDE]  x1 = gamma1 * n1 + beta1 rows
 constexpr int OFF_DZ = OFF_X + R * LDE * 2;          // [R][LDE]  dz2 rows
-constexpr int OFF_DH = OFF_DZ + R * LDE * 2;         // [R][LDF]  dh rows
-constexpr int OFF_VEC = OFF_DH + R * LDF * 2;        // b1' [F] fp32
-constexpr int OFF_ACC = OFF_VEC + F * 4;             // [6][NT] float4: running column sums of the element-wise phase (dgamma2, dbeta2, db2)
+constexpr int OFF_DH = OFF_DZ + R * LDE * 2;         // [R][LDF]  dh rows, hidden index permuted inside each block of 32 (see phase 2)
+constexpr int OFF_VEC = OFF_DH + R * LDF * 2;        // b1 [F], gamma2 [E], gamma1 [E], beta1 [E] fp32
+constexpr int OFF_ACC = OFF_VEC + (F + 3 * E) * 4;               // [6][NT] float4: running column sums of the element-wise phase (dgamma2, dbeta2, db2)
 constexpr int OFF_STG = OFF_ACC + 6 * NT * 16;        // [6][NW][64] x 16 B: next tile's dy / n2 / n1 chunks, landed by LDS-DMA (thread-private slots)
 constexpr int LDS_BYTES = OFF_STG + 6 * NT * 16;
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
@@ -76,7 +75,7 @@ __device__ __forceinline__ void unpack8(const uint4 &u, float (&v)[8]) {
 template <int ACT>
 __global__ __launch_bounds__(NT) void mlp_block_bwd_kernel(const MlpBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    bf16 *W1T = reinterpret_cast<bf16 *>(smem + OFF_W1T);
+    bf16 *W1i = reinterpret_cast<bf16 *>(smem + OFF_W1);
     bf16 *X = reinterpret_cast<bf16 *>(smem + OFF_X), *DZ = reinterpret_cast<bf16 *>(smem + OFF_DZ), *DH = reinterpret_cast<bf16 *>(smem + OFF_DH);
     float *b1f = reinterpret_cast<float *>(smem + OFF_VEC);
     f32x4 *cacc = reinterpret_cast<f32x4 *>(smem + OFF_ACC);
@@ -85,40 +84,20 @@ __global__ __launch_bounds__(NT) void mlp_block_bwd_kernel(const MlpBwdArgs a) {
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 
     // ---- one-time staging ----
-    // W1^T image: W1T[k][n] = W1[n][k]
     for (int i = tid; i < F * (E / 8); i += NT) {
-        const int n = i / (E / 8), c = i - n * (E / 8);
-        const uint4 v = *reinterpret_cast<const uint4 *>(a.W1 + (int64_t)n * E + c * 8);
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int e = 0; e < 8; ++e) W1T[(c * 8 + e) * LDF + n].v = (uint16_t)((e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xffffu));
+        const int n = i / (E / 8), cc = i - n * (E / 8);
+        *reinterpret_cast<uint4 *>(W1i + n * LDE + cc * 8) = *reinterpret_cast<const uint4 *>(a.W1 + (int64_t)n * E + cc * 8);
     }
-    // b1' = b1 + W1 beta1
-    for (int n = tid; n < F; n += NT) {
-        float acc = a.b1[n];
-        for (int c = 0; c < E / 8; ++c) {
-            float v[8];
-            load16(a.W1 + (int64_t)n * E + c * 8, v);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) acc += v[e] * a.beta1[c * 8 + e];
-        }
-        b1f[n] = acc;
-    }
-    // register-resident operands of this wave's hidden units n = 64 wave + 16 nt + cq:
-    //   w1f[nt][ks]: W1'[n][32ks + 8g .. +7]          (column operand of u = n1 W1'^T)
+    for (int n = tid; n < F; n += NT) b1f[n] = a.b1[n];
+    for (int i = tid; i < E; i += NT) { b1f[F + i] = a.gamma2[i]; b1f[F + E + i] = a.gamma1[i]; b1f[F + 2 * E + i] = a.beta1[i]; }
+    // register-resident operand of this wave's hidden units n = 64 wave + 16 nt + cq:
     //   w2f[nt][ks]: W2[32ks + 8g .. +7][n]           (column operand of dh = dz2 W2)
-    bf16x8 w1f[4][4], w2f[4][4];
+    bf16x8 w2f[4][4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
         const int n = 64 * wave + 16 * nt + cq;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            float v[8];
-            load16(a.W1 + (int64_t)n * E + ks * 32 + 8 * g, v);
-            f32x4 lo, hi;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { lo[e] = v[e] * a.gamma1[ks * 32 + 8 * g + e]; hi[e] = v[4 + e] * a.gamma1[ks * 32 + 8 * g + 4 + e]; }
-            w1f[nt][ks] = pack8(lo, hi);
             bf16x8 t;
 #pragma unroll
             for (int e = 0; e < 8; ++e) t[e] = __builtin_bit_cast(__bf16, a.W2[(int64_t)(ks * 32 + 8 * g + e) * F + n].v);
@@ -127,9 +106,7 @@ __global__ __launch_bounds__(NT) void mlp_block_bwd_kernel(const MlpBwdArgs a) {
     }
     // this thread's slice of the element-wise phase: columns 8c .. 8c+7 of rows r0 and r0 + 16 of the tile
     const int c = tid & 15, r0 = tid >> 4;
-    float gam2[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) gam2[e] = a.gamma2[8 * c + e];
+    const float *gam2 = b1f + F + 8 * c, *gam1 = b1f + F + E + 8 * c, *bet1 = b1f + F + 2 * E + 8 * c;     // (LDS: free registers)
 #pragma unroll
     for (int i = 0; i < 6; ++i) cacc[i * NT + tid] = f32x4{0.f, 0.f, 0.f, 0.f};       // (thread-private slots: no barrier needed)
     f32x4 dW1[4][8], dW2[8][4];
@@ -157,6 +134,7 @@ __global__ __launch_bounds__(NT) void mlp_block_bwd_kernel(const MlpBwdArgs a) {
         }
     };
     if (tile < ntiles) prefetch(tile);
+    bool first = true;
     for (; tile < ntiles; tile += gridDim.x) {
         const int64_t row0 = (int64_t)tile * R;
         // ---------------- phase 0: LayerNorm backward (element-wise), images X and DZ ----------------
@@ -164,7 +142,10 @@ __global__ __launch_bounds__(NT) void mlp_block_bwd_kernel(const MlpBwdArgs a) {
             float sg[8], sb[8], sz[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) sg[e] = sb[e] = sz[e] = 0.f;
-            wait_vm<0>();
+            // the staged rows were requested one tile ago; younger than them are only the four row stores of the last
+            // phase 2 (issued by every full tile -- the one partial tile is the last of the launch)
+            if (first) wait_vm<0>(); else wait_vm<4>();
+            first = false;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 float d[8], nh[8], gdy[8];
@@ -185,7 +166,11 @@ __global__ __launch_bounds__(NT) void mlp_block_bwd_kernel(const MlpBwdArgs a) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { dz[e] = prs[i] * (gdy[e] - s1 - nh[e] * s2); sz[e] += dz[e]; }
                 store16(DZ + (r0 + 16 * i) * LDE + 8 * c, dz);
-                *reinterpret_cast<uint4 *>(X + (r0 + 16 * i) * LDE + 8 * c) = pn1;
+                float x1v[8];
+                unpack8(pn1, x1v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x1v[e] = ok ? x1v[e] * gam1[e] + bet1[e] : 0.f;
+                store16(X + (r0 + 16 * i) * LDE + 8 * c, x1v);
             }
             cacc[0 * NT + tid] += f32x4{sg[0], sg[1], sg[2], sg[3]}; cacc[1 * NT + tid] += f32x4{sg[4], sg[5], sg[6], sg[7]};
             cacc[2 * NT + tid] += f32x4{sb[0], sb[1], sb[2], sb[3]}; cacc[3 * NT + tid] += f32x4{sb[4], sb[5], sb[6], sb[7]};
@@ -195,35 +180,57 @@ __global__ __launch_bounds__(NT) void mlp_block_bwd_kernel(const MlpBwdArgs a) {
         prefetch(min(tile + (int)gridDim.x, ntiles - 1));       // next tile's rows: in flight under phases 1 and 2
         __syncthreads();
         // ---------------- phase 1: u, dh for this wave's 64 hidden units; dW1, dW2 ----------------
+        bf16x8 hB[4], dhB[4];
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {             // one 16-wide block of the wave's hidden units at a time (register budget)
-            const float bv = b1f[64 * wave + 16 * nt + cq];
-            f32x4 u[2] = {f32x4{bv, bv, bv, bv}, f32x4{bv, bv, bv, bv}}, dh[2] = {zero, zero};
+        for (int hf = 0; hf < 2; ++hf) {
+            // u and dh for 32 of the wave's 64 hidden units at a time (register budget): un-transposed products, so the
+            // accumulators (lane = hidden unit, registers = rows) are the row-contraction operands of the weight gradients
+            f32x4 u[2][2], dh[2][2];
+#pragma unroll
+            for (int n2 = 0; n2 < 2; ++n2) {
+                const float bv = b1f[64 * wave + 32 * hf + 16 * n2 + cq];
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) { u[rt][n2] = f32x4{bv, bv, bv, bv}; dh[rt][n2] = zero; }
+            }
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
                 for (int rt = 0; rt < 2; ++rt) {
-                    u[rt] = mma(lds_frag(X + (16 * rt + cq) * LDE + ks * 32 + 8 * g), w1f[nt][ks], u[rt]);
-                    dh[rt] = mma(lds_frag(DZ + (16 * rt + cq) * LDE + ks * 32 + 8 * g), w2f[nt][ks], dh[rt]);
+                    const bf16x8 xa = lds_frag(X + (16 * rt + cq) * LDE + ks * 32 + 8 * g);
+                    const bf16x8 za = lds_frag(DZ + (16 * rt + cq) * LDE + ks * 32 + 8 * g);
+#pragma unroll
+                    for (int n2 = 0; n2 < 2; ++n2) {
+                        const int nt = 2 * hf + n2;
+                        u[rt][n2] = mma(xa, lds_frag(W1i + (64 * wave + 16 * nt + cq) * LDE + ks * 32 + 8 * g), u[rt][n2]);
+                        dh[rt][n2] = mma(za, w2f[nt][ks], dh[rt][n2]);
+                    }
                 }
 #pragma unroll
-            for (int rt = 0; rt < 2; ++rt)
+            for (int n2 = 0; n2 < 2; ++n2) {
+                const int nt = 2 * hf + n2;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float uu = u[rt][j];
-                    dh[rt][j] *= act_bwd(ACT, ACT == MIVIT_ACT_GELU ? uu : act_fwd(ACT, uu));
-                    u[rt][j] = act_fwd(ACT, uu);
-                    db1[nt] += dh[rt][j];
-                    DH[(16 * rt + 4 * g + j) * LDF + 64 * wave + 16 * nt + cq] = from_f32<bf16>(dh[rt][j]);
-                }
-            const bf16x8 hB = pack8(u[0], u[1]), dhB = pack8(dh[0], dh[1]);
-            // weight gradients: the contraction runs over the 32 rows of the tile (slots 0-3 = rows 4g.., slots 4-7 = rows 16+4g..)
+                for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const bf16x8 xb = tr_pair(X + (4 * g + q) * LDE + 16 * t + 4 * pp, X + (16 + 4 * g + q) * LDE + 16 * t + 4 * pp);
-                const bf16x8 zb = tr_pair(DZ + (4 * g + q) * LDE + 16 * t + 4 * pp, DZ + (16 + 4 * g + q) * LDE + 16 * t + 4 * pp);
-                dW1[nt][t] = mma(dhB, xb, dW1[nt][t]);       // [n][k] += dh^T n1
-                dW2[t][nt] = mma(zb, hB, dW2[t][nt]);        // [e][n] += dz2^T h
+                    for (int j = 0; j < 4; ++j) {
+                        const float uu = u[rt][n2][j];
+                        dh[rt][n2][j] *= act_bwd(ACT, ACT == MIVIT_ACT_GELU ? uu : act_fwd(ACT, uu));
+                        u[rt][n2][j] = act_fwd(ACT, uu);
+                        db1[nt] += dh[rt][n2][j];
+                        DH[(16 * rt + 4 * g + j) * LDF + 64 * wave + 32 * hf + 8 * (cq >> 2) + 4 * n2 + (cq & 3)] = from_f32<bf16>(dh[rt][n2][j]);
+                    }
+                hB[nt] = pack8(u[0][n2], u[1][n2]);
+                dhB[nt] = pack8(dh[0][n2], dh[1][n2]);
+            }
+        }
+        // weight gradients: the contraction runs over the 32 rows of the tile (slots 0-3 = rows 4g.., slots 4-7 = rows 16+4g..)
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const bf16x8 xb = tr_pair(X + (4 * g + q) * LDE + 16 * t + 4 * pp, X + (16 + 4 * g + q) * LDE + 16 * t + 4 * pp);
+            const bf16x8 zb = tr_pair(DZ + (4 * g + q) * LDE + 16 * t + 4 * pp, DZ + (16 + 4 * g + q) * LDE + 16 * t + 4 * pp);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                dW1[nt][t] = mma(dhB[nt], xb, dW1[nt][t]);       // [n][k] += dh^T n1
+                dW2[t][nt] = mma(zb, hB[nt], dW2[t][nt]);        // [e][n] += dz2^T h
             }
         }
         __syncthreads();
@@ -233,12 +240,15 @@ __global__ __launch_bounds__(NT) void mlp_block_bwd_kernel(const MlpBwdArgs a) {
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) dx[kt][rt] = zero;
+        // A = W1^T read transposed out of the W1 image: k-slots 0-3 = hidden units 32ks + 4g + {0..3}, slots 4-7 = 32ks + 16 + 4g + {0..3};
+        // the DH image stores hidden unit 32b + 16hi + 4gg + j at position 32b + 8gg + 4hi + j, so its plain 16-byte read matches
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
             const bf16x8 d0 = lds_frag(DH + cq * LDF + ks * 32 + 8 * g), d1 = lds_frag(DH + (16 + cq) * LDF + ks * 32 + 8 * g);
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt) {
-                const bf16x8 wa = lds_frag(W1T + (32 * wave + 16 * kt + cq) * LDF + ks * 32 + 8 * g);
+                const bf16x8 wa = tr_pair(W1i + (32 * ks + 4 * g + q) * LDE + 32 * wave + 16 * kt + 4 * pp,
+                                          W1i + (32 * ks + 16 + 4 * g + q) * LDE + 32 * wave + 16 * kt + 4 * pp);
                 dx[kt][0] = mma(wa, d0, dx[kt][0]);
                 dx[kt][1] = mma(wa, d1, dx[kt][1]);
             }
@@ -294,7 +304,7 @@ int grid_for(int M) { return std::min(256, ceil_div(M, R)); }
 
 size_t mlp_block_bwd_ws_bytes(int M) { return align_up((size_t)grid_for(std::max(M, 1)) * SL_TOTAL * sizeof(float), 256); }
 
-// dW1 [F,E] (taken against n1: the caller applies launch_affine_fixup), db1 [F], dW2 [E,F], db2 [E], dgamma2, dbeta2 [E]: overwritten
+// dW1 [F,E], db1 [F], dW2 [E,F], db2 [E], dgamma2, dbeta2 [E]: overwritten
 int launch_mlp_block_bwd(const void *dy, const void *n2, const float *rstd2, const float *gamma2, const void *n1,
                          const float *gamma1, const float *beta1, const void *W1, const float *b1, const void *W2, int M, int act,
                          void *dx1, float *dW1, float *db1, float *dW2, float *db2, float *dgamma2, float *dbeta2, void *ws,
@@ -339,7 +349,6 @@ extern "C" int mivit_mlp_block_bwd(const void *dy, const void *n2, const float *
                                    float *dgamma2, float *dbeta2, void *workspace, size_t workspace_bytes, void *stream) {
     prof_set_tag(MIVIT_PROF_OP);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    RC(launch_mlp_block_bwd(dy, n2, rstd2, gamma2, n1, gamma1, beta1, W1_bf16, b1, W2_bf16, M, act, dx1, dW1, db1, dW2, db2, dgamma2,
-                            dbeta2, workspace, workspace_bytes, s));
-    return launch_affine_fixup(dW1, db1, gamma1, beta1, F, E, s);       // operator level: dW1 comes back against x1, as autograd's
+    return launch_mlp_block_bwd(dy, n2, rstd2, gamma2, n1, gamma1, beta1, W1_bf16, b1, W2_bf16, M, act, dx1, dW1, db1, dW2, db2, dgamma2,
+                                dbeta2, workspace, workspace_bytes, s);
 }

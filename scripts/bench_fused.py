@@ -48,7 +48,10 @@ cases = {
                                       8 * U, M * 4 * E * FH),
 }
 if hasattr(ops, "mlp_block_bwd"):
-    pass
+    dy = rn(M, E).bfloat16()
+    rstd = 1 + 0.1 * rn(M).abs()
+    cases["mlp_block_bwd"] = (lambda: ops.mlp_block_bwd(dy, n_in.view(M, E), rstd, gi, n_in.view(M, E), gi, bi, W1, b1, W2), 4 * U,
+                              M * 10 * E * FH)
 for name, (fn, byt, fl) in cases.items():
     us = timeit(fn)
     print(f"{name:34s} {us:9.1f} us   {byt / us / 1e3:8.1f} GB/s   {fl / us / 1e6:8.1f} TFLOP/s", flush=True)

@@ -163,8 +163,7 @@ def _act_grad(act, u):
 @pytest.mark.parametrize("act", [1, 2, 3])
 def test_mlp_block_bwd(M, act):
     """Fused feed-forward backward vs the chain rule of x2 = LN2(x1 + fc2(act(fc1 x1))), x1 = gamma1 * n1 + beta1, written
-    out in fp32.  The pre-activations are taken as the kernel forms them (normalised rows times the gamma-folded bf16
-    weights): a ReLU unit whose pre-activation lies within bf16 rounding of zero would otherwise take the other branch in
+    out in fp32.  The pre-activations are taken as the kernel forms them (x1 rounded to bf16 times the bf16 weights): a ReLU unit whose pre-activation lies within bf16 rounding of zero would otherwise take the other branch in
     one of the two computations -- the function is discontinuous there."""
     from moleculardiffusion_mivit_amd import ops
     n1 = _bf(_mk((M, E), 21)).float()
@@ -174,7 +173,7 @@ def test_mlp_block_bwd(M, act):
     g2, be2 = 1.0 + 0.3 * _mk((E,), 28), 0.2 * _mk((E,), 29)
     dy = _bf(_mk((M, E), 30)).float()
     x1 = n1 * g1 + be1
-    u = F.linear(n1, _bf(W1 * g1).float(), b1 + W1 @ be1)
+    u = F.linear(_bf(x1).float(), W1, b1)          # the kernel's recompute: x1 rounded to bf16, fc1's bf16 weights
     h = ACTS[act](u)
     z2 = x1 + F.linear(h, W2, b2)
     nh, _, rstd = _ln_hat(z2)
