@@ -1,6 +1,7 @@
 // Error plumbing, small elementwise / reduction kernels and library-level C-ABI entry points.
 #include "common.h"
 #include <stdarg.h>
+#include <algorithm>
 
 static thread_local char g_err[512] = "";
 
@@ -243,7 +244,7 @@ struct GraphState {
     uint64_t replays = 0, captures = 0;
 };
 GraphState g_graph;
-constexpr size_t GRAPH_CAP = 32;
+size_t graph_cap() { static const size_t c = [] { const char *e = getenv("MIVIT_GRAPH_CAP"); return e ? (size_t)atoi(e) : (size_t)32; }(); return c; }
 
 void graph_drop(GraphEntry &e) {
     if (e.exec) (void)hipGraphExecDestroy(e.exec);
@@ -274,7 +275,7 @@ int graph_run(const uint64_t *key, int nkey, hipStream_t s, const std::function<
         return 0;
     }
     if (!hit) {                                   // first sighting: remember, run directly
-        if (g.entries.size() >= GRAPH_CAP) {
+        if (g.entries.size() >= graph_cap()) {
             size_t lru = 0;
             for (size_t i = 1; i < g.entries.size(); ++i)
                 if (g.entries[i].last_use < g.entries[lru].last_use) lru = i;
@@ -441,9 +442,29 @@ int launch_convert(int src_is_f32, const void *src, int64_t lds_, int dst_is_f32
     return 0;
 }
 
+// A kernel, not hipMemsetAsync: this runs inside stream captures, and replayed MEMSET nodes were observed to leave the
+// buffer untouched on some replays (ROCm 7.2): training trajectories drifted from step ~30 on with graphs enabled while
+// the same launches outside a graph matched the reference (tests/test_training_parity_gpu.py).
+namespace {
+__global__ __launch_bounds__(256) void fill_zero_kernel(uint4 *p16, size_t n16, unsigned char *tail, size_t ntail) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n16) p16[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (i < ntail) tail[i] = 0;
+}
+}  // namespace
 int launch_fill_zero(void *p, size_t bytes, hipStream_t s) {
     if (!bytes) return 0;
-    MIVIT_HIP(hipMemsetAsync(p, 0, bytes, s));
+    unsigned char *b = static_cast<unsigned char *>(p);
+    const size_t head = (16 - (reinterpret_cast<uintptr_t>(b) & 15)) & 15;          // bytes before the first 16-byte boundary
+    if (head >= bytes) {
+        hipLaunchKernelGGL(fill_zero_kernel, dim3(1), dim3(256), 0, s, nullptr, (size_t)0, b, bytes);
+    } else {
+        if (head) hipLaunchKernelGGL(fill_zero_kernel, dim3(1), dim3(256), 0, s, nullptr, (size_t)0, b, head);
+        const size_t n16 = (bytes - head) / 16, ntail = (bytes - head) % 16;
+        hipLaunchKernelGGL(fill_zero_kernel, dim3((unsigned)std::max<size_t>(1, (n16 + 255) / 256)), dim3(256), 0, s,
+                           reinterpret_cast<uint4 *>(b + head), n16, b + head + n16 * 16, ntail);
+    }
+    MIVIT_LAUNCH_CHECK();
     return 0;
 }
 
