@@ -339,6 +339,52 @@ def test_deepresnet_native_training_matches_torch_stack(precision, P, B, T, E):
         assert rel_err(bn.float(), br.float()) < tol_stats, k          # running_mean / running_var / num_batches_tracked
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_deepresnet_native_training_at_camera_count_scale(precision):
+    """The reference's PSFNoise loop feeds UN-normalised camera counts to DeepResNetEmbedding (background ~5000 plus a spot
+    of ~5000, Experiments/PSFNoise/trainSettingsPSFNoise.py image_props; no normalize_images call), so the first
+    convolution's raw output carries a DC level in the thousands where one bf16 ulp is 16-32.  Same gates as the O(1) test:
+    fp32 2e-4 against the PyTorch-ROCm stack, bf16 at least as accurate as PyTorch's own bf16 autocast of that stack
+    (<= 1.5x its error + 1e-2) -- forward tokens, every parameter gradient, running statistics; then eval mode."""
+    import copy
+    from moleculardiffusion_mivit_amd.helpers.models import DeepResNetEmbedding
+    P, B, T, E = 9, 6, 10, 64
+    torch.manual_seed(77)
+    ref = DeepResNetEmbedding(P, E)
+    _randomise_bn(ref, 5)
+    ref = ref.cuda().train()
+    nat, ac = copy.deepcopy(ref), copy.deepcopy(ref)
+    nat.__dict__["_mivit_precision"] = precision
+    yy, xx = torch.meshgrid(torch.arange(P, dtype=torch.float32), torch.arange(P, dtype=torch.float32), indexing="ij")
+    cen = 4.0 + 1.5 * torch.randn(B, T, 2)
+    spot = torch.exp(-((yy - cen[..., 0, None, None]) ** 2 + (xx - cen[..., 1, None, None]) ** 2) / (2 * 1.1 ** 2))
+    x = (5000.0 + 70.0 * torch.randn(B, T, P, P) + 5000.0 * spot).cuda()
+    wgt = torch.randn(B, T, E, device="cuda")
+    o_ref, g_ref = _drn_step(ref, x, wgt, native=False)
+    o_nat, g_nat = _drn_step(nat, x, wgt, native=True)
+    if precision == "fp32":
+        assert rel_err(o_nat, o_ref) < 2e-4
+        assert _worst(g_nat, g_ref) < 2e-4
+    else:
+        o_ac, g_ac = _drn_step(ac, x, wgt, native=False, autocast=True)
+        print(f"count-scale bf16: tokens {rel_err(o_nat, o_ref):.2e} (autocast {rel_err(o_ac, o_ref):.2e}), "
+              f"worst grad {_worst(g_nat, g_ref):.2e} (autocast {_worst(g_ac, g_ref):.2e})")
+        assert rel_err(o_nat, o_ref) < 1.5 * rel_err(o_ac, o_ref) + 1e-2
+        assert _worst(g_nat, g_ref) < 1.5 * _worst(g_ac, g_ref) + 1e-2
+    for (k, br), (_, bn) in zip(ref.named_buffers(), nat.named_buffers()):
+        assert rel_err(bn.float(), br.float()) < (2e-4 if precision == "fp32" else 2e-2), k
+    import os
+    ref.eval(), nat.eval()
+    with torch.no_grad():
+        os.environ["MIVIT_NO_DEEPRESNET_EVAL"] = "1"          # the yardstick: PyTorch-ROCm conv stack on the running statistics
+        try:
+            e_ref = ref(x)
+        finally:
+            os.environ.pop("MIVIT_NO_DEEPRESNET_EVAL", None)
+        e_nat = nat(x)
+    assert rel_err(e_nat, e_ref) < (1e-4 if precision == "fp32" else 3e-2)
+
+
 def test_deepresnet_native_training_two_steps_then_fused_inference():
     """Two native training steps (running statistics move), then eval(): the fused inference kernel must fold the
     UPDATED statistics (cache invalidation) and agree with the torch stack in eval mode."""
