@@ -22,6 +22,7 @@ class StagedGradReducer:
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self._comm = None
+        self._events = {}
 
     def reduce_stage(self, grads: torch.Tensor, stage: int):
         b, e = self.stage_ranges[stage]
@@ -31,7 +32,9 @@ class StagedGradReducer:
             if self._comm is None:
                 self._comm = torch.cuda.Stream(device=grads.device)
             main = torch.cuda.current_stream(grads.device)
-            ev = torch.cuda.Event()
+            ev = self._events.get(stage)
+            if ev is None:
+                ev = self._events[stage] = torch.cuda.Event()
             ev.record(main)
             self._comm.wait_event(ev)
             with torch.cuda.stream(self._comm):
@@ -81,12 +84,40 @@ def attach(model, group=None, broadcast: bool = True, sync_batchnorm=None):
 
 
 def finish_external_grads(model, group=None):
-    """Average the gradients of parameters that are not in the arena (call after loss.backward())."""
+    """Average the gradients of parameters that are not in the arena (a DeepResNet embedding's 23 tensors; call after
+    loss.backward()): ONE collective on one flat buffer, pre-scaled by 1/world, issued on the communication stream so
+    it runs beside whatever the main stream still has queued (the optimizer waits for it through the stream join)."""
     world = dist.get_world_size(group)
     if world == 1:
         return
     inside = {id(p) for p in getattr(model, "_arena_params", [])}
-    for p in model.parameters():
-        if id(p) not in inside and p.grad is not None:
-            dist.all_reduce(p.grad, group=group)
-            p.grad /= world
+    ext = [p for p in model.parameters() if id(p) not in inside and p.grad is not None]
+    if not ext:
+        return
+    dev = ext[0].grad.device
+    reducer = getattr(model, "_dp", None)
+    if dev.type == "cuda":
+        comm = reducer._comm if reducer is not None and reducer._comm is not None else torch.cuda.Stream(device=dev)
+        if reducer is not None:
+            reducer._comm = comm
+        main = torch.cuda.current_stream(dev)
+        comm.wait_stream(main)
+        with torch.cuda.stream(comm):
+            flat = torch.cat([p.grad.reshape(-1) for p in ext]).mul_(1.0 / world)
+            dist.all_reduce(flat, group=group)
+            off = 0
+            for p in ext:
+                n = p.grad.numel()
+                p.grad.copy_(flat[off:off + n].view_as(p.grad))
+                off += n
+        main.wait_stream(comm)
+        for p in ext:
+            p.grad.record_stream(comm)
+    else:
+        flat = torch.cat([p.grad.reshape(-1) for p in ext]).mul_(1.0 / world)
+        dist.all_reduce(flat, group=group)
+        off = 0
+        for p in ext:
+            n = p.grad.numel()
+            p.grad.copy_(flat[off:off + n].view_as(p.grad))
+            off += n

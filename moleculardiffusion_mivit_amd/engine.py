@@ -99,8 +99,13 @@ class MivitFunction(torch.autograd.Function):
         ws = torch.empty(plan.workspace_bytes(B, T, need_bwd), dtype=torch.uint8, device=x.device)
         out = torch.empty(B, plan.output_dim, dtype=torch.float32, device=x.device)
         plan.forward(arena, x, feats, B, T, ws, need_bwd, out)
-        ctx.owner, ctx.ws, ctx.x, ctx.feats, ctx.BT = owner, ws, x, feats, (B, T)
+        # x / features go through save_for_backward: autograd then refuses a backward after an in-place write to them.
+        # The workspace is private to this node (never visible to the caller) and is released by the first backward.
+        ctx.save_for_backward(x, feats if feats is not None else x.new_empty(0))
+        ctx.has_feats = feats is not None
+        ctx.owner, ctx.ws, ctx.BT = owner, ws, (B, T)
         ctx.arena_version = owner._arena_version
+        ctx.arena_data_version = arena._version       # bumped by optimizer.step() / any in-place parameter write
         ctx.n_params = len(params)
         ctx.need_x = ctx.needs_input_grad[1]
         ctx.need_f = feats is not None and ctx.needs_input_grad[2]
@@ -113,8 +118,16 @@ class MivitFunction(torch.autograd.Function):
         arena = owner._arena
         if ctx.arena_version != owner._arena_version:
             raise RuntimeError("model parameters were re-allocated between forward and backward")
+        if ctx.ws is None:
+            raise RuntimeError("backward through the MiViT forward a second time: its saved activations were released by the "
+                               "first backward (run the forward again; retain_graph is not supported by this node)")
+        if arena._version != ctx.arena_data_version:
+            raise RuntimeError("model parameters were modified in place (optimizer.step()?) between this forward and its "
+                               "backward: the backward kernels read the live parameters and would produce wrong gradients")
         B, T = ctx.BT
-        x, feats, ws = ctx.x, ctx.feats, ctx.ws
+        x, feats_saved = ctx.saved_tensors
+        feats = feats_saved if ctx.has_feats else None
+        ws = ctx.ws
         dp = getattr(owner, "_dp", None)            # dp.StagedGradReducer or None
         dout = dout.contiguous().float()
         if dp is not None and dp.world > 1:

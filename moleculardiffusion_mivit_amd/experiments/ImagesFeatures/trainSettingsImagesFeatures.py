@@ -3,14 +3,19 @@
 keys im_tr / im_ft_late_tr / im_ft_early_tr / im_resnet / im_ft_resnet / ft_mlp, rotation test-time augmentation
 :255-300, name-dispatched ``make_prediction`` :303-341).
 
-The 25 trajectory descriptors themselves (``helpers/helpersFeatures.compute_diffusion_features``) are a CPU
-pre-processing step outside the hot path: the model only sees a ``[B, 25]`` tensor, which the
-caller supplies."""
+The 25 trajectory descriptors (``helpers/features.compute_diffusion_features``, pinned against the reference's
+``helpers/helpersFeatures.py``) are a CPU pre-processing step outside the hot path: the model sees a
+``[B, 25]`` tensor.  ``create_video_and_feature_pairs`` / ``load_validation_data`` mirror helpersGeneration.py:674-720 and
+trainSettingsImagesFeatures.py:194-231."""
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 import torch.optim as optim
 
+import numpy as np
+
+from ...helpers import features as ft
+from ...helpers import generation as gen
 from ...helpers.models import *            # noqa: F401,F403
 from ...helpers.models import DeepResNetEmbedding, GeneralTransformer, MLPHead, MultiImageFeatureResNet, MultiImageResNet
 from .. import _common as C
@@ -46,6 +51,10 @@ N_features = 25                            # helpers/helpersFeatures.py:34
 background_mean, background_sigma = C.BACKGROUND_MEAN, C.BACKGROUND_SIGMA
 part_mean, part_std = C.PART_MEAN, C.PART_STD
 image_props = C.real_data_image_props(patch_size)
+
+localization_uncertainty = (0, 0)
+val_d_in_order = np.arange(0.1, 10.01, 0.1)
+N_in_order = 10
 
 im_resnet, im_ft_resnet = "im_resnet", "im_ft_resnet"
 ft_mlp = "ft_mlp"
@@ -113,3 +122,42 @@ def make_prediction(model, name, images, features, trajectories=None, msd_mult_f
     with torch.no_grad():
         feats = features if "ft" in name else None
         return predict_with_rotations(model, images, feats) if rot else model(images, feats)
+
+
+def create_video_and_feature_pairs(trajectories, nPosPerFrame, center, image_props, localization_uncertainty=(0, 0), dt=1.0,
+                                   generator=None):
+    """(N, T, 2) trajectories -> (normalised videos [N, nFrames, P, P], features [N, 25], (trajectories, frame-averaged,
+    frame-averaged + localisation error)) -- helpersGeneration.py:674-720."""
+    traj = np.asarray(trajectories, dtype=np.float32)
+    bg_mean, bg_sigma = image_props["background_intensity"]
+    pm = image_props["particle_intensity"][0]
+    vid = gen.trajectories_to_video(torch.as_tensor(traj), nPosPerFrame, center=center, image_props=image_props, generator=generator)
+    vid = gen.normalize_images(vid, bg_mean, bg_sigma, pm + bg_mean)[0]
+    seed = int(torch.randint(0, 2 ** 31 - 1, (1,), generator=generator)) if generator is not None else None
+    feats, avg, noisy = ft.compute_features_for_trajectories(traj, nPosPerFrame, dt=dt, localization_uncertainty=localization_uncertainty,
+                                                             rng=np.random.default_rng(seed))
+    return np.asarray(vid, dtype=np.float32), feats.astype(np.float32), (traj, avg, noisy)
+
+
+def load_validation_data(length=20, skip_inorder=False, generator=None, n_synthetic=50):
+    """((videos, features, trajectory triple) for D = 1, 3, 5, 7, 9, and the in-order set) -- reference :194-231.  Uses the
+    reference's validation_trajectories/*.npy when present (MIVIT_VALIDATION_ROOT), seeded Brownian sets otherwise."""
+    g = generator or torch.Generator().manual_seed(20250815)
+    sets, tio = C.validation_trajectories(length, T, traj_div_factor, g, n_synthetic,
+                                          None if skip_inorder else (val_d_in_order, N_in_order))
+    out = []
+    for tr in sets:
+        v, f, t = create_video_and_feature_pairs(tr, nPosPerFrame, center, image_props, localization_uncertainty, dt, g)
+        out.append((torch.Tensor(v), torch.Tensor(f), t))
+    if skip_inorder:
+        out.append((torch.zeros(1), torch.zeros(1), np.zeros(1)))
+    else:
+        v, f, t = create_video_and_feature_pairs(tio, nPosPerFrame, center, image_props, localization_uncertainty, dt, g)
+        out.append((torch.Tensor(v).reshape(len(val_d_in_order), N_in_order, nFrames, patch_size, patch_size),
+                    torch.Tensor(f).reshape(len(val_d_in_order), N_in_order, N_features), t))
+    return tuple(out)
+
+
+def make_prediction_tuple(model, name, vid_ft_trajs, eval=True):
+    """make_prediction on a (videos, features, trajectories) triple (reference trainSettingsImagesFeatures.py:343-345)."""
+    return make_prediction(model, name, vid_ft_trajs[0], vid_ft_trajs[1], vid_ft_trajs[2], eval=eval)

@@ -152,10 +152,17 @@ def select_models_from_noise(models, wanted_noise_index, wanted_prefix=None):
 
 
 def trajs_to_vid_psf_noise(trajectories, nPosPerFrame, center=False, image_props={}, PSF_Settings=[], Noise_Settings=[],
-                           generator=None, device="cpu"):
+                           generator=None, device="cpu", reference_chain=True):
     """(N, T, 2) trajectories -> (N, N_PSF, N_Noise, nFrames, P, P) float32: one noise-free rendering per PSF width
     (sigma / PSF_Settings[i]), one frame intensity ~ N(part_mean, part_std) shared by its sub-positions, then per
-    noise level a clipped-Gaussian background (std = part_mean * level) and Poisson(frame * pn) / pn."""
+    noise level a clipped-Gaussian background (std = part_mean * level) and Poisson(frame * pn) / pn.
+
+    ``reference_chain=True`` (default) reproduces the reference's loop exactly (trainSettingsPSFNoise.py:296-306): the
+    level-0 result Poisson(clean + background) OVERWRITES out[psf, 0, f], and every level j >= 1 is then built on that
+    already-noised frame -- background added twice (~2 * bm), Poisson applied twice.  That is the input distribution the
+    reference's checkpoints and published validation losses were produced on.  ``reference_chain=False`` builds every
+    level from the clean frame (one background, one Poisson draw): the cleaner camera model, NOT comparable with the
+    reference's numbers."""
     if len(PSF_Settings) == 0 or len(Noise_Settings) == 0:
         raise Exception("No settings given")
     props = dict(gen.DEFAULT_IMAGE_PROPS)
@@ -178,7 +185,11 @@ def trajs_to_vid_psf_noise(trajectories, nPosPerFrame, center=False, image_props
                               props["upsampling_factor"], amp, center)           # (N, N_PSF, F, P, P)
     pn = props["poisson_noise"]
     out = torch.empty(N, len(PSF_Settings), len(Noise_Settings), F_, props["output_size"], props["output_size"])
+    base = clean
     for j, level in enumerate(Noise_Settings):
-        noisy = clean + gen.clipped_background(clean.shape, bm, part_mean * level, generator, traj.device)
-        out[:, :, j] = (torch.poisson((noisy * pn).clamp_min(0), generator=generator) / pn).cpu()
+        noisy = base + gen.clipped_background(clean.shape, bm, part_mean * level, generator, traj.device)
+        frame = torch.poisson((noisy * pn).clamp_min(0), generator=generator) / pn
+        out[:, :, j] = frame.cpu()
+        if reference_chain and j == 0:
+            base = frame                              # the reference reads out_video[psf, 0, f] back for the later levels
     return out.numpy()

@@ -58,6 +58,11 @@ CASES = {
                       use_global_features=True, fusion_type="early", global_feature_dim=25), 4, 32, False, True, 0),
     "c5_late": (dict(embedding="linear", patch_size=16, embed_dim=128, num_heads=4, hidden_dim=256, num_layers=2,
                      use_global_features=True, fusion_type="late", global_feature_dim=25), 4, 32, False, True, 0),
+    # cfg 5 at the BASELINE shape (c1 + 25 features): 64 x 64 frames, dim 128, depth 4
+    "c5_real_early": (dict(embedding="linear", patch_size=64, embed_dim=128, num_heads=4, hidden_dim=256, num_layers=4,
+                           use_global_features=True, fusion_type="early", global_feature_dim=25), 4, 32, False, True, 0),
+    "c5_real_late": (dict(embedding="linear", patch_size=64, embed_dim=128, num_heads=4, hidden_dim=256, num_layers=4,
+                          use_global_features=True, fusion_type="late", global_feature_dim=25), 4, 32, False, True, 0),
     # constructor corners: mean-pool readout, pos-enc, other activations, small/large Embeddings variants
     "meanpool_posenc_leaky": (dict(embedding="linear", patch_size=9, embed_dim=32, num_heads=2, hidden_dim=64,
                                    num_layers=3, use_regression_token=False, use_pos_encoding=True,

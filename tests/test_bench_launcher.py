@@ -31,3 +31,34 @@ def test_bench_launcher_propagates_failure():
     # a world size that contradicts --gpus is an error in every rank -> non-zero exit from the parent
     r = _run(["--gpus", "2"], {"MIVIT_BENCH_DRY": "1", "WORLD_SIZE": "3", "RANK": "0"})
     assert r.returncode != 0
+
+
+import pytest
+
+
+def _bench_json(args, env):
+    r = _run(args, env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1500:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_share_one_gpu_over_gloo():
+    """The whole multi-rank path of bench.py on the one-GPU box: self-launch, rendezvous, per-stage gradient all-reduce on
+    the side stream, max-over-ranks timing -- two ranks on cuda:0, gloo instead of RCCL (RCCL refuses two ranks per device)."""
+    out = _bench_json(["--gpus", "2", "--steps", "3", "--warmup", "2", "--batch-per-gpu", "512", "--no-cpu-baseline"],
+                      {"MIVIT_BENCH_SHARE_GPU": "1", "MIVIT_DIST_BACKEND": "gloo"})
+    assert out["n_gpus"] == 2 and out["dist_backend"] == "gloo" and out["scaling"] == "weak"
+    assert out["config"]["global_batch"] == 1024 and out["value"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_rccl():
+    """RCCL (backend "nccl") over xGMI: needs two GPUs, so it runs on the driver's multi-GPU node and is skipped on a one-GPU box."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    out = _bench_json(["--gpus", "2", "--steps", "3", "--warmup", "2", "--batch-per-gpu", "1024", "--no-cpu-baseline"], {})
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["dist_backend"] == "nccl" and out["value"] > 0

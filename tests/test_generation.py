@@ -111,6 +111,15 @@ def test_psfnoise_settings_surface():
     assert v[:, 0, 0].sum() < v[:, 4, 0].sum()
     # noise grows with the noise index
     assert v[:, 2, 5].std() > v[:, 2, 0].std()
+    # the reference's chain (trainSettingsPSFNoise.py:296-306): level 0 = Poisson(clean + bm) overwrites out[psf, 0, f] and the
+    # later levels are built ON it, so their background is ~2 * bm; the clean-frame variant has ~bm at every level
+    bm = S.image_props["background_intensity"][0]
+    corner = lambda a, j: float(a[:, :, j, :, 0, 0].mean())           # noqa: E731  (a pixel far from the spot)
+    assert abs(corner(v, 0) - bm) < 0.1 * bm and abs(corner(v, 2) - 2 * bm) < 0.15 * bm
+    v1 = S.trajs_to_vid_psf_noise(tr.permute(1, 0, 2).numpy() / S.traj_div_factor, S.nPosPerFrame, center=S.center,
+                                  image_props=S.image_props, PSF_Settings=S.PSF_Settings, Noise_Settings=S.Noise_Settings,
+                                  generator=torch.Generator().manual_seed(1), reference_chain=False)
+    assert abs(corner(v1, 0) - bm) < 0.1 * bm and abs(corner(v1, 2) - bm) < 0.15 * bm
 
 
 def test_other_experiment_settings_surfaces():

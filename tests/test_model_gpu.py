@@ -539,3 +539,26 @@ def test_hipgraph_not_replayed_across_plans():
             ref = build_product_model(cfg, prec, params).eval()(x)
             assert torch.equal(o, ref), prec
     assert float((o32 - ref).abs().max()) < 5e-2
+
+
+def test_autograd_node_refuses_second_backward_and_stale_parameters():
+    """The forward's activations live in a private workspace released by the first backward, and the backward kernels read the
+    LIVE parameter arena: a second backward, or an optimizer step between a forward and its backward, must raise instead of
+    returning wrong gradients (stock autograd raises in both situations)."""
+    cfg = orc.MiViTConfig(embedding="linear", patch_size=9, embed_dim=64, num_heads=4, hidden_dim=128, num_layers=2)
+    m = build_product_model(cfg, "fp32", orc.closed_form_params(cfg), device="cuda")
+    x, y, _ = orc.closed_form_batch(3, 10, 9)
+    loss = F.mse_loss(m(x.cuda()), y.cuda())
+    loss.backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="second time"):
+        loss.backward()
+    opt = torch.optim.SGD(m.parameters(), lr=1e-3)
+    loss = F.mse_loss(m(x.cuda()), y.cuda())
+    opt.step()                                       # parameters change under the recorded forward
+    with pytest.raises(RuntimeError, match="modified in place"):
+        loss.backward()
+    xin = x.cuda().clone().requires_grad_(False)
+    loss = F.mse_loss(m(xin), y.cuda())
+    xin.add_(1.0)                                    # the saved input changes under the recorded forward
+    with pytest.raises(RuntimeError):
+        loss.backward()

@@ -76,3 +76,55 @@ def test_reduced_psfnoise_run_fp16_with_loss_scaling(tmp_path):
     assert np.isfinite(vlosses["tr_1_0"]["val_avg"]).all()
     for p in models["tr_1_0"].parameters():
         assert p.dtype == torch.float32 and bool(torch.isfinite(p).all())
+
+
+def test_reduced_imagesfeatures_run(tmp_path):
+    """BASELINE config 5's loop API (reference Experiments/ImagesFeatures/trainModelsImagesFeatures.py:112-255): every model of the
+    zoo trains on the same (video, 25-feature) minibatches with the reference's name dispatch, validation per D, checkpoint
+    training_results_ten*.pth with the save_results schema; early / late fusion go through the HIP engine."""
+    from moleculardiffusion_mivit_amd.experiments.ImagesFeatures import trainModelsImagesFeatures as TM
+    from moleculardiffusion_mivit_amd.experiments.ImagesFeatures import trainSettingsImagesFeatures as S
+    models, vlosses, labels = TM.run_training(num_cycles=2, N=4, seed=3, out_dir=str(tmp_path))
+    assert sorted(models) == sorted([S.im_tr, S.im_ft_late_tr, S.im_ft_early_tr, S.im_resnet, S.im_ft_resnet, S.ft_mlp])
+    for n in models:
+        assert set(vlosses[n]) == {"val_1.0", "val_3.0", "val_5.0", "val_7.0", "val_9.0", "val_avg"}
+        assert len(vlosses[n]["val_avg"]) == 2 and np.isfinite(vlosses[n]["val_avg"]).all(), n
+    assert labels.shape == (2 * 5 * 4,)
+    ck = torch.load(tmp_path / "training_results_ten.pth", weights_only=False)
+    assert set(ck) == {"validation_losses", "all_labels", "model_weights"} and (tmp_path / "training_results_ten1.pth").exists()
+    fresh, _, _ = S.getTrainingModels()
+    for n, m in fresh.items():
+        m.load_state_dict(ck["model_weights"][n])
+    vals = S.load_validation_data(S.nFrames, skip_inorder=True, generator=torch.Generator().manual_seed(5), n_synthetic=3)
+    a = S.make_prediction_tuple(models[S.im_ft_early_tr], S.im_ft_early_tr, vals[0])
+    b = S.make_prediction_tuple(fresh[S.im_ft_early_tr].cuda(), S.im_ft_early_tr, vals[0])
+    assert a.shape == (3, 1) and torch.equal(a, b)
+
+
+@pytest.mark.parametrize("fusion", ["early", "late"])
+def test_config5_fp16_with_loss_scaling_at_the_baseline_shape(fusion):
+    """BASELINE config 5: image sequence + 25-feature vector, fp16 compute under dynamic loss scaling (init 2**16, x2 / 2000
+    good steps, /2 and skip on inf), at the real shape (32 x 64 x 64, dim 128, depth 4): the first scaled backward
+    overflows fp16, the scaler skips that step and backs off, then the loss falls; weights and their gradients stay fp32."""
+    import torch.nn.functional as F
+    from oracle import mivit_oracle as orc
+    from util import build_product_model, golden_inputs, load_golden
+    from moleculardiffusion_mivit_amd.experiments._common import backward_and_step, make_scaler
+    fx, meta, cfg = load_golden(f"c5_real_{fusion}")
+    params, x, labels, feats = golden_inputs(meta, cfg)
+    m = build_product_model(cfg, "fp16", params, device="cuda").train()
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-4)
+    scaler = make_scaler(m)
+    assert scaler is not None and scaler.get_scale() == 2.0 ** 16
+    x, labels, feats = x.cuda(), labels.cuda(), feats.cuda()
+    losses, scales = [], []
+    for _ in range(12):
+        opt.zero_grad()
+        loss = F.mse_loss(m(x, feats), labels)
+        backward_and_step(loss, opt, scaler, m)
+        losses.append(float(loss))
+        scales.append(scaler.get_scale())
+    assert abs(losses[0] - float(fx["loss"])) / float(fx["loss"]) < 1e-2          # fp16 forward vs the reference's loss
+    assert scales[-1] <= scales[0] and losses[-1] < losses[0]
+    for p in m.parameters():
+        assert p.dtype == torch.float32 and bool(torch.isfinite(p).all())
