@@ -105,7 +105,8 @@ class MivitFunction(torch.autograd.Function):
         ctx.has_feats = feats is not None
         ctx.owner, ctx.ws, ctx.BT = owner, ws, (B, T)
         ctx.arena_version = owner._arena_version
-        ctx.arena_data_version = arena._version       # bumped by optimizer.step() / any in-place parameter write
+        # every in-place write to a parameter (optimizer.step(), load_state_dict, ...) bumps that parameter's version
+        ctx.arena_data_version = sum(p._version for p in owner._arena_params)
         ctx.n_params = len(params)
         ctx.need_x = ctx.needs_input_grad[1]
         ctx.need_f = feats is not None and ctx.needs_input_grad[2]
@@ -121,7 +122,7 @@ class MivitFunction(torch.autograd.Function):
         if ctx.ws is None:
             raise RuntimeError("backward through the MiViT forward a second time: its saved activations were released by the "
                                "first backward (run the forward again; retain_graph is not supported by this node)")
-        if arena._version != ctx.arena_data_version:
+        if sum(p._version for p in owner._arena_params) != ctx.arena_data_version:
             raise RuntimeError("model parameters were modified in place (optimizer.step()?) between this forward and its "
                                "backward: the backward kernels read the live parameters and would produce wrong gradients")
         B, T = ctx.BT
