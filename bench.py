@@ -109,6 +109,7 @@ def main():
     ap.add_argument("--precision", default=os.environ.get("MIVIT_BENCH_PRECISION", "bf16"), choices=["bf16", "fp32"])
     ap.add_argument("--resident-batches", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the B=4096 / fp32-parity-mode / trained-val side runs")
     ap.add_argument("--breakdown", action="store_true", help="print the per-kernel-category time table to stderr")
     args = ap.parse_args()
 
@@ -154,32 +155,49 @@ def main():
 
     T, P, E, H, Fh, L = (CFG["frames"], CFG["patch_size"], CFG["embed_dim"], CFG["num_heads"], CFG["hidden_dim"],
                          CFG["num_layers"])
-    torch.manual_seed(0)
-    model = GeneralTransformer(LinearProjectionEmbedding, {"patch_size": P, "embed_dim": E}, E, H, Fh, L, MLPHead,
-                               F.relu, dropout=0.0, use_pos_encoding=False, use_regression_token=True,
-                               precision=args.precision).to(dev)
-    model.train()
-    if world > 1:
-        dp.attach(model)
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, fused=True)
-    Bg = args.batch_per_gpu
-    data = [synth(Bg, T, P, 1234 + rank + 1000 * i, dev) for i in range(args.resident_batches)]
     loss_fn = torch.nn.MSELoss()
 
-    def step(i):
-        x, y = data[i % len(data)]
-        opt.zero_grad(set_to_none=True)
-        loss = loss_fn(model(x), y)
-        loss.backward()
-        opt.step()
-        return loss
+    def build(precision, lr=1e-4, seed=0):
+        torch.manual_seed(seed)
+        m = GeneralTransformer(LinearProjectionEmbedding, {"patch_size": P, "embed_dim": E}, E, H, Fh, L, MLPHead,
+                               F.relu, dropout=0.0, use_pos_encoding=False, use_regression_token=True,
+                               precision=precision).to(dev)
+        m.train()
+        if world > 1:
+            dp.attach(m)
+        return m, torch.optim.AdamW(m.parameters(), lr=lr, fused=True)
+
+    def make_step(m, opt, data):
+        def step(i):
+            x, y = data[i % len(data)]
+            opt.zero_grad(set_to_none=True)
+            loss = loss_fn(m(x), y)
+            loss.backward()
+            opt.step()
+            return loss
+        return step
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- warmup; the last warmup steps time every kernel category to find the dominant one ----
+    def timed(step, steps, warmup):
+        for i in range(warmup):
+            step(i)
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(i)
+        barrier()
+        return time.perf_counter() - t0
+
+    model, opt = build(args.precision)
+    Bg = args.batch_per_gpu
+    data = [synth(Bg, T, P, 1234 + rank + 1000 * i, dev) for i in range(args.resident_batches)]
+    step = make_step(model, opt, data)
+
+    # ---- warmup; the last warmup steps time every kernel category ----
     nprof = min(2, args.warmup)
     for i in range(args.warmup - nprof):
         step(i)
@@ -193,13 +211,15 @@ def main():
         ms, cnt = ctypes.c_double(), ctypes.c_int()
         N.lib.mivit_profile_collect(t, ctypes.byref(ms), ctypes.byref(cnt))
         cat[name] = (ms.value / max(nprof, 1), cnt.value // max(nprof, 1))
-    dominant = max(("embed_fwd", "embed_wgrad", "linear_fwd", "linear_dgrad", "linear_wgrad", "attn_fwd", "attn_bwd"),
-                   key=lambda k: cat[k][0] / max(cat[k][1], 1)) if nprof else "embed_fwd"
+    # the kernel that owns the roofline entry: the single launch with the most time per step among the HBM-streaming ones
+    # (the frame-embedding forward); the encoder-layer family, which owns the largest SHARE of the step, gets `roofline_layers`
+    dominant = "embed_fwd"
     if args.breakdown and rank == 0:
         tot = sum(v[0] for v in cat.values())
         for k, (ms, c) in sorted(cat.items(), key=lambda kv: -kv[1][0]):
             print(f"  {k:14s} {ms:9.3f} ms/step  {c:4d} launches/step  {100 * ms / max(tot, 1e-9):5.1f}%", file=sys.stderr)
     dom_tag = N.PROF_TAGS.index(dominant)
+    layer_tags = ("linear_fwd", "linear_dgrad", "linear_wgrad", "attn_fwd", "attn_bwd", "ln_fwd", "ln_bwd")
     N.lib.mivit_profile_enable(ctypes.c_uint64(1 << dom_tag))
 
     # ---- timed region: EXACTLY --steps steps ----
@@ -217,54 +237,91 @@ def main():
     N.lib.mivit_profile_collect(dom_tag, ctypes.byref(ms), ctypes.byref(cnt))
     N.lib.mivit_profile_enable(ctypes.c_uint64(0))
 
-    # ---- val MSE(D) on a held-out synthetic shard (pred * 10 vs D; trainModelsPSFNoise.py:224-229) ----
+    # ---- val MSE(D) of the (untrained, K-step) benchmark model on a held-out synthetic shard ----
     model.eval()
     with torch.no_grad():
         xv, yv = synth(min(Bg, 1024), T, P, 99991 + rank, dev)
         val_mse = float(F.mse_loss(model(xv) * 10.0, yv * 10.0))
+    del model, opt, data, step
+    torch.cuda.empty_cache()
+
+    extras = {}
+    if world == 1 and not args.no_extras:
+        # (1) the SURVEY 8d batch point 4096 and the fp32 parity mode (v_mfma_f32_16x16x4_f32 kernels), short runs
+        for tag, prec, bsz in (("batch_4096", args.precision, 4096), ("fp32_parity_mode", "fp32", 2048)):
+            m2, o2 = build(prec)
+            d2 = [synth(bsz, T, P, 777 + i, dev) for i in range(2)]
+            t2 = timed(make_step(m2, o2, d2), 8, 3)
+            extras[tag] = {"sequences_per_s": round(8 * bsz / t2, 1), "ms_per_step": round(1e3 * t2 / 8, 4), "per_gpu_batch": bsz,
+                           "dtype": prec}
+            del m2, o2, d2
+            torch.cuda.empty_cache()
+        # (2) a TRAINED validation MSE(D): fixed short schedule (AdamW 1e-3, 300 steps of 1024 fresh synthetic sequences,
+        #     StepLR(5, 0.9) every 30 steps), same seed in the benchmark precision and in the fp32 parity mode
+        for tag, prec in (("val_mse_D_trained", args.precision), ("val_mse_D_trained_fp32", "fp32")):
+            m3, o3 = build(prec, lr=1e-3, seed=1)
+            sch = torch.optim.lr_scheduler.StepLR(o3, step_size=5, gamma=0.9)
+            for s_ in range(300):
+                x3, y3 = synth(1024, T, P, 50000 + s_, dev)
+                o3.zero_grad(set_to_none=True)
+                loss_fn(m3(x3), y3).backward()
+                o3.step()
+                if (s_ + 1) % 30 == 0:
+                    sch.step()
+            m3.eval()
+            with torch.no_grad():
+                xv3, yv3 = synth(4096, T, P, 99991, dev)
+                extras[tag] = round(float(F.mse_loss(m3(xv3) * 10.0, yv3 * 10.0)), 4)
+            del m3, o3
+            torch.cuda.empty_cache()
 
     if rank == 0:
         seqs = args.steps * Bg * world
         fl = flops_per_seq(T, P, E, H, Fh, L)
         k_ms = ms.value / max(cnt.value, 1)
+        ts = 2 if args.precision == "bf16" else 4
         roof = None
         if cnt.value:
-            if dominant in ("embed_fwd", "embed_wgrad"):
-                # algorithmic bytes per launch: the fp32 frames of the per-GPU batch, read once, + weight + output
-                ts = 2 if args.precision == "bf16" else 4
-                byt = Bg * T * P * P * 4 + E * P * P * 4 + Bg * T * E * ts
-                ach = byt / (k_ms * 1e-3) / 1e9
-                roof = {"kernel": dominant, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
-                        "launch_ms": round(k_ms, 4), "launches_timed": cnt.value,
-                        "algorithmic_bytes_per_launch": byt}
-            else:
-                S = T + 1
-                per = {"linear_fwd": (6 + 2) * S * E * E + 4 * S * E * Fh, "linear_dgrad": (6 + 2) * S * E * E + 4 * S * E * Fh,
-                       "linear_wgrad": (6 + 2) * S * E * E + 4 * S * E * Fh, "attn_fwd": 4 * S * S * E,
-                       "attn_bwd": 10 * S * S * E}[dominant]
-                launches_per_layer = {"linear_fwd": 4, "linear_dgrad": 4, "linear_wgrad": 4, "attn_fwd": 1, "attn_bwd": 1}[dominant]
-                fl_launch = per * Bg / launches_per_layer
-                ach = fl_launch / (k_ms * 1e-3) / 1e12
-                pk = MFMA_PEAK[args.precision]
-                roof = {"kernel": dominant, "bound": "mfma", "achieved": round(ach, 2), "peak": pk, "unit": "TFLOP/s",
-                        "frac": round(ach / pk, 4), "traffic": None, "launch_ms": round(k_ms, 4),
-                        "launches_timed": cnt.value}
-        # HBM traffic of the dominant kernel from the PMC passes committed under profiles/ (rocprofv3 cannot run
-        # inside this process): used only when it was collected for this kernel at this per-GPU batch
-        if roof is not None:
+            # algorithmic bytes per launch: the fp32 frames of the per-GPU batch, read once, + weight + output
+            byt = Bg * T * P * P * 4 + E * P * P * 4 + Bg * T * E * ts
+            ach = byt / (k_ms * 1e-3) / 1e9
+            roof = {"kernel": dominant, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                    "launch_ms": round(k_ms, 4), "launches_timed": cnt.value,
+                    "algorithmic_bytes_per_launch": byt}
+        # encoder-layer family (everything between the embedding LayerNorm and the final norm, forward + backward): HBM-bound
+        # at these widths.  Algorithmic bytes = what the launches must move given what is kept for the backward, in units of
+        # U = one [tokens, E] activation: per layer forward 8 U (attention block: x in, n1 + ctx + q|k|v out; feed-forward
+        # block: n1 in, n2 out), backward 27 U (feed-forward block 4; LayerNorm-1 3; out-proj wgrad 2 + dgrad 2; attention
+        # 7; q|k|v wgrad 4 + dgrad 5) -- see DESIGN.md section 6.
+        S = T + 1
+        U = Bg * S * E * ts
+        layer_bytes = L * 35 * U
+        layer_ms = sum(cat[k][0] for k in layer_tags)
+        roof_layers = {"kernels": list(layer_tags), "bound": "hbm", "achieved": round(layer_bytes / (layer_ms * 1e-3) / 1e9, 1),
+                       "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(layer_bytes / (layer_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                       "traffic": None, "ms_per_step": round(layer_ms, 4), "algorithmic_bytes_per_step": layer_bytes,
+                       "share_of_step": round(layer_ms / (1e3 * dt / args.steps), 3)} if layer_ms > 0 else None
+        # HBM traffic from the PMC passes committed under profiles/ (rocprofv3 cannot run inside this process): used only
+        # when it was collected at this per-GPU batch
+        for fname in ("r02_pmc.json", "r01_pmc_embed.json"):
             try:
-                with open(os.path.join(ROOT, "profiles", "r01_pmc_embed.json")) as fh:
+                with open(os.path.join(ROOT, "profiles", fname)) as fh:
                     pmc = json.load(fh)
-                if pmc.get("per_gpu_batch") == Bg and dominant in pmc["kernels"] and args.precision == "bf16":
-                    roof["traffic"] = pmc["kernels"][dominant]["hbm_bytes_per_launch"]
-                    roof["traffic_source"] = "profiles/r01_pmc_embed.json"
+                if pmc.get("per_gpu_batch") == Bg and args.precision == "bf16":
+                    if roof is not None and roof["traffic"] is None and dominant in pmc.get("kernels", {}):
+                        roof["traffic"] = pmc["kernels"][dominant]["hbm_bytes_per_launch"]
+                        roof["traffic_source"] = "profiles/" + fname
+                    if roof_layers is not None and roof_layers["traffic"] is None and "layers_hbm_bytes_per_step" in pmc:
+                        roof_layers["traffic"] = pmc["layers_hbm_bytes_per_step"]
+                        roof_layers["traffic_source"] = "profiles/" + fname
             except (OSError, ValueError, KeyError):
                 pass
         line = {
             "metric": "training image-sequences/sec", "value": round(seqs / dt, 1), "unit": "sequences/s",
             "n_gpus": world, "rccl_ranks": (dist.get_world_size() if world > 1 and backend == "nccl" else 0),
-            "dist_backend": (backend if world > 1 else None), "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
+            "dist_backend": (backend if world > 1 else None), "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision,
             "data": "synthetic",
             "config": {"workload": "PSFNoise 32-frame 64x64 sequences, MiViT depth=4 dim=128 heads=4 hidden=256, linear "
@@ -275,8 +332,10 @@ def main():
             "model_tflops": round(3 * fl["total_fwd"] * seqs / dt / 1e12, 2),
             "attn_mlp_mfma_frac": round(3 * fl["attn_mlp_fwd"] * seqs / dt / 1e12 / world / MFMA_PEAK[args.precision], 5),
             "roofline": roof,
+            "roofline_layers": roof_layers,
             "kernel_ms_per_step": {k: round(v[0], 4) for k, v in cat.items()},
         }
+        line.update(extras)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
