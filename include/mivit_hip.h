@@ -147,6 +147,16 @@ int mivit_mlp_block_bwd(const void *dy, const void *n2, const float *rstd2, cons
                         int M, int act, void *dx1, float *dW1, float *db1, float *dW2, float *db2, float *dgamma2,
                         float *dbeta2, void *workspace, size_t workspace_bytes, void *stream);
 
+/* Noise-free rendering of single-particle image sequences from trajectories (the synthetic-data step right before the hot
+ * path: helpers/helpersGeneration.py:128-319 trajectories_to_video / trajectory_to_video / gaussian_2d + block_reduce, and the
+ * per-PSF variant Experiments/PSFNoise/trainSettingsPSFNoise.py:196-309).  traj_px [N, T, 2] fp32 positions (x, y) in camera
+ * pixels; every frame integrates npos consecutive sub-positions (optionally centred on their mean), each a Gaussian of
+ * sigma sigmas[i] (fine-grid units, grid `up` times finer than the camera) whose PEAK on the fine grid is rescaled to
+ * amp[n, f, p]; the fine frame is mean-pooled up x up.  out [N, nsig, T / npos, P, P] fp32.  Background, Poisson gain and
+ * normalisation are element-wise torch ops on the caller's side (helpers/generation.py). */
+int mivit_render_frames(const float *traj_px, int N, int T, int npos, const float *sigmas, int nsig, int P, int up,
+                        const float *amp, int center, float *out, void *stream);
+
 /* DeepResNetEmbedding in inference mode (helpers/models.py:230-257; ResidualBlock :202-228): conv3x3(1->32)+BN+ReLU,
  * ResidualBlock(32->64), ResidualBlock(64->128), global average pool, Linear(128->E), fused in one kernel that keeps F
  * whole frames in LDS.  Eval-mode BatchNorm is folded by the caller: conv weights are pre-scaled by

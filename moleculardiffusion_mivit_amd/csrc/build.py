@@ -10,7 +10,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 ROOT = os.path.dirname(PKG)
-SOURCES = ["gemm.hip", "norm.hip", "attention.hip", "attention_fast.hip", "embed.hip", "rowstream.hip", "wavestream.hip", "gemm_dma.hip", "wgrad_dma.hip", "wgrad_small.hip", "fused_fwd.hip", "fused_bwd.hip", "deepresnet.hip", "deepresnet_train.hip", "misc.hip", "engine.hip"]
+SOURCES = ["gemm.hip", "norm.hip", "attention.hip", "attention_fast.hip", "embed.hip", "rowstream.hip", "wavestream.hip", "gemm_dma.hip", "wgrad_dma.hip", "wgrad_small.hip", "fused_fwd.hip", "fused_bwd.hip", "render.hip", "deepresnet.hip", "deepresnet_train.hip", "misc.hip", "engine.hip"]
 HEADERS = [os.path.join(HERE, "common.h"), os.path.join(HERE, "stream_prims.h"), os.path.join(ROOT, "include", "mivit_hip.h")]
 LIB = os.path.join(PKG, "libmivit_hip.so")
 OBJDIR = os.path.join(HERE, "build")

@@ -80,6 +80,8 @@ def render_frames(traj_px: torch.Tensor, nPosPerFrame: int, sigmas: Sequence[flo
     N, T, _ = traj_px.shape
     if T % nPosPerFrame != 0:
         raise Exception("T is not divisble by posPerFrame")
+    if traj_px.device.type == "cuda":
+        return _render_frames_hip(traj_px, nPosPerFrame, sigmas, output_size, upsampling_factor, spot_intensity, center)
     F_, p, P, up = T // nPosPerFrame, nPosPerFrame, output_size, upsampling_factor
     G = P * up
     dev = traj_px.device
@@ -91,15 +93,38 @@ def render_frames(traj_px: torch.Tensor, nPosPerFrame: int, sigmas: Sequence[flo
     axis = torch.linspace(-limit, limit, G, device=dev, dtype=traj_px.dtype)
     out = []
     for s in sigmas:
-        prof = torch.exp(-((axis.view(1, 1, 1, G) - seg[..., 0:1]) ** 2) / (2 * s * s))      # x profile  (N,F,p,G)
-        profy = torch.exp(-((axis.view(1, 1, 1, G) - seg[..., 1:2]) ** 2) / (2 * s * s))     # y profile
-        prof = prof / prof.amax(dim=-1, keepdim=True).clamp_min(1e-30)    # peak normalisation (spot / spot_max)
-        profy = profy / profy.amax(dim=-1, keepdim=True).clamp_min(1e-30)
+        # spot / spot_max per axis, as ONE exponential of the difference of squared distances: the reference divides two
+        # float64 Gaussians (a spot that left the frame still peaks at full intensity on the border); fp32 factors would
+        # underflow to 0 / 0 there
+        dx2 = (axis.view(1, 1, 1, G) - seg[..., 0:1]) ** 2
+        dy2 = (axis.view(1, 1, 1, G) - seg[..., 1:2]) ** 2
+        prof = torch.exp(-(dx2 - dx2.amin(dim=-1, keepdim=True)) / (2 * s * s))       # x profile (N,F,p,G), peak-normalised
+        profy = torch.exp(-(dy2 - dy2.amin(dim=-1, keepdim=True)) / (2 * s * s))      # y profile
         px = prof.reshape(N, F_, p, P, up).mean(dim=-1)                   # mean pooling of each 1-D profile
         py = profy.reshape(N, F_, p, P, up).mean(dim=-1)
         # frame[y, x] = sum_p a_p * py_p[y] * px_p[x]
         out.append(torch.einsum("nfp,nfpy,nfpx->nfyx", spot_intensity, py, px))
     return torch.stack(out, dim=1)
+
+
+def _render_frames_hip(traj_px, nPosPerFrame, sigmas, output_size, upsampling_factor, spot_intensity, center):
+    """GPU tensors: the hand-written kernel (csrc/render.hip, mivit_render_frames) -- one workgroup per (sequence, frame, PSF)."""
+    import ctypes
+    from .. import _native as Nat
+    N, T, _ = traj_px.shape
+    F_ = T // nPosPerFrame
+    dev = traj_px.device
+    traj = traj_px.contiguous().float()
+    amp = spot_intensity.to(dev).expand(N, F_, nPosPerFrame).contiguous().float()
+    sig = torch.tensor([float(s) for s in sigmas], dtype=torch.float32, device=dev)
+    out = torch.empty(N, len(sig), F_, output_size, output_size, dtype=torch.float32, device=dev)
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())      # noqa: E731
+    for n0 in range(0, N, 65535):                     # grid.y limit
+        n1 = min(N, n0 + 65535)
+        Nat.check(Nat.lib.mivit_render_frames(vp(traj[n0:n1]), n1 - n0, T, nPosPerFrame, vp(sig), len(sig), output_size,
+                                              upsampling_factor, vp(amp[n0:n1]), int(bool(center)), vp(out[n0:n1]),
+                                              ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "mivit_render_frames")
+    return out.to(traj_px.dtype)
 
 
 def clipped_background(shape, mean: float, std: float, generator=None, device="cpu"):

@@ -6,9 +6,13 @@ the reference (Biomedical-Imaging-Group/MolecularDiffusion_MiViT, helpers/models
 (include/mivit_hip.h).  The ``nn.Module`` tree below is a *parameter container*: it gives the reference's
 state-dict schema, while the tensors themselves live in one fp32 arena laid out by the native plan.
 
-Not supported (raises instead of silently computing something else): dropout > 0, attention masks,
-activations other than relu / leaky_relu / gelu, MLP heads other than ``MLPHead`` with ReLU.
-There is no CPU path in this package.
+Constructor points the fused engine has no kernels for -- dropout > 0, an arbitrary activation callable, an ``MLPHead``
+with another activation class or dropout -- are legal in the reference and run here on the COMPOSED path: the same
+module tree evaluated layer by layer, every Linear / LayerNorm / attention core on the operator-level HIP kernels
+(``ops.py``), the element-wise extras (dropout, the callable) as PyTorch-ROCm ops on the GPU in between; attention
+dropout, which sits between softmax and P V inside the fused attention kernel, switches that core to explicit
+PyTorch-ROCm matmuls while training.  Attention masks raise (the reference never passes one).  There is no CPU path in
+this package.
 """
 from __future__ import annotations
 
@@ -44,12 +48,7 @@ def _act_code(fn) -> int:
         return N.ACT_GELU
     if isinstance(fn, nn.LeakyReLU) and fn.negative_slope == 0.01:
         return N.ACT_LEAKY_RELU
-    raise NotImplementedError(f"activation {fn!r} has no HIP kernel (supported: F.relu, F.leaky_relu, F.gelu)")
-
-
-def _require_no_dropout(p: float):
-    if p and p > 0:
-        raise NotImplementedError("dropout > 0 is not implemented on the HIP path (every shipped config uses 0.0)")
+    return None            # no fused epilogue for this callable: applied as a separate op (composed path)
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -63,7 +62,7 @@ class MultiHeadAttention(nn.Module):
         self.num_heads = num_heads
         self.head_dim = embed_dim // num_heads
         assert self.head_dim * num_heads == embed_dim, "embed_dim must be divisible by num_heads"
-        _require_no_dropout(dropout)
+        self.dropout = nn.Dropout(dropout)
         self.q_proj = nn.Linear(embed_dim, embed_dim)
         self.k_proj = nn.Linear(embed_dim, embed_dim)
         self.v_proj = nn.Linear(embed_dim, embed_dim)
@@ -78,7 +77,14 @@ class MultiHeadAttention(nn.Module):
         q = _ops.linear(x, self.q_proj.weight, self.q_proj.bias)
         k = _ops.linear(x, self.k_proj.weight, self.k_proj.bias)
         v = _ops.linear(x, self.v_proj.weight, self.v_proj.bias)
-        ctx = _ops.attention(torch.cat([q, k, v], dim=-1), self.num_heads)
+        if self.training and self.dropout.p > 0:
+            # dropout acts on the probabilities, between softmax and P V (reference models.py:45-50): explicit core
+            H, Dh = self.num_heads, self.head_dim
+            qh, kh, vh = [t.view(B, S, H, Dh).transpose(1, 2) for t in (q, k, v)]
+            p = self.dropout(torch.softmax((qh @ kh.transpose(-2, -1)).float() / (Dh ** 0.5), dim=-1)).to(vh.dtype)
+            ctx = (p @ vh).transpose(1, 2).reshape(B, S, E)
+        else:
+            ctx = _ops.attention(torch.cat([q, k, v], dim=-1), self.num_heads)
         return _ops.linear(ctx, self.out_proj.weight, self.out_proj.bias)
 
 
@@ -87,13 +93,16 @@ class FeedForward(nn.Module):
         super().__init__()
         self.fc1 = nn.Linear(embed_dim, hidden_dim)
         self.fc2 = nn.Linear(hidden_dim, embed_dim)
-        _require_no_dropout(dropout)
-        self._act_code = _act_code(activation_fct)
+        self.dropout = nn.Dropout(dropout)
+        self._act_code = _act_code(activation_fct)          # None: no fused epilogue, the callable runs as its own op
         self.activation = activation_fct
 
     def forward(self, x):
-        h = _ops.linear(x, self.fc1.weight, self.fc1.bias, act=self._act_code)
-        return _ops.linear(h, self.fc2.weight, self.fc2.bias)
+        if self._act_code is not None:
+            h = _ops.linear(x, self.fc1.weight, self.fc1.bias, act=self._act_code)
+        else:
+            h = self.activation(_ops.linear(x, self.fc1.weight, self.fc1.bias))
+        return _ops.linear(self.dropout(h), self.fc2.weight, self.fc2.bias)
 
 
 class TransformerEncoderLayerWithSkip(nn.Module):
@@ -105,10 +114,11 @@ class TransformerEncoderLayerWithSkip(nn.Module):
         self.norm1 = nn.LayerNorm(embed_dim)
         self.norm2 = nn.LayerNorm(embed_dim)
         self.feed_forward = FeedForward(embed_dim, hidden_dim, activation_fct, dropout)
+        self.dropout = nn.Dropout(dropout)
 
     def forward(self, x, mask=None):
-        x = _ops.layer_norm(x + self.self_attn(x, mask), self.norm1.weight, self.norm1.bias)
-        return _ops.layer_norm(x + self.feed_forward(x), self.norm2.weight, self.norm2.bias)
+        x = _ops.layer_norm(x + self.dropout(self.self_attn(x, mask)), self.norm1.weight, self.norm1.bias)
+        return _ops.layer_norm(x + self.dropout(self.feed_forward(x)), self.norm2.weight, self.norm2.bias)
 
 
 class Transformer(nn.Module):
@@ -329,9 +339,11 @@ class MLPHead(nn.Module):
 
     def forward(self, x):
         act = _act_code(self.mlp[1])
-        _require_no_dropout(getattr(self.mlp[2], "p", 0.0))
-        h = _ops.linear(x, self.mlp[0].weight, self.mlp[0].bias, act=act)
-        return _ops.linear(h, self.mlp[3].weight, self.mlp[3].bias)
+        if act is not None:
+            h = _ops.linear(x, self.mlp[0].weight, self.mlp[0].bias, act=act)
+        else:
+            h = self.mlp[1](_ops.linear(x, self.mlp[0].weight, self.mlp[0].bias))
+        return _ops.linear(self.mlp[2](h), self.mlp[3].weight, self.mlp[3].bias)
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -347,7 +359,6 @@ class GeneralTransformer(nn.Module):
                  single_prediction=True, use_global_features=False, fusion_type='early', global_feature_dim=None,
                  precision: Optional[str] = None):
         super().__init__()
-        _require_no_dropout(dropout)
         self.embed_dim = embed_dim
         self.embedding = embedding_cls(**embed_kwargs)
         self.norm = nn.LayerNorm(embed_dim)
@@ -370,10 +381,13 @@ class GeneralTransformer(nn.Module):
 
         # ---- native plan + parameter arena ----
         head = self.mlp_head
-        if not (hasattr(head, "mlp") and len(head.mlp) == 4 and isinstance(head.mlp[0], nn.Linear)
-                and isinstance(head.mlp[3], nn.Linear) and isinstance(head.mlp[1], nn.ReLU)
-                and not isinstance(head.mlp[2], nn.Dropout)):
-            raise NotImplementedError("the HIP path supports MLPHead(Linear, ReLU, Identity, Linear) heads only")
+        std_head = (hasattr(head, "mlp") and len(head.mlp) == 4 and isinstance(head.mlp[0], nn.Linear)
+                    and isinstance(head.mlp[3], nn.Linear))
+        if not std_head:
+            raise NotImplementedError("mlp_head must build a Linear -> activation -> (dropout) -> Linear `mlp` (MLPHead)")
+        # legal constructor points without fused kernels run on the composed path (module docstring)
+        self._composed = bool((dropout and dropout > 0) or _act_code(tr_activation_fct) is None
+                              or not isinstance(head.mlp[1], nn.ReLU) or isinstance(head.mlp[2], nn.Dropout))
         fusion = N.FUSION_NONE
         if use_global_features and fusion_type == 'late':
             fusion = N.FUSION_LATE
@@ -382,7 +396,7 @@ class GeneralTransformer(nn.Module):
         self._plan_kwargs = dict(
             embedding=getattr(self.embedding, "_mivit_embedding", N.EMBED_EXTERNAL),
             patch_size=int(getattr(self.embedding, "patch_size", 0) or 0), embed_dim=embed_dim, num_heads=num_heads,
-            hidden_dim=hidden_dim, num_layers=num_layers, activation=_act_code(tr_activation_fct),
+            hidden_dim=hidden_dim, num_layers=num_layers, activation=_act_code(tr_activation_fct) or N.ACT_RELU,
             use_pos_encoding=bool(use_pos_encoding), use_regression_token=bool(use_regression_token), fusion=fusion,
             global_feature_dim=int(global_feature_dim or 0), head_hidden=head.mlp[0].out_features,
             output_dim=head.mlp[3].out_features)
@@ -461,6 +475,8 @@ class GeneralTransformer(nn.Module):
         """x: [batch, num_images, image_size, image_size]; features: [batch, num_features] or None."""
         if not self._arena_ok():
             self._flatten()
+        if self._composed:
+            return self._forward_composed(x, features)
         emb_kind = self._plan.embedding
         if emb_kind == N.EMBED_EXTERNAL:
             tokens = self.embedding(x)                       # [B, T, E] through PyTorch-ROCm autograd
@@ -480,6 +496,35 @@ class GeneralTransformer(nn.Module):
             assert features is not None, "Global features required for late fusion"
             feats = features
         return MivitFunction.apply(self, tokens, feats, *self._arena_params)
+
+
+    def _forward_composed(self, x, features=None):
+        """reference models.py:328-361 evaluated module by module: Linear / LayerNorm / attention on the operator-level HIP
+        kernels in the model's precision, dropout and free-form activations as PyTorch-ROCm element-wise ops."""
+        if x.device.type != "cuda":
+            raise RuntimeError("the MiViT HIP path needs GPU tensors (no CPU fallback exists in this package)")
+        dt = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}.get(self.precision, torch.float32)
+        if self._plan.embedding == N.EMBED_EXTERNAL:
+            tok = self.embedding(x).to(dt)
+        else:
+            tok = self.embedding(x.to(dt))
+        tok = _ops.layer_norm(tok, self.norm.weight, self.norm.bias)
+        if self.use_regression_token:
+            reg = self.reg_token.expand(tok.shape[0], -1, -1).to(dt)
+            if self.use_global_features and self.fusion_type == 'early':
+                assert features is not None, "Global features required for early fusion"
+                reg = reg + self._project_features(features.to(dt)).unsqueeze(1)
+            tok = torch.cat((reg, tok), dim=1)
+        y = self.transformer(tok)
+        y = y[:, 0, :] if self.use_regression_token else y.mean(dim=1)
+        if self.use_global_features and self.fusion_type == 'late':
+            assert features is not None, "Global features required for late fusion"
+            y = torch.cat([y, self._project_features(features.to(dt))], dim=-1)
+        return self.mlp_head(y.contiguous()).float()
+
+    def _project_features(self, f):
+        fp = self.feature_projector
+        return _ops.linear(_ops.linear(f, fp[0].weight, fp[0].bias, act=N.ACT_RELU), fp[2].weight, fp[2].bias)
 
 
 # ------------------------------------------------------------------------------------------------------------

@@ -140,11 +140,13 @@ def test_error_conventions_host_side():
         M.MultiHeadAttention(10, 3)
     with pytest.raises(ValueError, match="activation_fct must be a callable"):
         M.FeedForward(8, 16, "relu")
-    with pytest.raises(NotImplementedError):
-        M.FeedForward(8, 16, torch.tanh)
-    with pytest.raises(NotImplementedError, match="dropout"):
-        M.GeneralTransformer(M.LinearProjectionEmbedding, dict(patch_size=9, embed_dim=64), 64, 4, 128, 1, M.MLPHead,
+    # legal constructor points without fused kernels build, and are routed to the composed path (tests/test_model_gpu.py)
+    assert M.FeedForward(8, 16, torch.tanh)._act_code is None
+    m = M.GeneralTransformer(M.LinearProjectionEmbedding, dict(patch_size=9, embed_dim=64), 64, 4, 128, 1, M.MLPHead,
                              F.relu, dropout=0.1)
+    assert m._composed and m.transformer.encoder_layers[0].dropout.p == 0.1
+    with pytest.raises(RuntimeError, match="GPU tensors"):                     # ... which has no CPU fallback either
+        m(torch.zeros(1, 3, 9, 9))
     with pytest.raises(AssertionError, match="Must provide global_feature_dim"):
         M.GeneralTransformer(M.LinearProjectionEmbedding, dict(patch_size=9, embed_dim=64), 64, 4, 128, 1, M.MLPHead,
                              F.relu, use_global_features=True)

@@ -146,3 +146,21 @@ def test_other_experiment_settings_surfaces():
     x = torch.arange(2 * 3 * 4 * 4.).reshape(2, 3, 4, 4)
     r = IF.generate_rotated_sequences(x)
     assert torch.equal(r[2], torch.rot90(x, 2, (2, 3))) and len(r) == 4
+
+
+def test_extract_particle_patches_matches_padded_slicing():
+    """helpers/tracking.py against the reference's definition (helpersTracking.py:513-550): pad by half, slice a square."""
+    from moleculardiffusion_mivit_amd.helpers.tracking import extract_particle_patches
+    rng = np.random.default_rng(0)
+    img = rng.normal(size=(5, 20, 17)).astype(np.float32)
+    tracks = {7: [(0, 3.2, 4.7), (1, 0.0, 0.0), (4, 19.4, 16.5), (2, 10.5, 8.5)], "b": [(3, 9, 9)], 9: []}
+    got = extract_particle_patches(img, tracks, patch_size=7)
+    for tid, positions in tracks.items():
+        ref = []
+        for frame, y, x in positions:
+            y, x = int(round(y)), int(round(x))
+            padded = np.pad(img[frame], pad_width=3, mode="constant")
+            ref.append(padded[y:y + 7, x:x + 7])
+        assert np.array_equal(got[tid], np.array(ref)), tid
+    t = extract_particle_patches(torch.as_tensor(img), {1: [(2, 5, 5)]}, patch_size=3)[1]
+    assert torch.is_tensor(t) and t.shape == (1, 3, 3) and torch.equal(t[0], torch.as_tensor(img[2, 4:7, 4:7]))

@@ -562,3 +562,52 @@ def test_autograd_node_refuses_second_backward_and_stale_parameters():
     xin.add_(1.0)                                    # the saved input changes under the recorded forward
     with pytest.raises(RuntimeError):
         loss.backward()
+
+
+@pytest.mark.parametrize("fusion", [None, "early", "late"])
+def test_composed_path_for_constructor_points_without_fused_kernels(fusion):
+    """dropout > 0, a free-form activation callable and a non-ReLU MLPHead are legal in the reference (models.py:25,48,66-70,
+    75,95,266-270).  They run on the composed path: the module tree evaluated layer by layer on the operator-level HIP kernels
+    with the element-wise extras as PyTorch-ROCm ops.  Checked against the fused engine where the two must coincide (an
+    opaque callable that IS relu; dropout in eval mode), and for sane behaviour where they cannot (dropout while training)."""
+    from functools import partial
+    import torch.nn as nn
+    from moleculardiffusion_mivit_amd.helpers import models as M
+    kw = dict(embedding_cls=M.LinearProjectionEmbedding, embed_kwargs={"patch_size": 9, "embed_dim": 64}, embed_dim=64,
+              num_heads=4, hidden_dim=128, num_layers=2, mlp_head=M.MLPHead, use_regression_token=fusion != "late",
+              use_global_features=fusion is not None, fusion_type=fusion or "early", global_feature_dim=25 if fusion else None,
+              precision="fp32")
+    torch.manual_seed(0)
+    fused = M.GeneralTransformer(tr_activation_fct=F.relu, dropout=0.0, **kw).cuda()
+    opaque = M.GeneralTransformer(tr_activation_fct=lambda t: torch.clamp_min(t, 0.0), dropout=0.0, **kw).cuda()
+    dropped = M.GeneralTransformer(tr_activation_fct=F.relu, dropout=0.3, **kw).cuda()
+    assert not fused._composed and opaque._composed and dropped._composed
+    opaque.load_state_dict(fused.state_dict()); dropped.load_state_dict(fused.state_dict())
+    x = torch.rand(5, 12, 9, 9, device="cuda")
+    feats = torch.randn(5, 25, device="cuda") if fusion else None
+    y = torch.rand(5, 1, device="cuda")
+    outs, grads = {}, {}
+    for name, m in (("fused", fused), ("opaque", opaque)):
+        m.train()
+        out = m(x, feats)
+        F.mse_loss(out, y).backward()
+        outs[name], grads[name] = out.detach(), {k: p.grad.clone() for k, p in m.named_parameters()}
+    assert rel_err(outs["opaque"], outs["fused"]) < 1e-4
+    gs = max(float(g.abs().max()) for g in grads["fused"].values())
+    for k in grads["fused"]:
+        assert float((grads["opaque"][k] - grads["fused"][k]).abs().max()) < 1e-4 * (float(grads["fused"][k].abs().max()) + 1e-3 * gs), k
+    dropped.eval()
+    with torch.no_grad():
+        assert rel_err(dropped(x, feats), outs["fused"]) < 1e-4                  # dropout is the identity in eval mode
+    dropped.train()
+    a, b = dropped(x, feats), dropped(x, feats)
+    assert not torch.equal(a, b) and torch.isfinite(a).all()                      # stochastic while training
+    F.mse_loss(a, y).backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in dropped.parameters())
+    # a head with another activation class and its own dropout, a smooth free-form activation, bf16
+    silu = M.GeneralTransformer(tr_activation_fct=F.silu, dropout=0.1, **{**kw, "precision": "bf16",
+                                "mlp_head": partial(M.MLPHead, activation=nn.Tanh, dropout=0.2)}).cuda().train()
+    out = silu(x, feats)
+    F.mse_loss(out, y).backward()
+    assert out.shape == (5, 1) and out.dtype == torch.float32 and torch.isfinite(out).all()
+    assert all(torch.isfinite(p.grad).all() for p in silu.parameters())
