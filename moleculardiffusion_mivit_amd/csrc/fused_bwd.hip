@@ -41,7 +41,9 @@ constexpr int LDS_BYTES = OFF_STG + 6 * NT * 16;
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 
 // slab layout per workgroup (floats)
-constexpr int SL_W1 = 0, SL_W2 = SL_W1 + F * E, SL_B1 = SL_W2 + E * F, SL_B2 = SL_B1 + F, SL_G2 = SL_B2 + E, SL_BE2 = SL_G2 + E,
+// (the order of the parameter arena: fc1.weight, fc1.bias, fc2.weight, fc2.bias, norm2.weight, norm2.bias -- when the
+//  six outputs are contiguous like that, ONE reduction launch finishes all of them)
+constexpr int SL_W1 = 0, SL_B1 = SL_W1 + F * E, SL_W2 = SL_B1 + F, SL_B2 = SL_W2 + E * F, SL_G2 = SL_B2 + E, SL_BE2 = SL_G2 + E,
               SL_TOTAL = SL_BE2 + E;
 
 struct MlpBwdArgs {
@@ -335,7 +337,8 @@ int launch_mlp_block_bwd(const void *dy, const void *n2, const float *rstd2, con
         MIVIT_LAUNCH_CHECK();
     }
     const float *sl = static_cast<const float *>(ws);
-    // the slab rows are [dW1 | dW2 | db1 | db2 | dgamma2 | dbeta2]: one strided reduction per output
+    if (db1 == dW1 + SL_B1 && dW2 == dW1 + SL_W2 && db2 == dW1 + SL_B2 && dgamma2 == dW1 + SL_G2 && dbeta2 == dW1 + SL_BE2)
+        return launch_slab_reduce_strided(sl, grid, SL_TOTAL, SL_TOTAL, dW1, s);          // the arena's layout: one launch
     struct { int off, n; float *out; } parts[] = {{SL_W1, F * E, dW1}, {SL_W2, E * F, dW2}, {SL_B1, F, db1}, {SL_B2, E, db2},
                                                   {SL_G2, E, dgamma2}, {SL_BE2, E, dbeta2}};
     for (auto &p : parts) RC(launch_slab_reduce_strided(sl + p.off, grid, SL_TOTAL, p.n, p.out, s));
