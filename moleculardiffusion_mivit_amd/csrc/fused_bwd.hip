@@ -225,14 +225,22 @@ __global__ __launch_bounds__(NT) void mlp_block_bwd_kernel(const MlpBwdArgs a) {
             }
         }
         // weight gradients: the contraction runs over the 32 rows of the tile (slots 0-3 = rows 4g.., slots 4-7 = rows 16+4g..)
+        {   // (operands of column tile t+1 are requested before the MFMAs of tile t: one wave per SIMD has nobody else to hide LDS latency)
+            bf16x8 xb = tr_pair(X + (4 * g + q) * LDE + 4 * pp, X + (16 + 4 * g + q) * LDE + 4 * pp);
+            bf16x8 zb = tr_pair(DZ + (4 * g + q) * LDE + 4 * pp, DZ + (16 + 4 * g + q) * LDE + 4 * pp);
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const bf16x8 xb = tr_pair(X + (4 * g + q) * LDE + 16 * t + 4 * pp, X + (16 + 4 * g + q) * LDE + 16 * t + 4 * pp);
-            const bf16x8 zb = tr_pair(DZ + (4 * g + q) * LDE + 16 * t + 4 * pp, DZ + (16 + 4 * g + q) * LDE + 16 * t + 4 * pp);
+            for (int t = 0; t < 8; ++t) {
+                bf16x8 xn = xb, zn = zb;
+                if (t < 7) {
+                    xn = tr_pair(X + (4 * g + q) * LDE + 16 * (t + 1) + 4 * pp, X + (16 + 4 * g + q) * LDE + 16 * (t + 1) + 4 * pp);
+                    zn = tr_pair(DZ + (4 * g + q) * LDE + 16 * (t + 1) + 4 * pp, DZ + (16 + 4 * g + q) * LDE + 16 * (t + 1) + 4 * pp);
+                }
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                dW1[nt][t] = mma(dhB[nt], xb, dW1[nt][t]);       // [n][k] += dh^T n1
-                dW2[t][nt] = mma(zb, hB[nt], dW2[t][nt]);        // [e][n] += dz2^T h
+                for (int nt = 0; nt < 4; ++nt) {
+                    dW1[nt][t] = mma(dhB[nt], xb, dW1[nt][t]);       // [n][k] += dh^T x1
+                    dW2[t][nt] = mma(zb, hB[nt], dW2[t][nt]);        // [e][n] += dz2^T h
+                }
+                xb = xn; zb = zn;
             }
         }
         __syncthreads();
@@ -244,15 +252,23 @@ __global__ __launch_bounds__(NT) void mlp_block_bwd_kernel(const MlpBwdArgs a) {
             for (int rt = 0; rt < 2; ++rt) dx[kt][rt] = zero;
         // A = W1^T read transposed out of the W1 image: k-slots 0-3 = hidden units 32ks + 4g + {0..3}, slots 4-7 = 32ks + 16 + 4g + {0..3};
         // the DH image stores hidden unit 32b + 16hi + 4gg + j at position 32b + 8gg + 4hi + j, so its plain 16-byte read matches
+        {
+            auto wfrag = [&](int ks, int kt) {
+                return tr_pair(W1i + (32 * ks + 4 * g + q) * LDE + 32 * wave + 16 * kt + 4 * pp,
+                               W1i + (32 * ks + 16 + 4 * g + q) * LDE + 32 * wave + 16 * kt + 4 * pp);
+            };
+            bf16x8 d0 = lds_frag(DH + cq * LDF + 8 * g), d1 = lds_frag(DH + (16 + cq) * LDF + 8 * g);
+            bf16x8 w0 = wfrag(0, 0), w1 = wfrag(0, 1);
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            const bf16x8 d0 = lds_frag(DH + cq * LDF + ks * 32 + 8 * g), d1 = lds_frag(DH + (16 + cq) * LDF + ks * 32 + 8 * g);
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt) {
-                const bf16x8 wa = tr_pair(W1i + (32 * ks + 4 * g + q) * LDE + 32 * wave + 16 * kt + 4 * pp,
-                                          W1i + (32 * ks + 16 + 4 * g + q) * LDE + 32 * wave + 16 * kt + 4 * pp);
-                dx[kt][0] = mma(wa, d0, dx[kt][0]);
-                dx[kt][1] = mma(wa, d1, dx[kt][1]);
+            for (int ks = 0; ks < 8; ++ks) {
+                bf16x8 e0 = d0, e1 = d1, v0 = w0, v1 = w1;
+                if (ks < 7) {
+                    e0 = lds_frag(DH + cq * LDF + (ks + 1) * 32 + 8 * g); e1 = lds_frag(DH + (16 + cq) * LDF + (ks + 1) * 32 + 8 * g);
+                    v0 = wfrag(ks + 1, 0); v1 = wfrag(ks + 1, 1);
+                }
+                dx[0][0] = mma(w0, d0, dx[0][0]); dx[0][1] = mma(w0, d1, dx[0][1]);
+                dx[1][0] = mma(w1, d0, dx[1][0]); dx[1][1] = mma(w1, d1, dx[1][1]);
+                d0 = e0; d1 = e1; w0 = v0; w1 = v1;
             }
         }
 #pragma unroll
