@@ -256,6 +256,24 @@ def main():
                            "dtype": prec}
             del m2, o2, d2
             torch.cuda.empty_cache()
+        # (1b) inference (model.eval() + no_grad: the make_prediction path of the reference's evaluation loops): forward only,
+        #      the layers hand each other normalised tokens and nothing is kept for a backward
+        m2, _ = build(args.precision)
+        m2.eval()
+        d2 = [synth(Bg, T, P, 888 + i, dev) for i in range(2)]
+        with torch.no_grad():
+            for i in range(3):
+                m2(d2[i % 2][0])
+            barrier()
+            t0i = time.perf_counter()
+            for i in range(10):
+                m2(d2[i % 2][0])
+            barrier()
+            t2 = time.perf_counter() - t0i
+        extras["inference"] = {"sequences_per_s": round(10 * Bg / t2, 1), "ms_per_batch": round(1e3 * t2 / 10, 4), "per_gpu_batch": Bg,
+                               "dtype": args.precision}
+        del m2, d2
+        torch.cuda.empty_cache()
         # (2) a TRAINED validation MSE(D): fixed short schedule (AdamW 1e-3, 300 steps of 1024 fresh synthetic sequences,
         #     StepLR(5, 0.9) every 30 steps), same seed in the benchmark precision and in the fp32 parity mode
         for tag, prec in (("val_mse_D_trained", args.precision), ("val_mse_D_trained_fp32", "fp32")):
