@@ -611,3 +611,21 @@ def test_composed_path_for_constructor_points_without_fused_kernels(fusion):
     F.mse_loss(out, y).backward()
     assert out.shape == (5, 1) and out.dtype == torch.float32 and torch.isfinite(out).all()
     assert all(torch.isfinite(p.grad).all() for p in silu.parameters())
+
+
+def test_fused_inference_path_matches_training_forward_and_fp32():
+    """Headline shape (E 128, F 256, 4 heads, 33 tokens): the inference forward (layers hand each other normalised tokens,
+    nothing kept) against the training forward (q|k|v kept for the backward: another kernel instantiation) and against the
+    fp32 parity mode on the same weights."""
+    _, meta, cfg = load_golden("c1")
+    params, x, labels, _ = golden_inputs(meta, cfg)
+    xb = torch.cat([x, x.flip(0) * 0.9 + 0.02], dim=0).cuda()          # 16 sequences
+    m16 = build_product_model(cfg, "bf16", params, device="cuda")
+    m32 = build_product_model(cfg, "fp32", params, device="cuda")
+    m16.train()
+    out_train = m16(xb)
+    m16.eval(); m32.eval()
+    with torch.no_grad():
+        out_eval, out_ref = m16(xb), m32(xb)
+    assert rel_err(out_eval, out_train.detach()) < 1e-2
+    assert rel_err(out_eval, out_ref) < 5e-2
