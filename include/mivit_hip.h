@@ -157,6 +157,16 @@ int mivit_mlp_block_bwd(const void *dy, const void *n2, const float *rstd2, cons
 int mivit_render_frames(const float *traj_px, int N, int T, int npos, const float *sigmas, int nsig, int P, int up,
                         const float *amp, int center, float *out, void *stream);
 
+/* LayerNorm-1 backward + out-projection backward in one pass (autograd of x1 = LN1(x + out_proj(ctx)), models.py:57,100-102,
+ * between the feed-forward block's input gradient and the attention core), csrc/fused_bwd.hip:
+ * in : dy = dL/dx1 [M,E] bf16, n1 / rstd1 (LN1's normalised output, 1/std), gamma1, ctx [M,E] (out_proj's input), Wo bf16 [E,E];
+ * out: dz1 = dL/d(x + out_proj(ctx)) [M,E] bf16 (also the residual branch's gradient), dctx = dz1 Wo [M,E] bf16,
+ *      dWo [E,E], dbo [E], dgamma1 [E], dbeta1 [E] fp32 (overwritten).  Deterministic. */
+size_t mivit_attn_out_bwd_workspace_bytes(int M);
+int mivit_attn_out_bwd(const void *dy, const void *n1, const float *rstd1, const float *gamma1, const void *ctx,
+                       const void *Wo_bf16, int M, void *dz1, void *dctx, float *dWo, float *dbo, float *dgamma1,
+                       float *dbeta1, void *workspace, size_t workspace_bytes, void *stream);
+
 /* DeepResNetEmbedding in inference mode (helpers/models.py:230-257; ResidualBlock :202-228): conv3x3(1->32)+BN+ReLU,
  * ResidualBlock(32->64), ResidualBlock(64->128), global average pool, Linear(128->E), fused in one kernel that keeps F
  * whole frames in LDS.  Eval-mode BatchNorm is folded by the caller: conv weights are pre-scaled by

@@ -20,6 +20,10 @@ int launch_mlp_block_fwd(const void *nin, const float *gin, const float *bin, co
                          void *xout, void *zout, float *mean, void *hout, void *uout, hipStream_t s);
 
 size_t mlp_block_bwd_ws_bytes(int M);
+size_t attn_out_bwd_ws_bytes(int M);
+int launch_attn_out_bwd(const void *dy, const void *n1, const float *rstd1, const float *gamma1, const void *ctx, const void *Wo, int M,
+                        void *dz1, void *dctx, float *dWo, float *dbo, float *dgamma1, float *dbeta1, void *ws, size_t ws_bytes,
+                        hipStream_t s);
 int launch_mlp_block_bwd(const void *dy, const void *n2, const float *rstd2, const float *gamma2, const void *n1,
                          const float *gamma1, const float *beta1, const void *W1, const float *b1, const void *W2, int M, int act,
                          void *dx1, float *dW1, float *db1, float *dW2, float *db2, float *dgamma2, float *dbeta2, void *ws,
@@ -136,7 +140,7 @@ Ws make_ws(const mivit_plan *p, int B, int T, bool bwd) {
             if (b > wg) wg = b;
         };
         mx((int)M, 3 * E, E); mx((int)M, E, E); mx((int)M, F, E); mx((int)M, E, F);
-        if (fused) wg = std::max(wg, mlp_block_bwd_ws_bytes((int)M));
+        if (fused) wg = std::max(std::max(wg, mlp_block_bwd_ws_bytes((int)M)), attn_out_bwd_ws_bytes((int)M));
         if (c.embedding != MIVIT_EMBED_EXTERNAL) {
             mx((int)Mt, E, c.patch_size * c.patch_size);
             if (embed_dma_supported(c.dtype, (int)Mt, c.patch_size * c.patch_size, E)) {
@@ -641,6 +645,13 @@ static int backward_impl(const mivit_plan *plan, const float *params, const floa
             RC(lin_dgrad(dt, at(ws, w.dF), F, WT(lp.fc1_w), M, F, E, MIVIT_ACT_NONE, nullptr, 0, at(ws, w.dxb), E,
                          at(ws, w.dxa), E, 0, s));                                                // dxa = d(x1)
             }
+            if (fz) {
+                // LayerNorm-1 backward + out-projection weight / data gradient in one launch (fused_bwd.hip)
+                prof_set_tag(MIVIT_PROF_LINEAR_DGRAD);
+                RC(launch_attn_out_bwd(dx1, at(ws, b.z1), static_cast<const float *>(at(ws, b.rstd1)), P + lp.n1_w, at(ws, b.ctx),
+                                       WT(lp.out_w), M, dz1, at(ws, w.dctx), G + lp.out_w, G + lp.out_b, G + lp.n1_w, G + lp.n1_b,
+                                       wg, wgb, s));
+            } else {
             LayerNormBwdArgs n1 = n2;
             n1.dy = dx1; n1.z = at(ws, b.z1); n1.gamma = P + lp.n1_w;
             n1.mean = fz ? nullptr : static_cast<const float *>(at(ws, b.mean1)); n1.rstd = static_cast<const float *>(at(ws, b.rstd1));
@@ -649,6 +660,7 @@ static int backward_impl(const mivit_plan *plan, const float *params, const floa
             RC(lin_wgrad(dt, dz1, E, at(ws, b.ctx), 0, E, M, E, E, G + lp.out_w, cs ? G + lp.out_b : nullptr, wg, wgb, s));
             RC(lin_dgrad(dt, dz1, E, WT(lp.out_w), M, E, E, MIVIT_ACT_NONE, nullptr, 0, nullptr, 0,
                          at(ws, w.dctx), E, 0, s));
+            }
             prof_set_tag(MIVIT_PROF_ATTN_BWD); RC(launch_attention_bwd(dt, at(ws, b.qkv), at(ws, w.dctx), B, S, H, Dh, at(ws, w.dqkv), s));
             RC(lin_wgrad(dt, at(ws, w.dqkv), 3 * E, xin, 0, E, M, 3 * E, E, G + lp.qkv_w, G + lp.qkv_b, wg, wgb, s));
             if (fz && l > 0)

@@ -315,6 +315,160 @@ __global__ __launch_bounds__(NT) void mlp_block_bwd_kernel(const MlpBwdArgs a) {
     }
 }
 
+// ================================================================================================================
+// LayerNorm-1 backward + out-projection backward (autograd of x1 = LN1(x + out_proj(ctx)), models.py:57,100-102, up to the
+// attention core):   in : dy = dL/dx1, n1 / rstd1 (LN1's normalised output, 1/std), ctx (the out-projection's input)
+//                    out: dz1 = dL/d(pre-norm sum) [the residual branch's gradient], dctx = dz1 Wo, dWo = dz1^T ctx, dbo, dgamma1, dbeta1
+// one pass: 3 row reads, 2 row writes (the three launches it replaces -- LayerNorm backward, weight gradient, data gradient --
+// moved 7).  Same structure as the feed-forward backward, without its recompute: 32-row tiles, element-wise LayerNorm
+// backward by all threads into an LDS image, then wave w takes output features 32w..32w+31 of dctx (transposed product:
+// 8-byte row stores) and rows 32w..32w+31 of dWo (row contraction: both operands by transposing LDS reads).  Small LDS and
+// register footprint -> two workgroups per CU cover each other's barriers.
+// ================================================================================================================
+constexpr int AO_OFF_DZ = 0, AO_OFF_CT = AO_OFF_DZ + R * LDE * 2, AO_OFF_STG = AO_OFF_CT + R * LDE * 2;
+constexpr int AO_OFF_RED = AO_OFF_STG + 6 * NT * 16;            // [NW][3][E] floats: end-of-launch fold of the column sums
+constexpr int AO_LDS = AO_OFF_RED + NW * 3 * E * 4;
+constexpr int AO_SL_W = 0, AO_SL_B = E * E, AO_SL_G = AO_SL_B + E, AO_SL_BE = AO_SL_G + E, AO_SL_TOTAL = AO_SL_BE + E;   // arena order:
+                                                                // out_proj.weight, out_proj.bias, norm1.weight, norm1.bias
+struct AttnOutBwdArgs {
+    const bf16 *dy, *n1; const float *rstd1, *gamma1;
+    const bf16 *ctx, *Wo;
+    int M;
+    bf16 *dz1, *dctx;
+    float *slabs;
+};
+
+__global__ __launch_bounds__(NT, 2) void attn_out_bwd_kernel(const AttnOutBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16 *DZ = reinterpret_cast<bf16 *>(smem + AO_OFF_DZ), *CT = reinterpret_cast<bf16 *>(smem + AO_OFF_CT);
+    uint4 *stg = reinterpret_cast<uint4 *>(smem + AO_OFF_STG);
+    float *red = reinterpret_cast<float *>(smem + AO_OFF_RED);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, cq = lane & 15, q = cq >> 2, pp = cq & 3;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    // row operand of dctx^T = Wo^T dz1^T for this wave's context features c = 32 wave + 16 ct + cq: A[c][e] = Wo[e][c]
+    bf16x8 wof[2][4];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 t;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t[e] = __builtin_bit_cast(__bf16, a.Wo[(int64_t)(ks * 32 + 8 * g + e) * E + 32 * wave + 16 * ct + cq].v);
+            wof[ct][ks] = t;
+        }
+    const int c = tid & 15, r0 = tid >> 4;
+    float gam[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) gam[e] = a.gamma1[8 * c + e];
+    float sg[8], sb[8], sz[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sg[e] = sb[e] = sz[e] = 0.f;
+    f32x4 dWo[2][8];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dWo[i][j] = zero;
+
+    const int ntiles = (a.M + R - 1) / R;
+    int tile = blockIdx.x;
+    float prs[2];
+    auto prefetch = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int64_t row = min((int64_t)t * R + r0 + 16 * i, (int64_t)a.M - 1);
+            const int64_t o = row * E + 8 * c;
+            dma16(a.dy + o, stg + (3 * i + 0) * NT + wave * 64);
+            dma16(a.n1 + o, stg + (3 * i + 1) * NT + wave * 64);
+            dma16(a.ctx + o, stg + (3 * i + 2) * NT + wave * 64);
+            prs[i] = ((int64_t)t * R + r0 + 16 * i < a.M) ? a.rstd1[row] : 0.f;
+        }
+    };
+    if (tile < ntiles) prefetch(tile);
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int64_t row0 = (int64_t)tile * R;
+        // ---- phase 0: LayerNorm backward, dz1 -> HBM + LDS image, ctx -> LDS image ----
+        wait_vm<0>();
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float d[8], nh[8], gdy[8];
+            const bool ok = row0 + r0 + 16 * i < a.M;
+            const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
+            const uint4 pdy = ok ? stg[(3 * i + 0) * NT + tid] : z4, pn = stg[(3 * i + 1) * NT + tid];
+            const uint4 pct = ok ? stg[(3 * i + 2) * NT + tid] : z4;
+            unpack8(pdy, d); unpack8(pn, nh);
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                gdy[e] = d[e] * gam[e];
+                s1 += gdy[e]; s2 += gdy[e] * nh[e];
+                sg[e] += d[e] * nh[e]; sb[e] += d[e];
+            }
+            s1 = g16_sum(s1) * (1.f / E); s2 = g16_sum(s2) * (1.f / E);
+            float dz[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { dz[e] = prs[i] * (gdy[e] - s1 - nh[e] * s2); sz[e] += dz[e]; }
+            store16(DZ + (r0 + 16 * i) * LDE + 8 * c, dz);
+            if (ok) store16(a.dz1 + (row0 + r0 + 16 * i) * E + 8 * c, dz);
+            *reinterpret_cast<uint4 *>(CT + (r0 + 16 * i) * LDE + 8 * c) = pct;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        prefetch(min(tile + (int)gridDim.x, ntiles - 1));
+        __syncthreads();
+        // ---- phase 1: dctx^T for this wave's 32 context features; dWo rows 32 wave .. +31 ----
+        f32x4 dc[2][2] = {{zero, zero}, {zero, zero}};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const bf16x8 z0 = lds_frag(DZ + cq * LDE + ks * 32 + 8 * g), z1 = lds_frag(DZ + (16 + cq) * LDE + ks * 32 + 8 * g);
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) { dc[ct][0] = mma(wof[ct][ks], z0, dc[ct][0]); dc[ct][1] = mma(wof[ct][ks], z1, dc[ct][1]); }
+        }
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            const int64_t row = row0 + 16 * rt + cq;
+            if (row < a.M) {
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+                    const f32x4 o = dc[ct][rt];
+                    const bf16x4 ob = {(__bf16)o[0], (__bf16)o[1], (__bf16)o[2], (__bf16)o[3]};
+                    *reinterpret_cast<bf16x4 *>(a.dctx + row * E + 32 * wave + 16 * ct + 4 * g) = ob;
+                }
+            }
+        }
+#pragma unroll
+        for (int et = 0; et < 2; ++et) {
+            const bf16x8 za = tr_pair(DZ + (4 * g + q) * LDE + 32 * wave + 16 * et + 4 * pp, DZ + (16 + 4 * g + q) * LDE + 32 * wave + 16 * et + 4 * pp);
+#pragma unroll
+            for (int ct = 0; ct < 8; ++ct) {
+                const bf16x8 cb = tr_pair(CT + (4 * g + q) * LDE + 16 * ct + 4 * pp, CT + (16 + 4 * g + q) * LDE + 16 * ct + 4 * pp);
+                dWo[et][ct] = mma(za, cb, dWo[et][ct]);                 // [e][c] += dz1^T ctx
+            }
+        }
+        __syncthreads();
+    }
+    // ---- partial gradients -> this workgroup's slab ----
+    float *sl = a.slabs + (int64_t)blockIdx.x * AO_SL_TOTAL;
+#pragma unroll
+    for (int et = 0; et < 2; ++et)
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sl[AO_SL_W + (32 * wave + 16 * et + 4 * g + j) * E + 16 * ct + cq] = dWo[et][ct][j];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float vg = x4_sum(sg[e]), vb = x4_sum(sb[e]), vz = x4_sum(sz[e]);
+        if (g == 0) { red[(wave * 3 + 0) * E + 8 * c + e] = vg; red[(wave * 3 + 1) * E + 8 * c + e] = vb; red[(wave * 3 + 2) * E + 8 * c + e] = vz; }
+    }
+    __syncthreads();
+    for (int i = tid; i < 3 * E; i += NT) {
+        const int which = i / E, col = i - which * E;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) v += red[(w * 3 + which) * E + col];
+        sl[(which == 0 ? AO_SL_G : which == 1 ? AO_SL_BE : AO_SL_B) + col] = v;
+    }
+}
+
 bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 int grid_for(int M) { return std::min(256, ceil_div(M, R)); }
 
@@ -370,4 +524,41 @@ extern "C" int mivit_mlp_block_bwd(const void *dy, const void *n2, const float *
     hipStream_t s = static_cast<hipStream_t>(stream);
     return launch_mlp_block_bwd(dy, n2, rstd2, gamma2, n1, gamma1, beta1, W1_bf16, b1, W2_bf16, M, act, dx1, dW1, db1, dW2, db2, dgamma2,
                                 dbeta2, workspace, workspace_bytes, s);
+}
+
+size_t attn_out_bwd_ws_bytes(int M) { return align_up((size_t)std::min(512, ceil_div(std::max(M, 1), R)) * AO_SL_TOTAL * sizeof(float), 256); }
+
+// dz1, dctx [M,E] bf16; dWo [E,E], dbo, dgamma1, dbeta1 [E] fp32 (overwritten)
+int launch_attn_out_bwd(const void *dy, const void *n1, const float *rstd1, const float *gamma1, const void *ctx, const void *Wo, int M,
+                        void *dz1, void *dctx, float *dWo, float *dbo, float *dgamma1, float *dbeta1, void *ws, size_t ws_bytes,
+                        hipStream_t s) {
+    MIVIT_CHECK(dy && n1 && rstd1 && gamma1 && ctx && Wo && dz1 && dctx && dWo && dbo && dgamma1 && dbeta1 && ws && M > 0,
+                "attn_out_bwd: null pointer / empty problem");
+    MIVIT_CHECK(aligned16(dy) && aligned16(n1) && aligned16(ctx) && aligned16(Wo) && aligned16(dz1) && aligned16(dctx),
+                "attn_out_bwd: pointers must be 16-byte aligned");
+    MIVIT_CHECK(ws_bytes >= attn_out_bwd_ws_bytes(M), "attn_out_bwd: workspace too small");
+    AttnOutBwdArgs a{static_cast<const bf16 *>(dy), static_cast<const bf16 *>(n1), rstd1, gamma1, static_cast<const bf16 *>(ctx),
+                     static_cast<const bf16 *>(Wo), M, static_cast<bf16 *>(dz1), static_cast<bf16 *>(dctx), static_cast<float *>(ws)};
+    const int grid = std::min(512, ceil_div(M, R));            // two resident workgroups per CU
+    {
+        ProfScope prof(s);
+        MIVIT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(attn_out_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, AO_LDS));
+        hipLaunchKernelGGL(attn_out_bwd_kernel, dim3(grid), dim3(NT), AO_LDS, s, a);
+        MIVIT_LAUNCH_CHECK();
+    }
+    const float *sl = static_cast<const float *>(ws);
+    if (dbo == dWo + AO_SL_B && dgamma1 == dWo + AO_SL_G && dbeta1 == dWo + AO_SL_BE)
+        return launch_slab_reduce_strided(sl, grid, AO_SL_TOTAL, AO_SL_TOTAL, dWo, s);
+    struct { int off, n; float *out; } parts[] = {{AO_SL_W, E * E, dWo}, {AO_SL_B, E, dbo}, {AO_SL_G, E, dgamma1}, {AO_SL_BE, E, dbeta1}};
+    for (auto &p : parts) RC(launch_slab_reduce_strided(sl + p.off, grid, AO_SL_TOTAL, p.n, p.out, s));
+    return 0;
+}
+
+extern "C" size_t mivit_attn_out_bwd_workspace_bytes(int M) { return attn_out_bwd_ws_bytes(M); }
+extern "C" int mivit_attn_out_bwd(const void *dy, const void *n1, const float *rstd1, const float *gamma1, const void *ctx,
+                                  const void *Wo_bf16, int M, void *dz1, void *dctx, float *dWo, float *dbo, float *dgamma1,
+                                  float *dbeta1, void *workspace, size_t workspace_bytes, void *stream) {
+    prof_set_tag(MIVIT_PROF_OP);
+    return launch_attn_out_bwd(dy, n1, rstd1, gamma1, ctx, Wo_bf16, M, dz1, dctx, dWo, dbo, dgamma1, dbeta1, workspace, workspace_bytes,
+                               static_cast<hipStream_t>(stream));
 }

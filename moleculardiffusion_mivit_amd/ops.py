@@ -411,3 +411,20 @@ def mlp_block_bwd(dy, n2, rstd2, gamma2, n1, gamma1, beta1, W1, b1, W2, act=N.AC
                                       _p(out["db2"]), _p(out["dgamma2"]), _p(out["dbeta2"]), _p(ws), nbytes, _s(dy)),
             "mivit_mlp_block_bwd")
     return out
+
+
+@torch.no_grad()
+def attn_out_bwd(dy, n1, rstd1, gamma1, ctx, Wo):
+    """LayerNorm-1 backward + out-projection backward (include/mivit_hip.h): dict(dz1, dctx, dWo, dbo, dgamma1, dbeta1)."""
+    _gpu(dy, n1, ctx, Wo)
+    M, E = dy.shape
+    dev = dy.device
+    out = {"dz1": torch.empty(M, E, dtype=torch.bfloat16, device=dev), "dctx": torch.empty(M, E, dtype=torch.bfloat16, device=dev),
+           "dWo": torch.empty(E, E, device=dev), "dbo": torch.empty(E, device=dev), "dgamma1": torch.empty(E, device=dev),
+           "dbeta1": torch.empty(E, device=dev)}
+    nbytes = N.lib.mivit_attn_out_bwd_workspace_bytes(M)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    args = [dy.contiguous(), n1.contiguous(), _f32(rstd1), _f32(gamma1), ctx.contiguous(), Wo.contiguous()]
+    N.check(N.lib.mivit_attn_out_bwd(*[_p(t) for t in args], M, _p(out["dz1"]), _p(out["dctx"]), _p(out["dWo"]), _p(out["dbo"]),
+                                     _p(out["dgamma1"]), _p(out["dbeta1"]), _p(ws), nbytes, _s(dy)), "mivit_attn_out_bwd")
+    return out

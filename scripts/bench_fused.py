@@ -52,6 +52,8 @@ if hasattr(ops, "mlp_block_bwd"):
     rstd = 1 + 0.1 * rn(M).abs()
     cases["mlp_block_bwd"] = (lambda: ops.mlp_block_bwd(dy, n_in.view(M, E), rstd, gi, n_in.view(M, E), gi, bi, W1, b1, W2), 4 * U,
                               M * 10 * E * FH)
+if hasattr(ops, "attn_out_bwd"):
+    cases["attn_out_bwd"] = (lambda: ops.attn_out_bwd(dy, n_in.view(M, E), rstd, gi, n_in.view(M, E), Wo), 5 * U, M * 4 * E * E)
 for name, (fn, byt, fl) in cases.items():
     us = timeit(fn)
     print(f"{name:34s} {us:9.1f} us   {byt / us / 1e3:8.1f} GB/s   {fl / us / 1e6:8.1f} TFLOP/s", flush=True)

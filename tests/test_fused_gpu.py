@@ -199,3 +199,26 @@ def test_mlp_block_bwd_is_deterministic():
     torch.cuda.synchronize()
     for k in a:
         assert torch.equal(a[k], b[k]), k
+
+
+@pytest.mark.parametrize("M", [1, 31, 264, 1000, 16500])
+def test_attn_out_bwd(M):
+    """LayerNorm-1 backward + out-projection backward vs the chain rule in fp32 (reference models.py:57,100-102)."""
+    from moleculardiffusion_mivit_amd import ops
+    dy = _bf(_mk((M, E), 41)).float()
+    nh = _bf(_mk((M, E), 42)).float()
+    rstd = 1.0 + 0.2 * _mk((M,), 43).abs()
+    g1 = 1.0 + 0.3 * _mk((E,), 44)
+    ctx = _bf(_mk((M, E), 45)).float()
+    Wo = _bf(_mk((E, E), 46, 1 / math.sqrt(E))).float()
+    gdy = dy * g1
+    dz1 = rstd[:, None] * (gdy - gdy.mean(-1, keepdim=True) - nh * (gdy * nh).mean(-1, keepdim=True))
+    dzb = _bf(dz1).float()                    # the MFMAs consume the bf16 image of dz1
+    ref = {"dz1": dz1, "dctx": dzb @ Wo, "dWo": dzb.t() @ ctx, "dbo": dz1.sum(0), "dgamma1": (dy * nh).sum(0), "dbeta1": dy.sum(0)}
+    out = ops.attn_out_bwd(_bf(dy).cuda(), _bf(nh).cuda(), rstd.cuda(), g1.cuda(), _bf(ctx).cuda(), _bf(Wo).cuda())
+    torch.cuda.synchronize()
+    for k, r in ref.items():
+        assert _rel(out[k].float(), r) < 2e-2, k
+    again = ops.attn_out_bwd(_bf(dy).cuda(), _bf(nh).cuda(), rstd.cuda(), g1.cuda(), _bf(ctx).cuda(), _bf(Wo).cuda())
+    for k in out:
+        assert torch.equal(out[k], again[k]), k
