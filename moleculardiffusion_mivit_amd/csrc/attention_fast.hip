@@ -393,8 +393,8 @@ __global__ __launch_bounds__(256, (NT * ND <= 6 ? 3 : 1)) void attn_bwd_fast2(co
     if (pair >= d.B * d.H) return;
     const int b = pair / d.H, h = pair % d.H;
     const int g = lane >> 4, cq = lane & 15;
-    bf16 *Qimg = reinterpret_cast<bf16 *>(smem_raw) + (size_t)wave * 3 * d.img;
-    bf16 *Kimg = Qimg + d.img, *Oimg = Kimg + d.img;
+    bf16 *Qimg = reinterpret_cast<bf16 *>(smem_raw) + (size_t)wave * (3 * d.img + NT * 256);
+    bf16 *Kimg = Qimg + d.img, *Oimg = Kimg + d.img, *Simg = Oimg + d.img;     // Simg: dS of the current row tile, [key][16 queries]
     const int64_t ld3 = 3 * (int64_t)d.E;
     const bf16 *q = qkv + (int64_t)b * d.S * ld3 + h * d.Dh, *k = q + d.E, *v = q + 2 * d.E;
     const bf16 *dO = dctx + (int64_t)b * d.S * d.E + h * d.Dh;
@@ -428,6 +428,7 @@ __global__ __launch_bounds__(256, (NT * ND <= 6 ? 3 : 1)) void attn_bwd_fast2(co
             qf[kd] = gfrag(q, ld3, it * 16, d.S, kd * 32, d.Dh, lane);
             of[kd] = gfrag(dO, d.E, it * 16, d.S, kd * 32, d.Dh, lane);
         }
+        f32x4 dS[NT];        // dS of this row tile: lane = key j*16 + cq, registers = queries it*16 + 4g + r
         {   // ---- lane = key orientation: S = Q K^T, dP = dO V^T  ->  P, dS of this row tile  ->  dV, dK ----
             f32x4 sc[NT], dp[NT];
 #pragma unroll
@@ -479,54 +480,23 @@ __global__ __launch_bounds__(256, (NT * ND <= 6 ? 3 : 1)) void attn_bwd_fast2(co
                     dk[j][jd] = mma16(pack4(dp[j]), bq, dk[j][jd]);
                 }
             }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) dS[j] = dp[j];
         }
-        {   // ---- lane = query orientation: S^T = K Q^T, dP^T = V dO^T -> dS^T -> dQ of this row tile ----
-            f32x4 st[NT], dt[NT];
-            float m = -INFINITY;
+        {   // ---- dQ of this row tile = dS K: the contraction runs over keys, which sit on the LANES of the dS tiles above.
+            //      One trip through a wave-private LDS image turns them: each lane stores its 4 consecutive queries of key
+            //      j*16 + cq (8 bytes) into a [key][query] image, a transposing read returns lane = query, k slots = keys --
+            //      instead of recomputing scores, dP and the softmax in the other orientation (12 MFMAs + a second softmax pass).
+            lds_sync();            // the previous row tile's dS reads are done
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                st[j] = zero; dt[j] = zero;
-#pragma unroll
-                for (int kd = 0; kd < KD; ++kd) {
-                    st[j] = mma(kf[j][kd], qf[kd], st[j]);
-                    dt[j] = mma(vf[j][kd], of[kd], dt[j]);
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const bool ok = j * 16 + 4 * g + r < d.S;
-                    st[j][r] = ok ? st[j][r] * scale : -INFINITY;
-                    m = fmaxf(m, st[j][r]);
-                }
-            }
-            m = x4_max(m);
-            float sum = 0.f;
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float e = (j * 16 + 4 * g + r < d.S) ? __expf(st[j][r] - m) : 0.f;
-                    st[j][r] = e;
-                    sum += e;
-                }
-            const float inv = 1.f / x4_sum(sum);
-            float delta = 0.f;
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    st[j][r] *= inv;
-                    delta += st[j][r] * dt[j][r];
-                }
-            delta = x4_sum(delta);
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) st[j][r] = scale * st[j][r] * (dt[j][r] - delta);    // dS^T: rows = keys, col = query
+            for (int j = 0; j < NT; ++j) *reinterpret_cast<k16_t *>(Simg + (j * 16 + cq) * 16 + 4 * g) = pack4(dS[j]);
+            lds_sync();
 #pragma unroll
             for (int jd = 0; jd < ND; ++jd) {
                 f32x4 dq = zero;
 #pragma unroll
-                for (int j = 0; j < NT; ++j) dq = mma16(pack4(st[j]), tr4(Kimg, d.ld, j * 16 + 4 * g, jd * 16, lane), dq);
+                for (int j = 0; j < NT; ++j)
+                    dq = mma16(tr4(Simg, 16, j * 16 + 4 * g, 0, lane), tr4(Kimg, d.ld, j * 16 + 4 * g, jd * 16, lane), dq);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = it * 16 + 4 * g + r;
@@ -586,7 +556,7 @@ int bwd_launch(const bf16 *qkv, const bf16 *dctx, bf16 *dqkv, const FastDims &d,
     if (version == 2) {        // the 16-deep version needs NT * 16 image rows, not the pair-padded NP * 32: more waves fit a CU
         FastDims d2 = d;
         d2.img = NT * 16 * d.ld;
-        const size_t pw = (size_t)3 * d2.img * sizeof(bf16);
+        const size_t pw = ((size_t)3 * d2.img + NT * 256) * sizeof(bf16);
         const int w2 = waves_per_block(pw);
         if (pw * w2 > 64 * 1024)
             MIVIT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(pw * w2)));
