@@ -102,6 +102,9 @@ int mivit_wavestream_dgrad(const void *dy, int64_t lddy, const void *W_bf16, int
  * fwd:   y = act(x W^T + bias) (+ resid), optional pre-activation copy;   dgrad: dx = (dy W) * act'(saved) (+ dres).
  * N (fwd) / K (dgrad) multiple of 128, contraction length multiple of 64, M >= 256; returns 3 otherwise. */
 int mivit_gemm_dma_supported(int M, int N, int K, int dgrad);
+/* Tile variant of the sizing sweep (BASELINE config 4's "MFMA tile + LDS sizing"; table in DESIGN.md 4a): 0 = default,
+ * 19 = first-generation 8 x (32 x 128) tile, 20..27 = transposed-product tiles.  Returns the previous value. */
+int mivit_gemm_dma_set_variant(int variant);
 int mivit_gemm_dma_fwd(const void *x, int64_t ldx, const void *W_bf16, const float *bias, int M, int N, int K, int act,
                        const void *resid, int64_t ldr, void *y, int64_t ldy, void *y_preact, void *stream);
 int mivit_gemm_dma_dgrad(const void *dy, int64_t lddy, const void *W_bf16, int M, int N, int K, int act,

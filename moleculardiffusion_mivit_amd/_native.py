@@ -64,6 +64,7 @@ SYMBOLS = {
     "mivit_wavestream_dgrad": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int64, c_void_p,
                                        c_int64, c_void_p, c_int64, c_void_p]),
     "mivit_gemm_dma_supported": (c_int, [c_int, c_int, c_int, c_int]),
+    "mivit_gemm_dma_set_variant": (c_int, [c_int]),
     "mivit_gemm_dma_fwd": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int64,
                                    c_void_p, c_int64, c_void_p, c_void_p]),
     "mivit_gemm_dma_dgrad": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int64, c_void_p,

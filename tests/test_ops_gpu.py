@@ -273,10 +273,23 @@ def test_wgrad_dma_exact(M, N, K):
     assert torch.equal(db.cpu(), dy.double().sum(0).float())
 
 
+GEMM_DMA_TILES = [0, 19, 20, 21, 22, 23, 27, 30, 31, 32, 33, 37]     # csrc/gemm_dma.hip launch_variant: default, first generation, transposed-product tiles, persistent
+
+
+@pytest.fixture
+def gemm_dma_tile(request):
+    from moleculardiffusion_mivit_amd import _native as N_
+    old = N_.lib.mivit_gemm_dma_set_variant(request.param)
+    yield request.param
+    N_.lib.mivit_gemm_dma_set_variant(old)
+
+
+@pytest.mark.parametrize("gemm_dma_tile", GEMM_DMA_TILES, indirect=True)
 @pytest.mark.parametrize("M,N,K", [(256, 128, 128), (1000, 512, 512), (4130, 1536, 512), (777, 512, 1024), (300, 1024, 576)])
-@pytest.mark.parametrize("variant", ["plain", "relu_preact", "resid"])
-def test_gemm_dma_forward_exact(M, N, K, variant):
-    """Wide-layer LDS-DMA GEMM (csrc/gemm_dma.hip), forward, on small integers: exact up to the final bf16 rounding."""
+@pytest.mark.parametrize("variant", ["plain", "relu_preact", "resid", "gelu"])
+def test_gemm_dma_forward_exact(M, N, K, variant, gemm_dma_tile):
+    """Wide-layer LDS-DMA GEMM (csrc/gemm_dma.hip), forward, on small integers: exact up to the final bf16 rounding
+    (every tile variant of the sizing sweep; ragged last row tile; K = 576 is not a multiple of 64 but of 32)."""
     import ctypes
     from moleculardiffusion_mivit_amd import _native as N_
     assert N_.lib.mivit_gemm_dma_supported(M, N, K, 0)
@@ -285,22 +298,27 @@ def test_gemm_dma_forward_exact(M, N, K, variant):
     p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())   # noqa: E731
     xg, Wg, bg, rg = x.bfloat16().cuda(), W.bfloat16().cuda(), b.cuda(), r.bfloat16().cuda()
     y = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
-    pre = torch.empty_like(y) if variant == "relu_preact" else None
+    pre = torch.empty_like(y) if variant in ("relu_preact", "gelu") else None
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    N_.check(N_.lib.mivit_gemm_dma_fwd(p(xg), K, p(Wg), p(bg), M, N, K, 1 if variant == "relu_preact" else 0,
+    act = {"relu_preact": 1, "gelu": 3}.get(variant, 0)
+    N_.check(N_.lib.mivit_gemm_dma_fwd(p(xg), K, p(Wg), p(bg), M, N, K, act,
                                        p(rg) if variant == "resid" else None, N, p(y), N, p(pre), st), "gemm_dma_fwd")
     u = x.double() @ W.double().t() + b.double()
     ref = torch.relu(u) if variant == "relu_preact" else u
     if variant == "resid":
         ref = ref + r.double()
-    assert torch.equal(y.float().cpu(), ref.float().bfloat16().float())
+    if variant == "gelu":
+        assert (y.float().cpu() - torch.nn.functional.gelu(u.float())).abs().max() <= 2e-2 * u.abs().max()
+    else:
+        assert torch.equal(y.float().cpu(), ref.float().bfloat16().float())
     if pre is not None:
         assert torch.equal(pre.float().cpu(), u.float().bfloat16().float())
 
 
+@pytest.mark.parametrize("gemm_dma_tile", GEMM_DMA_TILES, indirect=True)
 @pytest.mark.parametrize("M,N,K", [(256, 128, 128), (1000, 512, 512), (4130, 1536, 512), (777, 1024, 512), (300, 576, 1024)])
 @pytest.mark.parametrize("variant", ["plain", "dact_relu", "dres"])
-def test_gemm_dma_dgrad_exact(M, N, K, variant):
+def test_gemm_dma_dgrad_exact(M, N, K, variant, gemm_dma_tile):
     """dx[M,K] = dy[M,N] @ W[N,K] (* relu'(saved)) (+ dres): W tile consumed through transposed LDS reads."""
     import ctypes
     from moleculardiffusion_mivit_amd import _native as N_
