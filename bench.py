@@ -310,11 +310,11 @@ def main():
         # encoder-layer family (everything between the embedding LayerNorm and the final norm, forward + backward): HBM-bound
         # at these widths.  Algorithmic bytes = what the launches must move given what is kept for the backward, in units of
         # U = one [tokens, E] activation: per layer forward 8 U (attention block: x in, n1 + ctx + q|k|v out; feed-forward
-        # block: n1 in, n2 out), backward 27 U (feed-forward block 4; LayerNorm-1 3; out-proj wgrad 2 + dgrad 2; attention
-        # 7; q|k|v wgrad 4 + dgrad 5) -- see DESIGN.md section 6.
+        # block: n1 in, n2 out), backward 25 U (feed-forward block 4; LayerNorm-1 + out-projection wgrad + dgrad in one pass
+        # 5; attention 7; q|k|v wgrad 4 + dgrad 5) -- see DESIGN.md section 6.
         S = T + 1
         U = Bg * S * E * ts
-        layer_bytes = L * 35 * U
+        layer_bytes = L * 33 * U
         layer_ms = sum(cat[k][0] for k in layer_tags)
         roof_layers = {"kernels": list(layer_tags), "bound": "hbm", "achieved": round(layer_bytes / (layer_ms * 1e-3) / 1e9, 1),
                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(layer_bytes / (layer_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),

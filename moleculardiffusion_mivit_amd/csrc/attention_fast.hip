@@ -58,24 +58,11 @@ __device__ __forceinline__ bf16x8 pack_frag(const f32x4 a, const f32x4 b) {
 }
 
 
-__device__ __forceinline__ float g16_max(float v) {
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
-}
-__device__ __forceinline__ float g16_sum(float v) {
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-__device__ __forceinline__ float x4_max(float v) {   // across the 4 lane groups (same lane & 15)
-    v = fmaxf(v, __shfl_xor(v, 16, 64));
-    return fmaxf(v, __shfl_xor(v, 32, 64));
-}
-__device__ __forceinline__ float x4_sum(float v) {
-    v += __shfl_xor(v, 16, 64);
-    return v + __shfl_xor(v, 32, 64);
-}
+// reductions over the 16 lanes of a row / across the 4 rows: DPP and permlane-swap forms (common.h), no LDS round trips
+__device__ __forceinline__ float g16_max(float v) { return row16_max(v); }
+__device__ __forceinline__ float g16_sum(float v) { return row16_sum(v); }
+__device__ __forceinline__ float x4_max(float v) { return rows4_max(v); }   // across the 4 lane groups (same lane & 15)
+__device__ __forceinline__ float x4_sum(float v) { return rows4_sum(v); }
 
 __device__ __forceinline__ void lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");

@@ -139,6 +139,43 @@ struct Mma<f16> {
     }
 };
 
+// Cross-lane reductions without the LDS crossbar.  __shfl_xor compiles to ds_bpermute_b32 (an LDS-pipe round trip per
+// step); inside a 16-lane row a DPP row rotation does the same job as a modifier of the VALU add itself, and gfx950's
+// v_permlane16_swap / v_permlane32_swap exchange 16- / 32-lane rows between two registers (both operands = v: afterwards
+// one holds the even rows twice, the other the odd rows twice, and their sum / max is the xor-16 / xor-32 butterfly step).
+// Checked lane by lane against plain loops by scripts/probe_dpp.hip.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+// all 16 lanes of a row (lanes 16r .. 16r+15) get the row's sum / max            (row_ror:8, 4, 2, 1)
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_mov<0x128>(v); v += dpp_mov<0x124>(v); v += dpp_mov<0x122>(v); return v + dpp_mov<0x121>(v);
+}
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, dpp_mov<0x128>(v)); v = fmaxf(v, dpp_mov<0x124>(v)); v = fmaxf(v, dpp_mov<0x122>(v)); return fmaxf(v, dpp_mov<0x121>(v));
+}
+// across the four rows (lanes l, l ^ 16, l ^ 32, l ^ 48): every lane gets the sum / max.  The instruction is written out:
+// with __builtin_amdgcn_permlane{16,32}_swap this compiler (ROCm 7.2) hands back result[1] in the register of result[0]
+// (scripts/probe_dpp.hip: every lane got 4 x its own value).  The s_nop pads cover the VALU -> permlane hazards the
+// compiler does not see through inline asm.
+__device__ __forceinline__ void rows_swap32(float &a, float &b) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void rows_swap16(float &a, float &b) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ float rows4_sum(float v) {
+    float a = v, b = v;
+    rows_swap32(a, b);
+    float t = a + b, c = t;
+    rows_swap16(t, c);
+    return t + c;
+}
+__device__ __forceinline__ float rows4_max(float v) {
+    float a = v, b = v;
+    rows_swap32(a, b);
+    float t = fmaxf(a, b), c = t;
+    rows_swap16(t, c);
+    return fmaxf(t, c);
+}
+
 // wave-level helpers (wave = 64 lanes)
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

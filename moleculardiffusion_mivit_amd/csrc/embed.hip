@@ -346,8 +346,13 @@ __global__ __launch_bounds__(NW * 64) void embed_fwd_direct(const EmbFwdArgs a) 
             for (int j = 0; j < 8; ++j) {
                 const int n = j * 16 + cq, sw = (n >> 1) & 7;
                 const unsigned char *row = Bs + n * 128 + 8 * (g & 1);
-                const uint2 lo = *reinterpret_cast<const uint2 *>(row + ((4 * kk + (g >> 1)) ^ sw) * 16);
-                const uint2 hi = *reinterpret_cast<const uint2 *>(row + ((4 * kk + 2 + (g >> 1)) ^ sw) * 16);
+                // volatile: keeps these as ds_read_b64 (64-bank rule, this image is conflict-free under it).  Left alone the
+                // compiler pairs the reads of two column tiles into ds_read2st64_b64, which banks modulo 32 and runs at half the
+                // rate: lanes cq and cq ^ 1 (rows 128 B apart) then collide -- SQ_LDS_BANK_CONFLICT 0.49 of the LDS-active cycles
+                typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                typedef __attribute__((address_space(3))) const volatile u32x2 lds_u32x2;
+                const u32x2 lo = *(lds_u32x2 *)(row + ((4 * kk + (g >> 1)) ^ sw) * 16);
+                const u32x2 hi = *(lds_u32x2 *)(row + ((4 * kk + 2 + (g >> 1)) ^ sw) * 16);
                 const bf16x8 bf = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
 #pragma unroll
                 for (int i = 0; i < TMW; ++i) acc[i][j] = mma(af[i], bf, acc[i][j]);

@@ -61,12 +61,8 @@ __device__ __forceinline__ bf16x8 pack8(const f32x4 a, const f32x4 b) {
     f[4] = (__bf16)b[0]; f[5] = (__bf16)b[1]; f[6] = (__bf16)b[2]; f[7] = (__bf16)b[3];
     return f;
 }
-__device__ __forceinline__ float x4_sum(float v) { v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64); }
-__device__ __forceinline__ float g16_sum(float v) {
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
+__device__ __forceinline__ float x4_sum(float v) { return rows4_sum(v); }   // common.h: permlane-swap / DPP forms
+__device__ __forceinline__ float g16_sum(float v) { return row16_sum(v); }
 __device__ __forceinline__ bf16x8 lds_frag(const bf16 *p) { return *reinterpret_cast<const bf16x8 *>(p); }
 __device__ __forceinline__ void unpack8(const uint4 &u, float (&v)[8]) {
     const uint32_t w[4] = {u.x, u.y, u.z, u.w};

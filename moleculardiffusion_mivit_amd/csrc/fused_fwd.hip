@@ -41,14 +41,8 @@ __device__ __forceinline__ bf16x8 pack8(const f32x4 a, const f32x4 b) {
     f[4] = (__bf16)b[0]; f[5] = (__bf16)b[1]; f[6] = (__bf16)b[2]; f[7] = (__bf16)b[3];
     return f;
 }
-__device__ __forceinline__ float x4_sum(float v) {   // across the 4 lane groups (same lane & 15)
-    v += __shfl_xor(v, 16, 64);
-    return v + __shfl_xor(v, 32, 64);
-}
-__device__ __forceinline__ float x4_max(float v) {
-    v = fmaxf(v, __shfl_xor(v, 16, 64));
-    return fmaxf(v, __shfl_xor(v, 32, 64));
-}
+__device__ __forceinline__ float x4_sum(float v) { return rows4_sum(v); }   // across the 4 lane groups (same lane & 15): common.h
+__device__ __forceinline__ float x4_max(float v) { return rows4_max(v); }
 __device__ __forceinline__ f32x4 ld4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
 __device__ __forceinline__ bf16x8 lds_frag(const bf16 *p) { return *reinterpret_cast<const bf16x8 *>(p); }
 
