@@ -14,8 +14,13 @@ SOURCES = ["gemm.hip", "norm.hip", "attention.hip", "attention_fast.hip", "embed
 HEADERS = [os.path.join(HERE, "common.h"), os.path.join(HERE, "stream_prims.h"), os.path.join(ROOT, "include", "mivit_hip.h")]
 LIB = os.path.join(PKG, "libmivit_hip.so")
 OBJDIR = os.path.join(HERE, "build")
+# -amdgpu-mfma-vgpr-form: MFMA results in arch VGPRs where they fit.  By default the accumulators go to AGPRs and every value a
+# VALU instruction consumes afterwards (softmax, bias, packing, stores) costs a v_accvgpr_read first: attention_fast.hip 23 k
+# -> 5 k such moves, attn_block_fwd 1149 -> 238 per sequence (470 -> 358 registers), the scratch spills of mlp_block_fwd gone,
+# wgrad / gemm kernels 144-252 -> 94-186 registers.  Kernels that need more than 256 accumulators + operands (mlp_block_bwd,
+# the 128 x 128 wave tile) still get AGPRs for the part that does not fit.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
-         "-Wno-unused-variable", "-fno-gpu-rdc"]
+         "-Wno-unused-variable", "-fno-gpu-rdc", "-mllvm", "-amdgpu-mfma-vgpr-form"]
 
 
 def _hipcc():
@@ -39,7 +44,7 @@ def build(force=False, verbose=True):
     for src in SOURCES:
         s = os.path.join(HERE, src)
         o = os.path.join(OBJDIR, src.replace(".hip", ".o"))
-        if force or _stale(o, [s] + HEADERS):
+        if force or _stale(o, [s, os.path.abspath(__file__)] + HEADERS):        # the flags live in this file
             jobs.append((s, o))
 
     def compile_one(job):
