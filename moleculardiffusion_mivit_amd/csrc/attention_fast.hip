@@ -70,6 +70,11 @@ __device__ __forceinline__ void lds_sync() {
 }
 
 // stage a natural [S][Dh] head slice into an LDS image of NTP*16 rows (rows >= S zero), 16-byte chunks
+// SWZ (Dh = 32 only: 64-byte rows, no padding): the two 32-byte halves of rows 4..7 (mod 8) are exchanged.  A transposing
+// read (two 32-lane groups, 64 banks) touches 8 consecutive rows x 32 bytes; rows r and r + 4 of an unpadded 64-byte-row
+// image start on the same banks, so with the exchange they use opposite halves of their 16-bank window: conflict-free,
+// where the padded 80-byte pitch was 2-way on every such read (SQ_LDS_BANK_CONFLICT 0.24 of the LDS-active cycles).
+template <bool SWZ = false>
 __device__ __forceinline__ void stage_nat(bf16 *img, int ld, const bf16 *src, int64_t src_ld, int S, int rows, int Dh,
                                           int lane) {
     const int cpr = Dh >> 3;
@@ -77,7 +82,7 @@ __device__ __forceinline__ void stage_nat(bf16 *img, int ld, const bf16 *src, in
         const int r = u / cpr, d = (u % cpr) * 8;
         uint4 v = make_uint4(0u, 0u, 0u, 0u);
         if (r < S) v = *reinterpret_cast<const uint4 *>(src + (int64_t)r * src_ld + d);
-        *reinterpret_cast<uint4 *>(img + r * ld + d) = v;
+        *reinterpret_cast<uint4 *>(img + r * ld + (SWZ ? (d ^ (((r >> 2) & 1) << 4)) : d)) = v;
     }
 }
 
@@ -362,10 +367,12 @@ __device__ __forceinline__ k16_t pack4(const f32x4 a) {
     return __builtin_bit_cast(k16_t, f);
 }
 // operand with k = tokens t0 + 4g + 0..3 (t0 already includes 4g), lane index = column col0 + (lane & 15)
+template <bool SWZ = false>
 __device__ __forceinline__ k16_t tr4(const bf16 *img, int ld, int trow, int col0, int lane) {
     const int i = lane & 15, q = i >> 2, p = i & 3;
     typedef __attribute__((address_space(3))) s16x4 lds_v4;
-    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4 *)(img + (trow + q) * ld + col0 + 4 * p));
+    const int row = trow + q, col = col0 + 4 * p;
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4 *)(img + row * ld + (SWZ ? (col ^ (((row >> 2) & 1) << 4)) : col)));
 }
 __device__ __forceinline__ f32x4 mma16(k16_t a, k16_t b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
@@ -375,6 +382,7 @@ template <int NT, int ND>
 __global__ __launch_bounds__(256, (NT * ND <= 6 ? 3 : 1)) void attn_bwd_fast2(const bf16 *qkv, const bf16 *dctx, bf16 *dqkv, const FastDims d) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int KD = (ND + 1) / 2;
+    constexpr bool SWZ = ND == 2;          // 64-byte rows: unpadded images with the half-row exchange (launcher sets d.ld = 32)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pair = blockIdx.x * (blockDim.x >> 6) + wave;
     if (pair >= d.B * d.H) return;
@@ -385,9 +393,9 @@ __global__ __launch_bounds__(256, (NT * ND <= 6 ? 3 : 1)) void attn_bwd_fast2(co
     const int64_t ld3 = 3 * (int64_t)d.E;
     const bf16 *q = qkv + (int64_t)b * d.S * ld3 + h * d.Dh, *k = q + d.E, *v = q + 2 * d.E;
     const bf16 *dO = dctx + (int64_t)b * d.S * d.E + h * d.Dh;
-    stage_nat(Qimg, d.ld, q, ld3, d.S, NT * 16, d.Dh, lane);
-    stage_nat(Kimg, d.ld, k, ld3, d.S, NT * 16, d.Dh, lane);
-    stage_nat(Oimg, d.ld, dO, d.E, d.S, NT * 16, d.Dh, lane);
+    stage_nat<SWZ>(Qimg, d.ld, q, ld3, d.S, NT * 16, d.Dh, lane);
+    stage_nat<SWZ>(Kimg, d.ld, k, ld3, d.S, NT * 16, d.Dh, lane);
+    stage_nat<SWZ>(Oimg, d.ld, dO, d.E, d.S, NT * 16, d.Dh, lane);
     bf16x8 kf[NT][KD], vf[NT][KD];
 #pragma unroll
     for (int j = 0; j < NT; ++j)
@@ -459,8 +467,8 @@ __global__ __launch_bounds__(256, (NT * ND <= 6 ? 3 : 1)) void attn_bwd_fast2(co
             // of the 16-deep MFMA is its TRANSPOSE: A[row = key][k = query] -- which is what lane cq = key, k = 4g + r holds
 #pragma unroll
             for (int jd = 0; jd < ND; ++jd) {
-                const k16_t bo = tr4(Oimg, d.ld, it * 16 + 4 * g, jd * 16, lane);
-                const k16_t bq = tr4(Qimg, d.ld, it * 16 + 4 * g, jd * 16, lane);
+                const k16_t bo = tr4<SWZ>(Oimg, d.ld, it * 16 + 4 * g, jd * 16, lane);
+                const k16_t bq = tr4<SWZ>(Qimg, d.ld, it * 16 + 4 * g, jd * 16, lane);
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
                     dv[j][jd] = mma16(pack4(sc[j]), bo, dv[j][jd]);
@@ -483,7 +491,7 @@ __global__ __launch_bounds__(256, (NT * ND <= 6 ? 3 : 1)) void attn_bwd_fast2(co
                 f32x4 dq = zero;
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
-                    dq = mma16(tr4(Simg, 16, j * 16 + 4 * g, 0, lane), tr4(Kimg, d.ld, j * 16 + 4 * g, jd * 16, lane), dq);
+                    dq = mma16(tr4(Simg, 16, j * 16 + 4 * g, 0, lane), tr4<SWZ>(Kimg, d.ld, j * 16 + 4 * g, jd * 16, lane), dq);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = it * 16 + 4 * g + r;
@@ -542,7 +550,8 @@ int bwd_launch(const bf16 *qkv, const bf16 *dctx, bf16 *dqkv, const FastDims &d,
     auto kern = version == 2 ? attn_bwd_fast2<NT, ND> : attn_bwd_fast<NT, ND>;
     if (version == 2) {        // the 16-deep version needs NT * 16 image rows, not the pair-padded NP * 32: more waves fit a CU
         FastDims d2 = d;
-        d2.img = NT * 16 * d.ld;
+        if (ND == 2) d2.ld = 32;             // unpadded rows + half-row exchange (conflict-free transposing reads)
+        d2.img = NT * 16 * d2.ld;
         const size_t pw = ((size_t)3 * d2.img + NT * 256) * sizeof(bf16);
         const int w2 = waves_per_block(pw);
         if (pw * w2 > 64 * 1024)
