@@ -553,7 +553,7 @@ int bwd_launch(const bf16 *qkv, const bf16 *dctx, bf16 *dqkv, const FastDims &d,
         if (ND == 2) d2.ld = 32;             // unpadded rows + half-row exchange (conflict-free transposing reads)
         d2.img = NT * 16 * d2.ld;
         const size_t pw = ((size_t)3 * d2.img + NT * 256) * sizeof(bf16);
-        const int w2 = waves_per_block(pw);
+        const int w2 = waves_per_block(pw);       // (15 waves per CU in 3-wave workgroups at <= 128 registers: 25 spilled registers, 1.44 -> 2.25 ms per step)
         if (pw * w2 > 64 * 1024)
             MIVIT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(pw * w2)));
         ProfScope prof(s);
