@@ -393,18 +393,61 @@ __global__ __launch_bounds__(256, (NT * ND <= 6 ? 3 : 1)) void attn_bwd_fast2(co
     const int64_t ld3 = 3 * (int64_t)d.E;
     const bf16 *q = qkv + (int64_t)b * d.S * ld3 + h * d.Dh, *k = q + d.E, *v = q + 2 * d.E;
     const bf16 *dO = dctx + (int64_t)b * d.S * d.E + h * d.Dh;
-    stage_nat<SWZ>(Qimg, d.ld, q, ld3, d.S, NT * 16, d.Dh, lane);
-    stage_nat<SWZ>(Kimg, d.ld, k, ld3, d.S, NT * 16, d.Dh, lane);
-    stage_nat<SWZ>(Oimg, d.ld, dO, d.E, d.S, NT * 16, d.Dh, lane);
+    // Every global load of the prologue is issued before the first wait.  (The staging helper's loop has a run-time trip
+    // count: left as three calls it compiled to load -> s_waitcnt vmcnt(0) -> ds_write per 64 chunks, i.e. NINE serialised
+    // memory round trips at the start of every wave, and the per-row-tile q / dO fragment loads added three more.)
+    constexpr int CPR = ND * 2, NCH = NT * 16 * CPR, NIT = (NCH + 63) / 64;       // 16-byte chunks per image, per lane
+    constexpr bool BATCH = NIT <= 4 && NT <= 4;      // (longer sequences hold more accumulators: no room for the staging registers)
     bf16x8 kf[NT][KD], vf[NT][KD];
+    if (BATCH) {
+        uint4 sq[NIT], sk[NIT], so[NIT];
+        auto ld_nat = [&](const bf16 *src, int64_t sld, uint4 (&v)[NIT]) {
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
+            for (int i = 0; i < NIT; ++i) {
+                const int u = lane + 64 * i, r = u / CPR, dd = (u % CPR) * 8;
+                v[i] = make_uint4(0u, 0u, 0u, 0u);
+                if (u < NCH && r < d.S && dd + 8 <= d.Dh) v[i] = *reinterpret_cast<const uint4 *>(src + (int64_t)r * sld + dd);
+            }
+        };
+        auto st_nat = [&](bf16 *img, const uint4 (&v)[NIT]) {
 #pragma unroll
-        for (int kd = 0; kd < KD; ++kd) {
-            kf[j][kd] = gfrag(k, ld3, j * 16, d.S, kd * 32, d.Dh, lane);
-            vf[j][kd] = gfrag(v, ld3, j * 16, d.S, kd * 32, d.Dh, lane);
-        }
+            for (int i = 0; i < NIT; ++i) {
+                const int u = lane + 64 * i, r = u / CPR, dd = (u % CPR) * 8;
+                if (u < NCH) *reinterpret_cast<uint4 *>(img + r * d.ld + (SWZ ? (dd ^ (((r >> 2) & 1) << 4)) : dd)) = v[i];
+            }
+        };
+        ld_nat(q, ld3, sq); ld_nat(k, ld3, sk); ld_nat(dO, d.E, so);
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int kd = 0; kd < KD; ++kd) {
+                vf[j][kd] = gfrag(v, ld3, j * 16, d.S, kd * 32, d.Dh, lane);
+                if (!SWZ) kf[j][kd] = gfrag(k, ld3, j * 16, d.S, kd * 32, d.Dh, lane);
+            }
+        st_nat(Qimg, sq); st_nat(Kimg, sk); st_nat(Oimg, so);
+    } else {
+        stage_nat<SWZ>(Qimg, d.ld, q, ld3, d.S, NT * 16, d.Dh, lane);
+        stage_nat<SWZ>(Kimg, d.ld, k, ld3, d.S, NT * 16, d.Dh, lane);
+        stage_nat<SWZ>(Oimg, d.ld, dO, d.E, d.S, NT * 16, d.Dh, lane);
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int kd = 0; kd < KD; ++kd) {
+                vf[j][kd] = gfrag(v, ld3, j * 16, d.S, kd * 32, d.Dh, lane);
+                if (!SWZ) kf[j][kd] = gfrag(k, ld3, j * 16, d.S, kd * 32, d.Dh, lane);
+            }
+    }
     lds_sync();
+    // SWZ (Dh = 32): row-operand fragments come out of the images just staged (one conflict-free ds_read_b128 each: with the
+    // half-row exchange the four row quads of a b128 lane group use the four different 16-byte slots), not from global memory
+    auto lfrag = [&](const bf16 *img, int row0) {
+        const int r = row0 + cq, col = 8 * g;
+        return *reinterpret_cast<const bf16x8 *>(img + r * d.ld + (col ^ (((r >> 2) & 1) << 4)));
+    };
+    if (SWZ) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) kf[j][0] = lfrag(Kimg, j * 16);
+    }
     const float scale = 1.0f / sqrtf((float)d.Dh);
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     bf16 *dst = dqkv + (int64_t)b * d.S * ld3 + h * d.Dh;
@@ -420,8 +463,11 @@ __global__ __launch_bounds__(256, (NT * ND <= 6 ? 3 : 1)) void attn_bwd_fast2(co
         bf16x8 qf[KD], of[KD];
 #pragma unroll
         for (int kd = 0; kd < KD; ++kd) {
-            qf[kd] = gfrag(q, ld3, it * 16, d.S, kd * 32, d.Dh, lane);
-            of[kd] = gfrag(dO, d.E, it * 16, d.S, kd * 32, d.Dh, lane);
+            if (SWZ) { qf[kd] = lfrag(Qimg, it * 16); of[kd] = lfrag(Oimg, it * 16); }
+            else {
+                qf[kd] = gfrag(q, ld3, it * 16, d.S, kd * 32, d.Dh, lane);
+                of[kd] = gfrag(dO, d.E, it * 16, d.S, kd * 32, d.Dh, lane);
+            }
         }
         f32x4 dS[NT];        // dS of this row tile: lane = key j*16 + cq, registers = queries it*16 + 4g + r
         {   // ---- lane = key orientation: S = Q K^T, dP = dO V^T  ->  P, dS of this row tile  ->  dV, dK ----
