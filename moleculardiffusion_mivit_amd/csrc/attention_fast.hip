@@ -77,12 +77,22 @@ __device__ __forceinline__ void lds_sync() {
 template <bool SWZ = false>
 __device__ __forceinline__ void stage_nat(bf16 *img, int ld, const bf16 *src, int64_t src_ld, int S, int rows, int Dh,
                                           int lane) {
-    const int cpr = Dh >> 3;
-    for (int u = lane; u < rows * cpr; u += 64) {
-        const int r = u / cpr, d = (u % cpr) * 8;
-        uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (r < S) v = *reinterpret_cast<const uint4 *>(src + (int64_t)r * src_ld + d);
-        *reinterpret_cast<uint4 *>(img + r * ld + (SWZ ? (d ^ (((r >> 2) & 1) << 4)) : d)) = v;
+    const int cpr = Dh >> 3, n = rows * cpr;
+    // four chunks in flight per lane: one load -> wait -> store per iteration (what this run-time loop compiled to) costs a
+    // memory round trip per 64 chunks -- 30 of them in a row for three 80-row x 64-wide images
+    for (int u0 = lane; u0 < n; u0 += 4 * 64) {
+        uint4 v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int u = u0 + 64 * i, r = u / cpr, d = (u % cpr) * 8;
+            v[i] = make_uint4(0u, 0u, 0u, 0u);
+            if (u < n && r < S) v[i] = *reinterpret_cast<const uint4 *>(src + (int64_t)r * src_ld + d);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int u = u0 + 64 * i, r = u / cpr, d = (u % cpr) * 8;
+            if (u < n) *reinterpret_cast<uint4 *>(img + r * ld + (SWZ ? (d ^ (((r >> 2) & 1) << 4)) : d)) = v[i];
+        }
     }
 }
 

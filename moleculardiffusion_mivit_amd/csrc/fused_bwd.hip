@@ -82,9 +82,20 @@ __global__ __launch_bounds__(NT) void mlp_block_bwd_kernel(const MlpBwdArgs a) {
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 
     // ---- one-time staging ----
-    for (int i = tid; i < F * (E / 8); i += NT) {
-        const int n = i / (E / 8), cc = i - n * (E / 8);
-        *reinterpret_cast<uint4 *>(W1i + n * LDE + cc * 8) = *reinterpret_cast<const uint4 *>(a.W1 + (int64_t)n * E + cc * 8);
+    // (four loads in flight per thread: one load -> wait -> store per iteration is 16 serialised L2 round trips per workgroup)
+    static_assert((F * (E / 8)) % (4 * NT) == 0, "W1 staging batches");
+    for (int i0 = tid; i0 < F * (E / 8); i0 += 4 * NT) {
+        uint4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * NT, n = i / (E / 8), cc = i - n * (E / 8);
+            v[u] = *reinterpret_cast<const uint4 *>(a.W1 + (int64_t)n * E + cc * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * NT, n = i / (E / 8), cc = i - n * (E / 8);
+            *reinterpret_cast<uint4 *>(W1i + n * LDE + cc * 8) = v[u];
+        }
     }
     for (int n = tid; n < F; n += NT) b1f[n] = a.b1[n];
     for (int i = tid; i < E; i += NT) { b1f[F + i] = a.gamma2[i]; b1f[F + E + i] = a.gamma1[i]; b1f[F + 2 * E + i] = a.beta1[i]; }

@@ -59,22 +59,44 @@ __device__ __forceinline__ void store4_bf16(bf16 *p, const f32x4 v) {
 }
 
 // natural [rows][K] bf16 weight block (row pitch ldw elements) -> LDS operand image with pitch LD
+// The staging loops issue SU iterations' loads before the first store: with one load -> wait -> store per iteration (what a
+// loop with a run-time trip count compiles to) a workgroup spent 24 + 8 + ... serialised L2 round trips on its weights.
+constexpr int SU = 8;
 template <int K, int LD>
 __device__ __forceinline__ void stage_natural(bf16 *img, const bf16 *W, int rows, int tid, int nthr = NTHREADS) {
-    for (int i = tid; i < rows * (K / 8); i += nthr) {
-        const int r = i / (K / 8), c = i - r * (K / 8);
-        *reinterpret_cast<uint4 *>(img + r * LD + c * 8) = *reinterpret_cast<const uint4 *>(W + (int64_t)r * K + c * 8);
+    const int n = rows * (K / 8);
+    for (int i0 = tid; i0 < n; i0 += SU * nthr) {
+        uint4 v[SU];
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+            const int i = min(i0 + u * nthr, n - 1), r = i / (K / 8), c = i - r * (K / 8);          // (clamped: always a valid load)
+            v[u] = *reinterpret_cast<const uint4 *>(W + (int64_t)r * K + c * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+            const int i = i0 + u * nthr, r = i / (K / 8), c = i - r * (K / 8);
+            if (i < n) *reinterpret_cast<uint4 *>(img + r * LD + c * 8) = v[u];
+        }
     }
 }
 // the same with the contraction index permuted inside each block of 32 so that the 16-byte chunk g of block p holds
 // k = 32p + 4g + {0..3} and k = 32p + 16 + 4g + {0..3}: the operand that meets a packed accumulator pair
 template <int K, int LD>
 __device__ __forceinline__ void stage_permuted(bf16 *img, const bf16 *W, int rows, int tid, int nthr = NTHREADS) {
-    for (int i = tid; i < rows * (K / 8); i += nthr) {
-        const int r = i / (K / 8), c = i - r * (K / 8), p = c >> 2, g = c & 3;
-        const uint2 lo = *reinterpret_cast<const uint2 *>(W + (int64_t)r * K + 32 * p + 4 * g);
-        const uint2 hi = *reinterpret_cast<const uint2 *>(W + (int64_t)r * K + 32 * p + 16 + 4 * g);
-        *reinterpret_cast<uint4 *>(img + r * LD + c * 8) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+    const int n = rows * (K / 8);
+    for (int i0 = tid; i0 < n; i0 += SU * nthr) {
+        uint2 lo[SU], hi[SU];
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+            const int i = min(i0 + u * nthr, n - 1), r = i / (K / 8), c = i - r * (K / 8), p = c >> 2, g = c & 3;
+            lo[u] = *reinterpret_cast<const uint2 *>(W + (int64_t)r * K + 32 * p + 4 * g);
+            hi[u] = *reinterpret_cast<const uint2 *>(W + (int64_t)r * K + 32 * p + 16 + 4 * g);
+        }
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+            const int i = i0 + u * nthr, r = i / (K / 8), c = i - r * (K / 8);
+            if (i < n) *reinterpret_cast<uint4 *>(img + r * LD + c * 8) = make_uint4(lo[u].x, lo[u].y, hi[u].x, hi[u].y);
+        }
     }
 }
 __device__ __forceinline__ void stage_vec(float *dst, const float *src, int n, float fill, int tid, int nthr = NTHREADS) {
@@ -97,14 +119,28 @@ __device__ __forceinline__ bf16x8 as_frag(const uint4 &u) { return __builtin_bit
 template <int K, int LD>
 __device__ __forceinline__ void stage_folded(bf16 *img, const bf16 *W, int rows, const float *gam, int tid, int nthr = NTHREADS,
                                              int rs_rows = 0, float rs_val = 1.f) {      // rows < rs_rows are scaled by rs_val
-    for (int i = tid; i < rows * (K / 8); i += nthr) {
-        const int r = i / (K / 8), c = i - r * (K / 8);
-        const float rsc = r < rs_rows ? rs_val : 1.f;
-        float v[8];
-        load16(W + (int64_t)r * K + c * 8, v);
+    const int n = rows * (K / 8);
+    for (int i0 = tid; i0 < n; i0 += SU * nthr) {
+        uint4 raw[SU];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] *= gam[c * 8 + e] * rsc;
-        store16(img + r * LD + c * 8, v);
+        for (int u = 0; u < SU; ++u) {
+            const int i = min(i0 + u * nthr, n - 1), r = i / (K / 8), c = i - r * (K / 8);
+            raw[u] = *reinterpret_cast<const uint4 *>(W + (int64_t)r * K + c * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+            const int i = i0 + u * nthr, r = i / (K / 8), c = i - r * (K / 8);
+            if (i < n) {
+                const float rsc = r < rs_rows ? rs_val : 1.f;
+                const uint32_t w[4] = {raw[u].x, raw[u].y, raw[u].z, raw[u].w};
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[2 * e] = __uint_as_float(w[e] << 16); v[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u); }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= gam[c * 8 + e] * rsc;
+                store16(img + r * LD + c * 8, v);
+            }
+        }
     }
 }
 // dst[r] = b[r] + sum_k W[r][k] beta[k]   (beta == nullptr: plain copy)
@@ -114,6 +150,7 @@ __device__ __forceinline__ void fold_bias(float *dst, const float *b, const bf16
     for (int r = tid; r < rows; r += nthr) {
         float acc = b ? b[r] : 0.f;
         if (fold) {
+#pragma unroll
             for (int c = 0; c < K / 8; ++c) {
                 float v[8];
                 load16(W + (int64_t)r * K + c * 8, v);
