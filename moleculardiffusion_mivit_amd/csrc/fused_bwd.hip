@@ -37,7 +37,8 @@ constexpr int OFF_DH = OFF_DZ + R * LDE * 2;         // [R][LDF]  dh rows, hidde
 constexpr int OFF_VEC = OFF_DH + R * LDF * 2;        // b1 [F], gamma2 [E], gamma1 [E], beta1 [E] fp32
 constexpr int OFF_ACC = OFF_VEC + (F + 3 * E) * 4;               // [6][NT] float4: running column sums of the element-wise phase (dgamma2, dbeta2, db2)
 constexpr int OFF_STG = OFF_ACC + 6 * NT * 16;        // [6][NW][64] x 16 B: next tile's dy / n2 / n1 chunks, landed by LDS-DMA (thread-private slots)
-constexpr int LDS_BYTES = OFF_STG + 6 * NT * 16;
+constexpr int OFF_RST = OFF_STG + 6 * NT * 16;       // [2][NT] floats: rstd2 of the next tile's two rows per thread (LDS-DMA, thread-private slots)
+constexpr int LDS_BYTES = OFF_RST + 2 * NT * 4;
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 
 // slab layout per workgroup (floats)
@@ -70,6 +71,13 @@ __device__ __forceinline__ void unpack8(const uint4 &u, float (&v)[8]) {
     for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
 }
 
+// rows past the end were clamped to a real row: their staged chunks are zeroed IN REGISTERS.  (Written as `ok ? stg[i] : zero`
+// the compiler selects between the LDS pointer and the address of a constant zero and loads through the result: a generic
+// pointer, i.e. flat_load -- vmcnt AND lgkmcnt, out of order, so s_waitcnt vmcnt(0) in the middle of the element-wise phase.)
+__device__ __forceinline__ uint4 keep_if(const uint4 v, bool ok) {
+    const unsigned m = ok ? 0xffffffffu : 0u;
+    return make_uint4(v.x & m, v.y & m, v.z & m, v.w & m);
+}
 template <int ACT>
 __global__ __launch_bounds__(NT) void mlp_block_bwd_kernel(const MlpBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -78,6 +86,7 @@ __global__ __launch_bounds__(NT) void mlp_block_bwd_kernel(const MlpBwdArgs a) {
     float *b1f = reinterpret_cast<float *>(smem + OFF_VEC);
     f32x4 *cacc = reinterpret_cast<f32x4 *>(smem + OFF_ACC);
     uint4 *stg = reinterpret_cast<uint4 *>(smem + OFF_STG);
+    float *rst = reinterpret_cast<float *>(smem + OFF_RST);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, cq = lane & 15, q = cq >> 2, pp = cq & 3;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 
@@ -115,7 +124,11 @@ __global__ __launch_bounds__(NT) void mlp_block_bwd_kernel(const MlpBwdArgs a) {
     }
     // this thread's slice of the element-wise phase: columns 8c .. 8c+7 of rows r0 and r0 + 16 of the tile
     const int c = tid & 15, r0 = tid >> 4;
-    const float *gam2 = b1f + F + 8 * c, *gam1 = b1f + F + E + 8 * c, *bet1 = b1f + F + 2 * E + 8 * c;     // (LDS: free registers)
+    // LDS-typed pointers: as plain `const float *` they were kept across the tile loop as generic addresses and every read became
+    // a flat_load (vmcnt AND lgkmcnt, out of order -> s_waitcnt vmcnt(0) in the element-wise phase, i.e. a wait for the previous
+    // tile's store acks)
+    typedef __attribute__((address_space(3))) const float lds_cf;
+    lds_cf *gam2 = (lds_cf *)(b1f + F + 8 * c), *gam1 = (lds_cf *)(b1f + F + E + 8 * c), *bet1 = (lds_cf *)(b1f + F + 2 * E + 8 * c);
 #pragma unroll
     for (int i = 0; i < 6; ++i) cacc[i * NT + tid] = f32x4{0.f, 0.f, 0.f, 0.f};       // (thread-private slots: no barrier needed)
     f32x4 dW1[4][8], dW2[8][4];
@@ -130,16 +143,15 @@ __global__ __launch_bounds__(NT) void mlp_block_bwd_kernel(const MlpBwdArgs a) {
     int tile = blockIdx.x;
     // next tile's rows travel global -> LDS by DMA into slots only this thread reads back: no registers held across the
     // compute phases, no barrier -- the issuing wave's vmcnt wait is the only ordering needed
-    float prs[2];
     auto prefetch = [&](int t) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int64_t row = min((int64_t)t * R + r0 + 16 * i, (int64_t)a.M - 1);
             const int64_t o = row * E + 8 * c;
-            dma16(a.dy + o, stg + (3 * i + 0) * NT + wave * 64);
-            dma16(a.n2 + o, stg + (3 * i + 1) * NT + wave * 64);
-            dma16(a.n1 + o, stg + (3 * i + 2) * NT + wave * 64);
-            prs[i] = ((int64_t)t * R + r0 + 16 * i < a.M) ? a.rstd2[row] : 0.f;
+            dma16_opaque(a.dy + o, stg + (3 * i + 0) * NT + wave * 64);
+            dma16_opaque(a.n2 + o, stg + (3 * i + 1) * NT + wave * 64);
+            dma16_opaque(a.n1 + o, stg + (3 * i + 2) * NT + wave * 64);
+            dma4_opaque(a.rstd2 + row, rst + i * NT + wave * 64);
         }
     };
     if (tile < ntiles) prefetch(tile);
@@ -159,9 +171,8 @@ __global__ __launch_bounds__(NT) void mlp_block_bwd_kernel(const MlpBwdArgs a) {
             for (int i = 0; i < 2; ++i) {
                 float d[8], nh[8], gdy[8];
                 const bool ok = row0 + r0 + 16 * i < a.M;          // rows past the end were clamped to a real row: cancel them
-                const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
-                const uint4 pdy = ok ? stg[(3 * i + 0) * NT + tid] : z4, pn2 = stg[(3 * i + 1) * NT + tid];
-                const uint4 pn1 = ok ? stg[(3 * i + 2) * NT + tid] : z4;
+                const uint4 pdy = keep_if(stg[(3 * i + 0) * NT + tid], ok), pn2 = stg[(3 * i + 1) * NT + tid];
+                const uint4 pn1 = keep_if(stg[(3 * i + 2) * NT + tid], ok);
                 unpack8(pdy, d); unpack8(pn2, nh);
                 float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -172,8 +183,9 @@ __global__ __launch_bounds__(NT) void mlp_block_bwd_kernel(const MlpBwdArgs a) {
                 }
                 s1 = g16_sum(s1) * (1.f / E); s2 = g16_sum(s2) * (1.f / E);
                 float dz[8];
+                const float prs = __uint_as_float(__float_as_uint(rst[i * NT + tid]) & (ok ? 0xffffffffu : 0u));
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { dz[e] = prs[i] * (gdy[e] - s1 - nh[e] * s2); sz[e] += dz[e]; }
+                for (int e = 0; e < 8; ++e) { dz[e] = prs * (gdy[e] - s1 - nh[e] * s2); sz[e] += dz[e]; }
                 store16(DZ + (r0 + 16 * i) * LDE + 8 * c, dz);
                 float x1v[8];
                 unpack8(pn1, x1v);
@@ -187,7 +199,7 @@ __global__ __launch_bounds__(NT) void mlp_block_bwd_kernel(const MlpBwdArgs a) {
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the staging slots have been read: they may be refilled
         prefetch(min(tile + (int)gridDim.x, ntiles - 1));       // next tile's rows: in flight under phases 1 and 2
-        __syncthreads();
+        barrier();          // raw s_barrier (LDS drained): __syncthreads() also waits vmcnt(0), i.e. for the row prefetch just issued and for store acks
         // ---------------- phase 1: u, dh for this wave's 64 hidden units; dW1, dW2 ----------------
         bf16x8 hB[4], dhB[4];
 #pragma unroll
@@ -250,7 +262,7 @@ __global__ __launch_bounds__(NT) void mlp_block_bwd_kernel(const MlpBwdArgs a) {
                 xb = xn; zb = zn;
             }
         }
-        __syncthreads();
+        barrier();          // raw s_barrier (LDS drained): __syncthreads() also waits vmcnt(0), i.e. for the row prefetch just issued and for store acks
         // ---------------- phase 2: dx1^T for this wave's 32 input features ----------------
         f32x4 dx[2][2];
 #pragma unroll
@@ -295,7 +307,7 @@ __global__ __launch_bounds__(NT) void mlp_block_bwd_kernel(const MlpBwdArgs a) {
                 }
             }
         }
-        __syncthreads();
+        barrier();          // raw s_barrier (LDS drained): __syncthreads() also waits vmcnt(0), i.e. for the row prefetch just issued and for store acks
     }
 
     // ---------------- partial gradients -> this workgroup's slab ----------------
@@ -334,7 +346,8 @@ __global__ __launch_bounds__(NT) void mlp_block_bwd_kernel(const MlpBwdArgs a) {
 // ================================================================================================================
 constexpr int AO_OFF_DZ = 0, AO_OFF_CT = AO_OFF_DZ + R * LDE * 2, AO_OFF_STG = AO_OFF_CT + R * LDE * 2;
 constexpr int AO_OFF_RED = AO_OFF_STG + 6 * NT * 16;            // [NW][3][E] floats: end-of-launch fold of the column sums
-constexpr int AO_LDS = AO_OFF_RED + NW * 3 * E * 4;
+constexpr int AO_OFF_RST = AO_OFF_RED + NW * 3 * E * 4;        // [2][NT] floats: rstd1 of the next tile's rows
+constexpr int AO_LDS = AO_OFF_RST + 2 * NT * 4;
 constexpr int AO_SL_W = 0, AO_SL_B = E * E, AO_SL_G = AO_SL_B + E, AO_SL_BE = AO_SL_G + E, AO_SL_TOTAL = AO_SL_BE + E;   // arena order:
                                                                 // out_proj.weight, out_proj.bias, norm1.weight, norm1.bias
 struct AttnOutBwdArgs {
@@ -350,6 +363,7 @@ __global__ __launch_bounds__(NT, 2) void attn_out_bwd_kernel(const AttnOutBwdArg
     bf16 *DZ = reinterpret_cast<bf16 *>(smem + AO_OFF_DZ), *CT = reinterpret_cast<bf16 *>(smem + AO_OFF_CT);
     uint4 *stg = reinterpret_cast<uint4 *>(smem + AO_OFF_STG);
     float *red = reinterpret_cast<float *>(smem + AO_OFF_RED);
+    float *rst = reinterpret_cast<float *>(smem + AO_OFF_RST);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, cq = lane & 15, q = cq >> 2, pp = cq & 3;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     // row operand of dctx^T = Wo^T dz1^T for this wave's context features c = 32 wave + 16 ct + cq: A[c][e] = Wo[e][c]
@@ -378,30 +392,32 @@ __global__ __launch_bounds__(NT, 2) void attn_out_bwd_kernel(const AttnOutBwdArg
 
     const int ntiles = (a.M + R - 1) / R;
     int tile = blockIdx.x;
-    float prs[2];
     auto prefetch = [&](int t) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int64_t row = min((int64_t)t * R + r0 + 16 * i, (int64_t)a.M - 1);
             const int64_t o = row * E + 8 * c;
-            dma16(a.dy + o, stg + (3 * i + 0) * NT + wave * 64);
-            dma16(a.n1 + o, stg + (3 * i + 1) * NT + wave * 64);
-            dma16(a.ctx + o, stg + (3 * i + 2) * NT + wave * 64);
-            prs[i] = ((int64_t)t * R + r0 + 16 * i < a.M) ? a.rstd1[row] : 0.f;
+            dma16_opaque(a.dy + o, stg + (3 * i + 0) * NT + wave * 64);
+            dma16_opaque(a.n1 + o, stg + (3 * i + 1) * NT + wave * 64);
+            dma16_opaque(a.ctx + o, stg + (3 * i + 2) * NT + wave * 64);
+            dma4_opaque(a.rstd1 + row, rst + i * NT + wave * 64);
         }
     };
     if (tile < ntiles) prefetch(tile);
+    bool first = true;
     for (; tile < ntiles; tile += gridDim.x) {
         const int64_t row0 = (int64_t)tile * R;
         // ---- phase 0: LayerNorm backward, dz1 -> HBM + LDS image, ctx -> LDS image ----
-        wait_vm<0>();
+        // the staged rows were requested one tile ago; younger than them are only the four dctx row stores of the last
+        // phase 1 (every full tile issues them; the one partial tile is the last of the launch): do not wait for their acks
+        if (first) wait_vm<0>(); else wait_vm<4>();
+        first = false;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             float d[8], nh[8], gdy[8];
             const bool ok = row0 + r0 + 16 * i < a.M;
-            const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
-            const uint4 pdy = ok ? stg[(3 * i + 0) * NT + tid] : z4, pn = stg[(3 * i + 1) * NT + tid];
-            const uint4 pct = ok ? stg[(3 * i + 2) * NT + tid] : z4;
+            const uint4 pdy = keep_if(stg[(3 * i + 0) * NT + tid], ok), pn = stg[(3 * i + 1) * NT + tid];
+            const uint4 pct = keep_if(stg[(3 * i + 2) * NT + tid], ok);
             unpack8(pdy, d); unpack8(pn, nh);
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -412,15 +428,16 @@ __global__ __launch_bounds__(NT, 2) void attn_out_bwd_kernel(const AttnOutBwdArg
             }
             s1 = g16_sum(s1) * (1.f / E); s2 = g16_sum(s2) * (1.f / E);
             float dz[8];
+            const float prs = __uint_as_float(__float_as_uint(rst[i * NT + tid]) & (ok ? 0xffffffffu : 0u));
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { dz[e] = prs[i] * (gdy[e] - s1 - nh[e] * s2); sz[e] += dz[e]; }
+            for (int e = 0; e < 8; ++e) { dz[e] = prs * (gdy[e] - s1 - nh[e] * s2); sz[e] += dz[e]; }
             store16(DZ + (r0 + 16 * i) * LDE + 8 * c, dz);
             if (ok) store16(a.dz1 + (row0 + r0 + 16 * i) * E + 8 * c, dz);
             *reinterpret_cast<uint4 *>(CT + (r0 + 16 * i) * LDE + 8 * c) = pct;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         prefetch(min(tile + (int)gridDim.x, ntiles - 1));
-        __syncthreads();
+        barrier();          // raw s_barrier (LDS drained): __syncthreads() also waits vmcnt(0), i.e. for the row prefetch just issued and for store acks
         // ---- phase 1: dctx^T for this wave's 32 context features; dWo rows 32 wave .. +31 ----
         f32x4 dc[2][2] = {{zero, zero}, {zero, zero}};
 #pragma unroll
@@ -451,7 +468,7 @@ __global__ __launch_bounds__(NT, 2) void attn_out_bwd_kernel(const AttnOutBwdArg
                 dWo[et][ct] = mma(za, cb, dWo[et][ct]);                 // [e][c] += dz1^T ctx
             }
         }
-        __syncthreads();
+        barrier();          // raw s_barrier (LDS drained): __syncthreads() also waits vmcnt(0), i.e. for the row prefetch just issued and for store acks
     }
     // ---- partial gradients -> this workgroup's slab ----
     float *sl = a.slabs + (int64_t)blockIdx.x * AO_SL_TOTAL;

@@ -11,6 +11,23 @@ __device__ __forceinline__ void dma16(const void *g, void *l) {
     typedef __attribute__((address_space(3))) void lptr_t;
     __builtin_amdgcn_global_load_lds((gptr_t *)g, (lptr_t *)l, 16, 0, 0);
 }
+// The same instruction written out, for loops that also WRITE LDS while the DMA is in flight.  The compiler's waitcnt pass
+// cannot tell which LDS bytes a pending __builtin_amdgcn_global_load_lds will write: before the next ds_write it inserts
+// s_waitcnt vmcnt(0) -- which waits for the prefetch just issued and for the acks of every global store before it.  Inline asm
+// is invisible to that pass (extra unknown VM operations can only make its own counted waits stricter, never looser: they
+// retire in order); the consumer's explicit wait_vm<N>() orders the read-back.  LDS destination = wave-uniform base + lane * 16.
+__device__ __forceinline__ void dma16_opaque(const void *g, void *l) {
+    typedef __attribute__((address_space(3))) void lptr_t;
+    const unsigned base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lptr_t *)l);
+    asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(base) : "memory", "m0");
+}
+// 4 bytes per lane (LDS destination = wave-uniform base + lane * 4): per-row scalars of a prefetched tile.  A register-returning
+// load carried across the loop's back edge makes the compiler wait vmcnt(0) at its first use -- i.e. for the stores issued since.
+__device__ __forceinline__ void dma4_opaque(const void *g, void *l) {
+    typedef __attribute__((address_space(3))) void lptr_t;
+    const unsigned base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lptr_t *)l);
+    asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dword %0, off" ::"v"(g), "s"(base) : "memory", "m0");
+}
 // vector-memory operations retire in order: N = how many of this wave's youngest may still be in flight
 template <int N>
 __device__ __forceinline__ void wait_vm() {
