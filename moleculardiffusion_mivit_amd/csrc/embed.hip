@@ -435,7 +435,7 @@ __device__ __forceinline__ void wg_issue(const EmbWgArgs &a, unsigned char *slot
         const int r = inst * 4 + (lane >> 4), s = lane & 15;
         const int c = s ^ (2 * (r & 7));
         const int gm = min(mrow + r, mend - 1);
-        dma16(a.dY + (int64_t)gm * a.E + e0 + c * 8, slot + inst * 1024);
+        dma16_tracked(a.dY + (int64_t)gm * a.E + e0 + c * 8, slot + inst * 1024);
     }
     unsigned char *bs = slot + C::A_BYTES;
     constexpr int RPI = 64 / C::B_CH == 0 ? 1 : 1024 / C::B_ROW;    // X rows per wave-instruction (2 or 1)
@@ -445,7 +445,7 @@ __device__ __forceinline__ void wg_issue(const EmbWgArgs &a, unsigned char *slot
         const int r = inst * RPI + lane / C::B_CH, s = lane % C::B_CH;
         const int c = s ^ (((r >> 3) & 1) << 2);          // rows 8 apart land 16 floats (= 16 banks) apart
         const int gm = min(mrow + r, mend - 1);
-        dma16(a.X + (int64_t)gm * a.K + k0 + c * 4, bs + inst * 1024);
+        dma16_tracked(a.X + (int64_t)gm * a.K + k0 + c * 4, bs + inst * 1024);
     }
 }
 

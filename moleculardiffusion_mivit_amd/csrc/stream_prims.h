@@ -5,21 +5,26 @@
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
-// global -> LDS, 16 bytes per lane: the LDS destination is wave-uniform base + lane * 16, the source address is per lane
+// global -> LDS, 16 bytes per lane: the LDS destination is wave-uniform base + lane * 16, the source address is per lane.
+// The instruction is WRITTEN OUT rather than issued through __builtin_amdgcn_global_load_lds: the compiler's waitcnt pass cannot
+// tell which LDS bytes a pending LDS-DMA will write, so before the next ds_write -- and before LDS reads it cannot disambiguate,
+// e.g. the transposing reads of a weight image staged long ago -- it inserts s_waitcnt vmcnt(0): a wait for the prefetch just
+// issued (the ring never overlaps anything) and for the acks of every global store before it.  Inline asm is invisible to
+// that pass; unknown extra VM operations can only make its own counted waits stricter, never looser (they retire in order).
+// EVERY consumer therefore orders its read-back with an explicit wait_vm<N>() (+ barrier() where other waves' shares matter).
 __device__ __forceinline__ void dma16(const void *g, void *l) {
-    typedef __attribute__((address_space(1))) const void gptr_t;
-    typedef __attribute__((address_space(3))) void lptr_t;
-    __builtin_amdgcn_global_load_lds((gptr_t *)g, (lptr_t *)l, 16, 0, 0);
-}
-// The same instruction written out, for loops that also WRITE LDS while the DMA is in flight.  The compiler's waitcnt pass
-// cannot tell which LDS bytes a pending __builtin_amdgcn_global_load_lds will write: before the next ds_write it inserts
-// s_waitcnt vmcnt(0) -- which waits for the prefetch just issued and for the acks of every global store before it.  Inline asm
-// is invisible to that pass (extra unknown VM operations can only make its own counted waits stricter, never looser: they
-// retire in order); the consumer's explicit wait_vm<N>() orders the read-back.  LDS destination = wave-uniform base + lane * 16.
-__device__ __forceinline__ void dma16_opaque(const void *g, void *l) {
     typedef __attribute__((address_space(3))) void lptr_t;
     const unsigned base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lptr_t *)l);
     asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(base) : "memory", "m0");
+}
+__device__ __forceinline__ void dma16_opaque(const void *g, void *l) { dma16(g, l); }
+// the builtin form (the compiler tracks it).  Kept for the frame-embedding weight gradient, the one kernel that measured
+// SLOWER with the written-out form (1.39 -> 1.53 ms: its loop only reads LDS, nothing was being over-waited, and the
+// compiler's own placement of the M0 set-up and waits is the better schedule there).
+__device__ __forceinline__ void dma16_tracked(const void *g, void *l) {
+    typedef __attribute__((address_space(1))) const void gptr_t;
+    typedef __attribute__((address_space(3))) void lptr_t;
+    __builtin_amdgcn_global_load_lds((gptr_t *)g, (lptr_t *)l, 16, 0, 0);
 }
 // 4 bytes per lane (LDS destination = wave-uniform base + lane * 4): per-row scalars of a prefetched tile.  A register-returning
 // load carried across the loop's back edge makes the compiler wait vmcnt(0) at its first use -- i.e. for the stores issued since.
