@@ -102,7 +102,18 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float *part, int
     if (e0 < n) {
         if (vec_ok) {
             int p = pl;
-            for (; p + 24 < nparts; p += 32) {        // 4 independent 16-byte loads in flight per thread
+            // 8, then 4 independent 16-byte loads in flight per thread (each iteration is one memory round trip: 256 slabs over 8
+            // part-lanes were 8 round trips at 4 loads per iteration)
+            for (; p + 56 < nparts; p += 64) {
+                float4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4 *>(part + (int64_t)(p + 8 * u) * ps + e0);
+                acc.x += ((v[0].x + v[1].x) + (v[2].x + v[3].x)) + ((v[4].x + v[5].x) + (v[6].x + v[7].x));
+                acc.y += ((v[0].y + v[1].y) + (v[2].y + v[3].y)) + ((v[4].y + v[5].y) + (v[6].y + v[7].y));
+                acc.z += ((v[0].z + v[1].z) + (v[2].z + v[3].z)) + ((v[4].z + v[5].z) + (v[6].z + v[7].z));
+                acc.w += ((v[0].w + v[1].w) + (v[2].w + v[3].w)) + ((v[4].w + v[5].w) + (v[6].w + v[7].w));
+            }
+            for (; p + 24 < nparts; p += 32) {
                 const float4 a = *reinterpret_cast<const float4 *>(part + (int64_t)p * ps + e0);
                 const float4 b = *reinterpret_cast<const float4 *>(part + (int64_t)(p + 8) * ps + e0);
                 const float4 c = *reinterpret_cast<const float4 *>(part + (int64_t)(p + 16) * ps + e0);
