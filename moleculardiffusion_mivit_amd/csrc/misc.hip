@@ -167,7 +167,15 @@ __global__ __launch_bounds__(256) void mean_pool_fwd_kernel(const T *x, int B, i
     if (i >= (int64_t)B * E) return;
     const int b = (int)(i / E), e = (int)(i % E);
     float acc = 0.f;
-    for (int s = 0; s < S; ++s) acc += to_f32(x[((int64_t)b * S + s) * E + e]);
+    int s = 0;
+    for (; s + 8 <= S; s += 8) {          // eight loads in flight (same summation order as the rolled loop)
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = to_f32(x[((int64_t)b * S + s + u) * E + e]);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; s < S; ++s) acc += to_f32(x[((int64_t)b * S + s) * E + e]);
     out[i] = from_f32<T>(acc / (float)S);
 }
 
@@ -189,7 +197,16 @@ __global__ __launch_bounds__(256) void batch_colsum_kernel(const T *x, int B, in
     const int r = (int)(i / E), e = (int)(i % E);
     const int bb = blockIdx.y * bchunk, be = min(B, bb + bchunk);
     float acc = 0.f;
-    for (int b = bb; b < be; ++b) acc += to_f32(x[((int64_t)b * S + s0 + r) * E + e]);
+    // eight loads in flight (the rolled loop was one memory round trip per batch element: 128 in a row at B = 16384)
+    int b = bb;
+    for (; b + 8 <= be; b += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = to_f32(x[((int64_t)(b + u) * S + s0 + r) * E + e]);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; b < be; ++b) acc += to_f32(x[((int64_t)b * S + s0 + r) * E + e]);
     part[(int64_t)blockIdx.y * rows * E + i] = acc;
 }
 
