@@ -386,6 +386,131 @@ __global__ __launch_bounds__(NW * 64) void embed_fwd_direct(const EmbFwdArgs a) 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same kernel with the frame loads written out (inline asm) and two register stages swapped by a 2x unrolled loop.
+// With ordinary loads the compiler places its own wait for the previous stage's registers, s_waitcnt vmcnt(8): it counts
+// the 8 loads of the next stage issued since -- but not the 4 W-tile DMA pieces issued after them (they are inline asm too,
+// stream_prims.h::dma16), so that wait also drains the four OLDEST loads of the stage it has just requested: half of the
+// one-stage-ahead prefetch was being waited for every stage.  Here nothing in the loop is visible to the compiler's
+// waitcnt pass; the order is the explicit  load A(s+1) -> wait_vm<A_LD + (D-1) * B_DMA>() -> barrier  of the kernel above,
+// and there is no register copy between the stages (a copy would read registers whose loads are still in flight).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int TMW, int NW, int NS>
+__global__ __launch_bounds__(NW * 64) void embed_fwd_direct2(const EmbFwdArgs a) {
+    using C = DirCfg<TMW, NW, NS>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int D = NS - 1;
+    typedef float f32x4_t __attribute__((ext_vector_type(4)));
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, cq = lane & 15;
+    const int m0 = blockIdx.y * C::BM, n0 = blockIdx.x * C::BN, nst = a.K / C::BK;
+    const int s0 = (int)(((unsigned)blockIdx.y * (unsigned)a.kstag) % (unsigned)nst);
+    auto stage_k = [&](int s) { int t = s + s0; t = t >= nst ? t - nst : t; return t * C::BK; };
+    const float *ap[TMW];
+#pragma unroll
+    for (int i = 0; i < TMW; ++i) ap[i] = a.X + (int64_t)min(m0 + (wave * TMW + i) * 16 + cq, a.M - 1) * a.K + 4 * g;
+
+    f32x4 acc[TMW][8];
+#pragma unroll
+    for (int i = 0; i < TMW; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto load_a = [&](int k0, f32x4_t (&dst)[2][TMW][2]) {      // one address pair per row tile, the four pieces by immediate offset
+#pragma unroll
+        for (int i = 0; i < TMW; ++i) {
+            const float *base = ap[i] + k0;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst[0][i][0]) : "v"(base) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off offset:64" : "=v"(dst[0][i][1]) : "v"(base) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off offset:128" : "=v"(dst[1][i][0]) : "v"(base) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off offset:192" : "=v"(dst[1][i][1]) : "v"(base) : "memory");
+        }
+    };
+    auto compute = [&](const unsigned char *Bs, f32x4_t (&cx)[2][TMW][2]) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 af[TMW];
+#pragma unroll
+            for (int i = 0; i < TMW; ++i) {
+                asm volatile("" : "+v"(cx[kk][i][0]), "+v"(cx[kk][i][1]));          // (ordered after the wait above)
+                const float4 lo = make_float4(cx[kk][i][0][0], cx[kk][i][0][1], cx[kk][i][0][2], cx[kk][i][0][3]);
+                const float4 hi = make_float4(cx[kk][i][1][0], cx[kk][i][1][1], cx[kk][i][1][2], cx[kk][i][1][3]);
+                af[i] = cvt8(lo, hi);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int n = j * 16 + cq, sw = (n >> 1) & 7;
+                const unsigned char *row = Bs + n * 128 + 8 * (g & 1);
+                typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                typedef __attribute__((address_space(3))) const volatile u32x2 lds_u32x2;
+                const u32x2 lo = *(lds_u32x2 *)(row + ((4 * kk + (g >> 1)) ^ sw) * 16);
+                const u32x2 hi = *(lds_u32x2 *)(row + ((4 * kk + 2 + (g >> 1)) ^ sw) * 16);
+                const bf16x8 bf = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+#pragma unroll
+                for (int i = 0; i < TMW; ++i) acc[i][j] = mma(af[i], bf, acc[i][j]);
+            }
+        }
+    };
+    f32x4_t xa[2][TMW][2], xb[2][TMW][2];
+#pragma unroll
+    for (int s = 0; s < D; ++s)
+        if (s < nst) dir_issue_b<NW>(a, smem + s * C::B_BYTES, n0, stage_k(s), wave, lane);
+    load_a(stage_k(0), xa);
+    for (int s = 0; s < nst; s += 2) {
+        // VM program order: ... W(s) ... A(s) | A(s+1): W stage s and A(s) are done once at most the youngest A stage and the
+        // D - 1 youngest W stages are outstanding
+        load_a(stage_k(min(s + 1, nst - 1)), xb);
+        wait_vm<C::A_LD + (D - 1) * C::B_DMA>();
+        barrier();
+        if (s + D < nst) dir_issue_b<NW>(a, smem + ((s + D) % NS) * C::B_BYTES, n0, stage_k(s + D), wave, lane);
+        compute(smem + (s % NS) * C::B_BYTES, xa);
+        if (s + 1 >= nst) break;
+        load_a(stage_k(min(s + 2, nst - 1)), xa);
+        wait_vm<C::A_LD + (D - 1) * C::B_DMA>();
+        barrier();
+        if (s + 1 + D < nst) dir_issue_b<NW>(a, smem + ((s + 1 + D) % NS) * C::B_BYTES, n0, stage_k(s + 1 + D), wave, lane);
+        compute(smem + ((s + 1) % NS) * C::B_BYTES, xb);
+    }
+    wait_vm<0>();                  // the clamped extra stage loads of the last round
+    // epilogue: + bias, through LDS as fp32, one 16-row tile per wave per pass, 16-byte bf16 stores
+    constexpr int LDC = C::BN + 4;
+    float *Cs = reinterpret_cast<float *>(smem) + wave * 16 * LDC;
+#pragma unroll
+    for (int i = 0; i < TMW; ++i) {
+        barrier();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int lc = j * 16 + cq;
+            const float bv = a.bias ? a.bias[n0 + lc] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Cs[(4 * g + r) * LDC + lc] = acc[i][j][r] + bv;
+        }
+        barrier();
+        for (int c = lane; c < 16 * (C::BN / 8); c += 64) {
+            const int lr = c / (C::BN / 8), lc = (c % (C::BN / 8)) * 8;
+            const int row = m0 + (wave * TMW + i) * 16 + lr;
+            if (row < a.M) {
+                float v[8];
+                *reinterpret_cast<float4 *>(v) = *reinterpret_cast<const float4 *>(Cs + lr * LDC + lc);
+                *reinterpret_cast<float4 *>(v + 4) = *reinterpret_cast<const float4 *>(Cs + lr * LDC + lc + 4);
+                store16(a.Y + (int64_t)row * a.E + n0 + lc, v);
+            }
+        }
+    }
+}
+
+template <int TMW, int NW, int NS>
+int fwd_direct2_launch(const EmbFwdArgs &a, hipStream_t s) {
+    using C = DirCfg<TMW, NW, NS>;
+    const size_t ring = (size_t)NS * C::B_BYTES, scratch = (size_t)NW * 16 * (C::BN + 4) * 4;
+    const size_t bytes = ring > scratch ? ring : scratch;
+    auto kern = embed_fwd_direct2<TMW, NW, NS>;
+    MIVIT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    ProfScope prof(s);
+    hipLaunchKernelGGL(kern, dim3(a.E / 128, ceil_div(a.M, C::BM)), dim3(NW * 64), bytes, s, a);
+    MIVIT_LAUNCH_CHECK();
+    return 0;
+}
+
 template <int TMW, int NW, int NS, int PF = 1>
 int fwd_direct_launch(const EmbFwdArgs &a, hipStream_t s) {
     using C = DirCfg<TMW, NW, NS>;
@@ -591,6 +716,7 @@ int launch_embed_fwd_dma(const float *X, const void *W_bf16, const float *bias, 
     if (variant == 1) return fwd_dma_launch<256, 2>(a, s);     // LDS-DMA staging of the frames (first design, kept for A/B runs)
     switch (variant) {
         case 3: return fwd_direct_launch<2, 4, 3>(a, s);
+        case 14: return fwd_direct2_launch<2, 4, 3>(a, s);
         case 4: return fwd_direct_launch<1, 4, 2>(a, s);
         case 5: return fwd_direct_launch<1, 8, 3>(a, s);
         case 6: return fwd_direct_launch<1, 8, 2>(a, s);
@@ -610,7 +736,7 @@ int launch_embed_fwd_dma(const float *X, const void *W_bf16, const float *bias, 
         }
         default:
             // small problems: shrink the row tile until the grid covers the chip (a 128-row tile gives M / 128 workgroups)
-            if ((long)ceil_div(a.M, 128) * (a.E / 128) >= 512) return fwd_direct_launch<2, 4, 3>(a, s);
+            if ((long)ceil_div(a.M, 128) * (a.E / 128) >= 512) return fwd_direct2_launch<2, 4, 3>(a, s);
             if ((long)ceil_div(a.M, 64) * (a.E / 128) >= 512) return fwd_direct_launch<1, 4, 3>(a, s);
             return fwd_direct_launch<1, 2, 3>(a, s);
     }
