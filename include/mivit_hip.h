@@ -69,6 +69,10 @@ int mivit_linear_wgrad(int dtype, const void *dy, int64_t lddy, const void *x, i
  * then uses mivit_linear_fwd / mivit_linear_wgrad, which accept any shape. */
 int mivit_embed_fwd_bf16(const float *x, const void *W_bf16, const float *bias, int M, int K, int E, void *y_bf16,
                          void *stream);
+/* Forward tiling override (0 = chosen by problem size: embed_fwd_direct2<2,4,3> when M/128 * E/128 >= 512 workgroups,
+ * embed_fwd_direct<1,4,3> / <1,2,3> below that; 14 / 8 / 15 force those three, 1 / 2 / 13 the LDS-DMA designs, 3..7 the
+ * other direct tilings).  For A/B runs and so that parity tests reach every launcher branch.  Returns the previous value. */
+int mivit_embed_set_variant(int variant);
 size_t mivit_embed_wgrad_bf16_workspace_bytes(int M, int K, int E);
 int mivit_embed_wgrad_bf16(const void *dy_bf16, const float *x, int M, int K, int E, float *dW, void *workspace,
                            size_t workspace_bytes, void *stream);

@@ -53,6 +53,7 @@ SYMBOLS = {
     "mivit_linear_wgrad": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_void_p,
                                    c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "mivit_embed_fwd_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "mivit_embed_set_variant": (c_int, [c_int]),
     "mivit_embed_wgrad_bf16_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "mivit_embed_wgrad_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "mivit_rowstream_fwd": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int64,
@@ -134,17 +135,17 @@ class MivitError(RuntimeError):
     pass
 
 
-def _load():
-    if not os.path.exists(LIB_PATH):
+def _load(path=LIB_PATH):
+    if not os.path.exists(path):
         raise ImportError(
-            f"{LIB_PATH} is missing: the MiViT HIP extension has not been built. Run "
+            f"{path} is missing: the MiViT HIP extension has not been built. Run "
             "`python -m moleculardiffusion_mivit_amd.csrc.build` (needs hipcc, targets gfx950). "
             "There is no CPU / PyTorch fallback for this path.")
     # PyTorch-ROCm bundles its own libamdhip64 / libhsa-runtime64.  One process must hold ONE HIP runtime, and device
     # pointers + streams are shared with torch, so torch's copy has to be the one already resident when
     # libmivit_hip.so (NEEDED: libamdhip64.so.7) is resolved: import torch first.
     import torch  # noqa: F401
-    lib = ctypes.CDLL(LIB_PATH)
+    lib = ctypes.CDLL(path)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)          # AttributeError if the library does not export a declared symbol
         fn.restype = res
@@ -155,6 +156,15 @@ def _load():
 
 
 lib = _load()
+
+# the same library built with -DMIVIT_STRICT_WAITS (every counted s_waitcnt vmcnt(N) -> vmcnt(0), csrc/build.py).  Test
+# infrastructure: tests/test_strict_waits_gpu.py loads it through load_strict() and compares results bitwise; nothing in
+# the product does.
+STRICT_LIB_PATH = os.path.join(_PKG, "libmivit_hip_strict.so")
+
+
+def load_strict():
+    return _load(STRICT_LIB_PATH)
 
 
 def check(rc, what=""):

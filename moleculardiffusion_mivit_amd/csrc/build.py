@@ -13,6 +13,11 @@ ROOT = os.path.dirname(PKG)
 SOURCES = ["gemm.hip", "norm.hip", "attention.hip", "attention_fast.hip", "embed.hip", "rowstream.hip", "wavestream.hip", "gemm_dma.hip", "wgrad_dma.hip", "wgrad_small.hip", "fused_fwd.hip", "fused_bwd.hip", "render.hip", "deepresnet.hip", "deepresnet_train.hip", "misc.hip", "engine.hip"]
 HEADERS = [os.path.join(HERE, "common.h"), os.path.join(HERE, "stream_prims.h"), os.path.join(ROOT, "include", "mivit_hip.h")]
 LIB = os.path.join(PKG, "libmivit_hip.so")
+# the same library with every counted s_waitcnt vmcnt(N) of stream_prims.h::wait_vm turned into vmcnt(0) (-DMIVIT_STRICT_WAITS).
+# TEST INFRASTRUCTURE ONLY: tests/test_strict_waits_gpu.py runs the bench-scale shapes through both and requires bitwise-equal
+# results; the product (_native.py) never loads it.  Only the sources that call wait_vm are compiled twice.
+LIB_STRICT = os.path.join(PKG, "libmivit_hip_strict.so")
+WAIT_SOURCES = ["embed.hip", "rowstream.hip", "gemm_dma.hip", "wgrad_dma.hip", "fused_bwd.hip", "fused_fwd.hip"]
 OBJDIR = os.path.join(HERE, "build")
 # -amdgpu-mfma-vgpr-form: MFMA results in arch VGPRs where they fit.  By default the accumulators go to AGPRs and every value a
 # VALU instruction consumes afterwards (softmax, bias, packing, stores) costs a v_accvgpr_read first: attention_fast.hip 23 k
@@ -37,7 +42,7 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, strict=True):
     os.makedirs(OBJDIR, exist_ok=True)
     hipcc = _hipcc()
     jobs = []
@@ -45,11 +50,15 @@ def build(force=False, verbose=True):
         s = os.path.join(HERE, src)
         o = os.path.join(OBJDIR, src.replace(".hip", ".o"))
         if force or _stale(o, [s, os.path.abspath(__file__)] + HEADERS):        # the flags live in this file
-            jobs.append((s, o))
+            jobs.append((s, o, []))
+        if strict and src in WAIT_SOURCES:
+            o = os.path.join(OBJDIR, src.replace(".hip", ".strict.o"))
+            if force or _stale(o, [s, os.path.abspath(__file__)] + HEADERS):
+                jobs.append((s, o, ["-DMIVIT_STRICT_WAITS"]))
 
     def compile_one(job):
-        s, o = job
-        cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+        s, o, extra = job
+        cmd = [hipcc] + FLAGS + extra + ["-c", s, "-o", o]
         if verbose:
             print("[mivit build]", " ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
@@ -58,16 +67,18 @@ def build(force=False, verbose=True):
         if r.stderr.strip() and verbose:
             print(r.stderr, file=sys.stderr)
 
-    with ThreadPoolExecutor(max_workers=min(4, max(1, len(jobs)))) as ex:
+    with ThreadPoolExecutor(max_workers=min(os.cpu_count() or 4, 8, max(1, len(jobs)))) as ex:
         list(ex.map(compile_one, jobs))
     objs = [os.path.join(OBJDIR, s.replace(".hip", ".o")) for s in SOURCES]
-    if force or jobs or _stale(LIB, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
-        if verbose:
-            print("[mivit build]", " ".join(cmd), flush=True)
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    sobjs = [os.path.join(OBJDIR, s.replace(".hip", ".strict.o" if s in WAIT_SOURCES else ".o")) for s in SOURCES]
+    for lib, ob in ((LIB, objs), (LIB_STRICT, sobjs)) if strict else ((LIB, objs),):
+        if force or jobs or _stale(lib, ob):
+            cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + ob
+            if verbose:
+                print("[mivit build]", " ".join(cmd), flush=True)
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
     return LIB
 
 

@@ -282,7 +282,7 @@ __device__ __forceinline__ void dir_issue_b(const EmbFwdArgs &a, unsigned char *
     }
 }
 
-template <int TMW, int NW, int NS, int PF = 1>
+template <int TMW, int NW, int NS>
 __global__ __launch_bounds__(NW * 64) void embed_fwd_direct(const EmbFwdArgs a) {
     using C = DirCfg<TMW, NW, NS>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(NW * 64) void embed_fwd_direct(const EmbFwdArgs a) 
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    float4 nx[PF][2][TMW][2];                                    // [stage ahead][kk][tile][half]: PF stages in flight
+    float4 nx[2][TMW][2];                                        // [kk][tile][half]: the next stage's frame fragments
     auto load_a = [&](int k0, float4 (&dst)[2][TMW][2]) {
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
@@ -316,8 +316,7 @@ __global__ __launch_bounds__(NW * 64) void embed_fwd_direct(const EmbFwdArgs a) 
 #pragma unroll
     for (int s = 0; s < D; ++s)
         if (s < nst) dir_issue_b<NW>(a, smem + s * C::B_BYTES, n0, stage_k(s), wave, lane);
-#pragma unroll
-    for (int f = 0; f < PF; ++f) load_a(stage_k(min(f, nst - 1)), nx[f]);
+    load_a(stage_k(0), nx);
     for (int s = 0; s < nst; ++s) {
         float4 cx[2][TMW][2];
 #pragma unroll
@@ -325,15 +324,16 @@ __global__ __launch_bounds__(NW * 64) void embed_fwd_direct(const EmbFwdArgs a) 
 #pragma unroll
             for (int i = 0; i < TMW; ++i)
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    cx[kk][i][h] = nx[0][kk][i][h];
-#pragma unroll
-                    for (int f = 0; f + 1 < PF; ++f) nx[f][kk][i][h] = nx[f + 1][kk][i][h];
-                }
-        // program order of this wave's VM ops: ... A(s) ... | A(s + PF): everything up to A(s) and W stage s is done once at
-        // most the PF youngest A stages and the D - 1 youngest W stages are outstanding
-        load_a(stage_k(min(s + PF, nst - 1)), nx[PF - 1]);
-        wait_vm<PF * C::A_LD + (D - 1) * C::B_DMA>();
+                for (int h = 0; h < 2; ++h) cx[kk][i][h] = nx[kk][i][h];
+        // The frame loads are ordinary loads: the compiler orders their uses itself.  The explicit wait is for W stage s (the
+        // LDS-DMA is invisible to the compiler).  VM program order of a wave (A = A_LD frame loads, W = B_DMA DMA pieces):
+        //   prologue W(0) .. W(D-1) A(0);   iteration i:  A(i+1) | wait | barrier | W(i+D) if it exists | compute(i)
+        // W(s) was issued in iteration s - D (or the prologue); younger than it are A(s-D+2) .. A(s+1) -- at least A(s+1) --
+        // and W(s+1) .. W(s+D-1) where those exist.  The count used is the minimum over all s: the youngest frame stage plus,
+        // when W(s+D-1) was issued, the D - 1 younger W stages.
+        load_a(stage_k(min(s + 1, nst - 1)), nx);
+        if (s + D - 1 < nst) wait_vm<C::A_LD + (D - 1) * C::B_DMA>();
+        else wait_vm<C::A_LD>();
         barrier();          // every wave's share of W stage s landed; every wave finished reading the slot of stage s-1
         if (s + D < nst) dir_issue_b<NW>(a, smem + ((s + D) % NS) * C::B_BYTES, n0, stage_k(s + D), wave, lane);
         const unsigned char *Bs = smem + (s % NS) * C::B_BYTES;
@@ -451,21 +451,34 @@ __global__ __launch_bounds__(NW * 64) void embed_fwd_direct2(const EmbFwdArgs a)
         }
     };
     f32x4_t xa[2][TMW][2], xb[2][TMW][2];
+    // VM program order of a wave (A(i) = the A_LD frame loads of stage i, W(j) = the B_DMA DMA pieces of W stage j, W(j) exists
+    // for j < nst only; A(nst) is a clamped re-load of the last stage whose registers are never consumed):
+    //   prologue   W(0) .. W(D-2)  A(0)  W(D-1)
+    //   stage i    A(i+1) | wait | barrier | W(i+D) | compute(i)
+    // i.e. uniformly  ... A(i) W(i+D-1) A(i+1) W(i+D) ...  : at the wait of stage i everything up to and including A(i) must be
+    // complete (W(i) is older than A(i) for D >= 2), and the only younger operations are W(i+D-1) -- if it exists -- and A(i+1).
+    // (Round 2 issued the prologue as W(0) W(1) A(0) and waited vmcnt(A_LD + B_DMA) everywhere: in stage 0 the younger operations
+    // were A(1) only, so the four youngest loads of A(0) could still be in flight when compute() converted them; the same at the
+    // last stage, where no W stage follows A(nst-1).)
+    static_assert(D >= 2, "W(i) must be older than A(i)");
 #pragma unroll
-    for (int s = 0; s < D; ++s)
+    for (int s = 0; s < D - 1; ++s)
         if (s < nst) dir_issue_b<NW>(a, smem + s * C::B_BYTES, n0, stage_k(s), wave, lane);
     load_a(stage_k(0), xa);
+    if (D - 1 < nst) dir_issue_b<NW>(a, smem + (D - 1) * C::B_BYTES, n0, stage_k(D - 1), wave, lane);
+    auto wait_stage = [&](int i) {
+        if (i + D - 1 < nst) wait_vm<C::A_LD + C::B_DMA>();     // younger than A(i): W(i+D-1), A(i+1)
+        else wait_vm<C::A_LD>();                                // younger than A(i): A(i+1)
+    };
     for (int s = 0; s < nst; s += 2) {
-        // VM program order: ... W(s) ... A(s) | A(s+1): W stage s and A(s) are done once at most the youngest A stage and the
-        // D - 1 youngest W stages are outstanding
         load_a(stage_k(min(s + 1, nst - 1)), xb);
-        wait_vm<C::A_LD + (D - 1) * C::B_DMA>();
+        wait_stage(s);
         barrier();
         if (s + D < nst) dir_issue_b<NW>(a, smem + ((s + D) % NS) * C::B_BYTES, n0, stage_k(s + D), wave, lane);
         compute(smem + (s % NS) * C::B_BYTES, xa);
         if (s + 1 >= nst) break;
         load_a(stage_k(min(s + 2, nst - 1)), xa);
-        wait_vm<C::A_LD + (D - 1) * C::B_DMA>();
+        wait_stage(s + 1);
         barrier();
         if (s + 1 + D < nst) dir_issue_b<NW>(a, smem + ((s + 1 + D) % NS) * C::B_BYTES, n0, stage_k(s + 1 + D), wave, lane);
         compute(smem + ((s + 1) % NS) * C::B_BYTES, xb);
@@ -511,12 +524,12 @@ int fwd_direct2_launch(const EmbFwdArgs &a, hipStream_t s) {
     return 0;
 }
 
-template <int TMW, int NW, int NS, int PF = 1>
+template <int TMW, int NW, int NS>
 int fwd_direct_launch(const EmbFwdArgs &a, hipStream_t s) {
     using C = DirCfg<TMW, NW, NS>;
     const size_t ring = (size_t)NS * C::B_BYTES, scratch = (size_t)NW * 16 * (C::BN + 4) * 4;
     const size_t bytes = ring > scratch ? ring : scratch;
-    auto kern = embed_fwd_direct<TMW, NW, NS, PF>;
+    auto kern = embed_fwd_direct<TMW, NW, NS>;
     MIVIT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     ProfScope prof(s);
     hipLaunchKernelGGL(kern, dim3(a.E / 128, ceil_div(a.M, C::BM)), dim3(NW * 64), bytes, s, a);
@@ -699,6 +712,11 @@ int fwd_dma_launch(const EmbFwdArgs &a, hipStream_t s) {
 
 }  // namespace
 
+// forward tiling, selectable for A/B runs and so that the tests reach every launcher branch at small sizes:
+// MIVIT_EMBED_FWD_VARIANT / mivit_embed_set_variant (0 = by problem size)
+static int g_embed_variant = getenv("MIVIT_EMBED_FWD_VARIANT") ? atoi(getenv("MIVIT_EMBED_FWD_VARIANT")) : 0;
+extern "C" int mivit_embed_set_variant(int v) { const int old = g_embed_variant; g_embed_variant = v; return old; }
+
 bool embed_dma_supported(int dtype, int M, int K, int E) {
     return dtype == MIVIT_BF16 && E % 128 == 0 && K % 128 == 0 && K >= 256 && M >= 128;
 }
@@ -711,7 +729,7 @@ int launch_embed_fwd_dma(const float *X, const void *W_bf16, const float *bias, 
     // measured (c1, batch 16384): 0 -> 4.78 TB/s, 1 -> 5.06, 3 -> 5.09, 5..13 -> 5.00-5.03, 17 -> 5.09, 21 -> 5.03
     static const int kstag = getenv("MIVIT_EMBED_KSTAG") ? atoi(getenv("MIVIT_EMBED_KSTAG")) : 17;
     a.kstag = kstag;
-    static const int variant = getenv("MIVIT_EMBED_FWD_VARIANT") ? atoi(getenv("MIVIT_EMBED_FWD_VARIANT")) : 0;
+    const int variant = g_embed_variant;
     if (variant == 2) return fwd_dma_launch<128, 3>(a, s);
     if (variant == 1) return fwd_dma_launch<256, 2>(a, s);     // LDS-DMA staging of the frames (first design, kept for A/B runs)
     switch (variant) {
@@ -722,10 +740,7 @@ int launch_embed_fwd_dma(const float *X, const void *W_bf16, const float *bias, 
         case 6: return fwd_direct_launch<1, 8, 2>(a, s);
         case 7: return fwd_direct_launch<2, 4, 2>(a, s);
         case 8: return fwd_direct_launch<1, 4, 3>(a, s);
-        case 9: return fwd_direct_launch<1, 4, 3, 2>(a, s);
-        case 10: return fwd_direct_launch<1, 8, 3, 2>(a, s);
-        case 11: return fwd_direct_launch<2, 4, 3, 2>(a, s);
-        case 12: return fwd_direct_launch<1, 8, 3, 3>(a, s);
+        case 15: return fwd_direct_launch<1, 2, 3>(a, s);
         case 13: {
             const size_t bytes = (size_t)F32Cfg::NS * F32Cfg::STAGE;
             MIVIT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(embed_fwd_dma32), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));

@@ -139,13 +139,24 @@ __global__ __launch_bounds__(NT) void rowstream_kernel(const RsArgs a) {
 
     for (int t = 0; mt < ntm; mt += stride, ++t) {
         const int m0 = mt * BM;
-        // Tile t must have landed.  VMEM retires in order; younger than tile t's DMA are only: the D-1 tiles issued
-        // after it (PER_TILE each, when they exist) and the >= 4 store instructions of the last epilogue (every
-        // earlier tile of this block was a full tile, so each wave stored).  The first tile also waits for W.
+        // Tile t must have landed.  VM program order of a wave (T = the PER_TILE DMA pieces of a tile, st = the row stores of one
+        // epilogue: at least ST = BM / 32 store instructions, one unconditional-for-a-full-tile C store per 32-row pass; every
+        // tile before the one being waited for is a full tile, so every wave issued them; W = the weight slice):
+        //   prologue     W  T(0) .. T(D-1)
+        //   iteration i  wait | barrier | T(i+D) if it exists | compute(i) | st(i)
+        // D = 2:  W T0 T1 | T2 st0 | T3 st1 | ...   younger than T(t): T(t+1) [if it exists], st(t-2) [t >= 2], st(t-1) [t >= 1]
+        // D = 1:  W T0 | T1 st0 | T2 st1 | ...      younger than T(t): st(t-1) [t >= 1]
+        // (Round 2 counted "4 stores of the last epilogue" everywhere: with 32-row passes an epilogue guarantees BM / 32 = 1 or 2,
+        // so at t = 1 (D = 2) and at every t (D = 1: the K = 384 slices, BM = 32, one store) the count let DMA pieces of the
+        // tile being waited for stay in flight.)
+        constexpr int ST = BM / 32;
+        static_assert(D == 1 || D == 2, "the counts below are written out for one or two tiles in flight");
         const bool next_in_flight = D > 1 && mt + (D - 1) * stride < ntm;
         if (t == 0) { if (next_in_flight) wait_vm<(D - 1) * C::PER_TILE>(); else wait_vm<0>(); }
-        else if (D == 1 || next_in_flight) wait_vm<(D - 1) * C::PER_TILE + 4>();
-        else wait_vm<0>();
+        else if (D == 1) wait_vm<ST>();
+        else if (!next_in_flight) wait_vm<0>();
+        else if (t == 1) wait_vm<C::PER_TILE + ST>();
+        else wait_vm<C::PER_TILE + 2 * ST>();
         barrier();              // ... everyone's share landed; and everyone is done with the staging area of tile t-1
         if (mt + D * stride < ntm)
             issue_tile<K, DGRAD, HAS_E>(a, E, lde, ring + ((t + D) % C::NS) * C::SLOT, (mt + D * stride) * BM, n0, wave, lane);

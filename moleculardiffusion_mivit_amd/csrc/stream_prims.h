@@ -15,7 +15,9 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 __device__ __forceinline__ void dma16(const void *g, void *l) {
     typedef __attribute__((address_space(3))) void lptr_t;
     const unsigned base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lptr_t *)l);
-    asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(base) : "memory", "m0");
+    // s_nop 0: an SALU write of M0 needs one wait state before an LDS-DMA reads it; the hazard recogniser pads the builtin form
+    // but cannot see inside an asm string
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(base) : "memory", "m0");
 }
 __device__ __forceinline__ void dma16_opaque(const void *g, void *l) { dma16(g, l); }
 // the builtin form (the compiler tracks it).  Kept for the frame-embedding weight gradient, the one kernel that measured
@@ -31,12 +33,19 @@ __device__ __forceinline__ void dma16_tracked(const void *g, void *l) {
 __device__ __forceinline__ void dma4_opaque(const void *g, void *l) {
     typedef __attribute__((address_space(3))) void lptr_t;
     const unsigned base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lptr_t *)l);
-    asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dword %0, off" ::"v"(g), "s"(base) : "memory", "m0");
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(g), "s"(base) : "memory", "m0");
 }
-// vector-memory operations retire in order: N = how many of this wave's youngest may still be in flight
+// vector-memory operations (loads, LDS-DMA, stores) retire in order: N = how many of this wave's youngest may still be in flight.
+// Every call site states the VM program order it relies on (prologue, steady state, tail); tests/test_wait_model.py replays
+// those orders on the host and checks every count.  -DMIVIT_STRICT_WAITS (libmivit_hip_strict.so, csrc/build.py) turns every
+// counted wait into vmcnt(0): tests/test_strict_waits_gpu.py requires bitwise-equal results from the two libraries.
 template <int N>
 __device__ __forceinline__ void wait_vm() {
+#ifdef MIVIT_STRICT_WAITS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+#endif
 }
 // workgroup barrier without the compiler's blanket vmcnt(0): LDS traffic drained, DMA left in flight
 __device__ __forceinline__ void barrier() {

@@ -41,31 +41,33 @@ class MivitPlan:
         self.cfg = N.MivitConfig(N.ABI_VERSION, _PRECISIONS[precision], embedding, patch_size, embed_dim, num_heads,
                                  hidden_dim, num_layers, activation, int(use_pos_encoding), int(use_regression_token),
                                  fusion, int(global_feature_dim or 0), head_hidden, output_dim)
-        self._h = N.lib.mivit_plan_create(ctypes.byref(self.cfg))
+        self._lib = N.lib            # a plan handle belongs to the library instance that created it
+        self._h = self._lib.mivit_plan_create(ctypes.byref(self.cfg))
         if not self._h:
             raise N.MivitError(f"mivit_plan_create: {N.last_error()}")
         h = self._h
-        n = N.lib.mivit_plan_num_params(h)
-        self.param_names: List[str] = [N.lib.mivit_plan_param_name(h, i).decode() for i in range(n)]
-        self.param_offsets: List[int] = [N.lib.mivit_plan_param_offset(h, i) for i in range(n)]
-        self.param_numels: List[int] = [N.lib.mivit_plan_param_numel(h, i) for i in range(n)]
-        self.arena_numel: int = N.lib.mivit_plan_arena_numel(h)
-        self.num_stages: int = N.lib.mivit_plan_num_stages(h)
+        n = self._lib.mivit_plan_num_params(h)
+        self.param_names: List[str] = [self._lib.mivit_plan_param_name(h, i).decode() for i in range(n)]
+        self.param_offsets: List[int] = [self._lib.mivit_plan_param_offset(h, i) for i in range(n)]
+        self.param_numels: List[int] = [self._lib.mivit_plan_param_numel(h, i) for i in range(n)]
+        self.arena_numel: int = self._lib.mivit_plan_arena_numel(h)
+        self.num_stages: int = self._lib.mivit_plan_num_stages(h)
         self.stage_ranges = []
         for s in range(self.num_stages):
             b, e = ctypes.c_int64(), ctypes.c_int64()
-            N.check(N.lib.mivit_plan_stage_range(h, s, ctypes.byref(b), ctypes.byref(e)), "stage_range")
+            N.check(self._lib.mivit_plan_stage_range(h, s, ctypes.byref(b), ctypes.byref(e)), "stage_range")
             self.stage_ranges.append((b.value, e.value))
         self.embed_dim, self.output_dim = embed_dim, output_dim
         self.embedding = embedding
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
-        if h and N is not None and getattr(N, "lib", None) is not None:   # (module may be gone at interpreter exit)
-            N.lib.mivit_plan_destroy(h)
+        lib = getattr(self, "_lib", None)
+        if h and lib is not None:                   # (module may be gone at interpreter exit)
+            lib.mivit_plan_destroy(h)
 
     def workspace_bytes(self, B: int, T: int, need_backward: bool) -> int:
-        return N.lib.mivit_plan_workspace_bytes(self._h, B, T, int(need_backward))
+        return self._lib.mivit_plan_workspace_bytes(self._h, B, T, int(need_backward))
 
     @staticmethod
     def _require_gpu(*tensors):
@@ -75,12 +77,12 @@ class MivitPlan:
 
     def forward(self, arena, x, features, B, T, ws, need_backward, out):
         self._require_gpu(arena, x, features)
-        N.check(N.lib.mivit_forward(self._h, _ptr(arena), _ptr(x), _ptr(features), B, T, _ptr(ws), ws.numel(),
+        N.check(self._lib.mivit_forward(self._h, _ptr(arena), _ptr(x), _ptr(features), B, T, _ptr(ws), ws.numel(),
                                     int(need_backward), _ptr(out), _stream_ptr(x.device)), "mivit_forward")
 
     def backward(self, arena, x, features, B, T, ws, dout, grads, dfeatures, dx_tokens, s0, s1):
         self._require_gpu(arena, x, dout, grads)
-        N.check(N.lib.mivit_backward(self._h, _ptr(arena), _ptr(x), _ptr(features), B, T, _ptr(ws), ws.numel(),
+        N.check(self._lib.mivit_backward(self._h, _ptr(arena), _ptr(x), _ptr(features), B, T, _ptr(ws), ws.numel(),
                                      _ptr(dout), _ptr(grads), _ptr(dfeatures), _ptr(dx_tokens), s0, s1,
                                      _stream_ptr(x.device)), "mivit_backward")
 

