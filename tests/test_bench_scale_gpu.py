@@ -388,7 +388,7 @@ def _step(m, x, y):
     out = m(x)
     loss = F.mse_loss(out, y)
     loss.backward()
-    return out.detach(), float(loss), {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+    return out.detach(), float(loss.detach()), {k: p.grad.detach().clone() for k, p in m.named_parameters()}
 
 
 def test_c1_bf16_at_bench_batch_against_fp32_parity_mode():
@@ -401,17 +401,22 @@ def test_c1_bf16_at_bench_batch_against_fp32_parity_mode():
     o16, l16, g16 = _step(m16, xs, ls)
     assert rel_err(o16, o32) < 5e-2
     assert abs(l16 - l32) <= 2e-2 * abs(l32)
-    for k in g32:
-        e = float((g16[k] - g32[k]).norm() / (g32[k].norm() + 1e-12))
+    gscale = max(float(g.norm()) for g in g32.values())
+    for k in g32:       # (k_proj.bias has an analytically zero gradient -- both sides hold rounding noise there: floor by the global scale)
+        e = float((g16[k] - g32[k]).norm() / (g32[k].norm() + 1e-3 * gscale))
         assert e < 8e-2, (k, e)
     # batch independence of the bf16 path: the same sequences in chunks of 24 go through the small-problem kernels
-    # (embed_fwd_direct<1,2,3>, single-pass fused blocks) and must give the same predictions
+    # (embed_fwd_direct<1,2,3>, single-pass fused blocks) and must give the same predictions.  Not bitwise: the embedding
+    # kernels start their k loop at a workgroup-dependent stage (HBM channel spread), so the fp32 accumulation order of a row
+    # depends on where it sits in the batch; a one-ulp flip of a bf16 token then travels through four layers like any other
+    # bf16 rounding -- the band is the bf16-vs-fp32 band above (measured 2.0e-2 on the worst prediction, 5e-2 allowed there).
     with torch.no_grad():
         big = m16(xs)
         small = torch.cat([m16(xs[i:i + 24]) for i in range(0, 240, 24)])
         tail = m16(xs[B - 24:])
-    assert rel_err(big[:240], small) < 1e-2
-    assert rel_err(big[B - 24:], tail) < 1e-2
+    assert rel_err(big[:240], small) < 3e-2
+    assert rel_err(big[B - 24:], tail) < 3e-2
+    assert float((big[:240] - small).abs().mean() / small.abs().mean()) < 3e-3
     # and bitwise repeatable
     o16b, l16b, g16b = _step(m16, xs, ls)
     assert torch.equal(o16, o16b) and all(torch.equal(g16[k], g16b[k]) for k in g16)
