@@ -80,6 +80,21 @@ def attach(model, group=None, broadcast: bool = True, sync_batchnorm=None):
             raise ValueError("sync_batchnorm=True needs a DeepResNetEmbedding (the only embedding with BatchNorm)")
         emb.sync_batchnorm(group)
     model._dp = StagedGradReducer(model._plan.stage_ranges, group)
+    # Models on the composed path (dropout > 0, a free-form activation, a non-ReLU head: GeneralTransformer._forward_composed)
+    # differentiate through ordinary autograd, never through MivitFunction.backward -- the staged reducer above is not
+    # reached.  Their gradients are averaged by a hook per parameter instead, fired when autograd has accumulated that
+    # parameter's gradient (a compatibility path: ~50 small collectives per step, correct before fast).
+    for h in getattr(model, "_dp_hooks", []):
+        h.remove()
+    model._dp_hooks = []
+    if getattr(model, "_composed", False) and model._dp.world > 1:
+        world = model._dp.world
+
+        def _average(p, _world=world, _group=group):
+            p.grad.mul_(1.0 / _world)
+            dist.all_reduce(p.grad, group=_group)
+
+        model._dp_hooks = [p.register_post_accumulate_grad_hook(_average) for p in model.parameters() if p.requires_grad]
     return model
 
 
@@ -88,7 +103,7 @@ def finish_external_grads(model, group=None):
     loss.backward()): ONE collective on one flat buffer, pre-scaled by 1/world, issued on the communication stream so
     it runs beside whatever the main stream still has queued (the optimizer waits for it through the stream join)."""
     world = dist.get_world_size(group)
-    if world == 1:
+    if world == 1 or getattr(model, "_dp_hooks", None):      # composed-path models: every parameter was averaged by its hook
         return
     inside = {id(p) for p in getattr(model, "_arena_params", [])}
     ext = [p for p in model.parameters() if id(p) not in inside and p.grad is not None]

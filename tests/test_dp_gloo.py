@@ -124,6 +124,58 @@ def test_data_parallel_two_ranks_gloo():
     assert dict(ret) == {0: "ok", 1: "ok"}, dict(ret)
 
 
+def _composed_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from functools import partial
+        from moleculardiffusion_mivit_amd import dp
+        from moleculardiffusion_mivit_amd.helpers import models as M
+        torch.manual_seed(7 + rank)
+        cfg = orc.MiViTConfig(embedding="linear", patch_size=9, embed_dim=32, num_heads=2, hidden_dim=64, num_layers=2)
+        model = M.GeneralTransformer(
+            embedding_cls=M.LinearProjectionEmbedding, embed_kwargs={"patch_size": 9, "embed_dim": 32}, embed_dim=32, num_heads=2,
+            hidden_dim=64, num_layers=2, mlp_head=partial(M.MLPHead, hidden_dim=128, output_dim=1), tr_activation_fct=F.relu,
+            dropout=0.1, use_regression_token=True, precision="fp32")
+        assert model._composed                      # dropout > 0: ordinary autograd, MivitFunction.backward never runs
+        # the composed forward runs HIP operators; on CPU tensors the oracle's forward over the LIVE parameters stands in
+        # (dropout left out -- what is under test is who averages the gradients, not the arithmetic)
+        model._forward_composed = lambda x, features=None: orc.forward(dict(model.named_parameters()), cfg, x, features)
+        dp.attach(model)
+        assert len(model._dp_hooks) == len(list(model.parameters()))
+        ref_params = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        B = 8
+        x, y, _ = orc.closed_form_batch(B, 10, 9)
+        shard = slice(rank * B // world, (rank + 1) * B // world)
+        model.zero_grad()
+        F.mse_loss(model(x[shard]), y[shard]).backward()
+        dp.finish_external_grads(model)             # a no-op for hooked models (must not average twice)
+        _, _, full = orc.loss_and_grads(ref_params, cfg, x, y)
+        gscale = max(float(g.abs().max()) for g in full.values())
+        worst = max(float((p.grad - full[k]).abs().max() / (full[k].abs().max() + 1e-3 * gscale)) for k, p in model.named_parameters())
+        assert worst < 2e-5, worst
+        sums = [None] * world
+        dist.all_gather_object(sums, [float(p.grad.double().sum()) for p in model.parameters()])
+        assert sums[0] == sums[1], "gradients differ across ranks"
+        ret[rank] = "ok"
+    except Exception:  # noqa: BLE001
+        import traceback
+        ret[rank] = "FAIL: " + traceback.format_exc()
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def test_composed_path_models_average_their_gradients_too():
+    """dropout > 0 (or a free-form activation / non-ReLU head) puts a model on the composed path, whose backward is ordinary
+    autograd: dp.attach must still make training data-parallel (round-2 advisor finding: replicas silently diverged)."""
+    world = 2
+    ret = mp.Manager().dict()
+    mp.spawn(_composed_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert dict(ret) == {0: "ok", 1: "ok"}, dict(ret)
+
+
 def test_staged_reducer_single_process_is_identity():
     from moleculardiffusion_mivit_amd.dp import StagedGradReducer
     r = StagedGradReducer([(0, 4), (4, 10)])
