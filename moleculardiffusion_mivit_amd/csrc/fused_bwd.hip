@@ -21,6 +21,8 @@
 #include "stream_prims.h"
 #include <stdlib.h>
 #include <algorithm>
+#include <vector>
+#include <stdio.h>
 
 #define RC(call) do { int rc_ = (call); if (rc_) return rc_; } while (0)
 
@@ -33,8 +35,8 @@ constexpr int LDE = E + 16, LDF = F + 16;            // LDS row pitches (element
 constexpr int OFF_W1 = 0;                            // [F][LDE]  W1 as stored ([hidden unit][input feature]): serves u (plain reads) and dx1 (transposing reads)
 constexpr int OFF_X = OFF_W1 + F * LDE * 2;          // [R][LDE]  x1 = gamma1 * n1 + beta1 rows
 constexpr int OFF_DZ = OFF_X + R * LDE * 2;          // [R][LDE]  dz2 rows
-constexpr int OFF_DH = OFF_DZ + R * LDE * 2;         // [R][LDF]  dh rows, hidden index permuted inside each block of 32 (see phase 2)
-constexpr int OFF_VEC = OFF_DH + R * LDF * 2;        // b1 [F], gamma2 [E], gamma1 [E], beta1 [E] fp32
+constexpr int OFF_DH = OFF_DZ + R * LDE * 2;         // [F][R]    dh TRANSPOSED: one 64-byte row of the tile's 32 rows per hidden unit (see dht_off)
+constexpr int OFF_VEC = OFF_DH + F * R * 2;          // b1 [F], gamma2 [E], gamma1 [E], beta1 [E] fp32
 constexpr int OFF_ACC = OFF_VEC + (F + 3 * E) * 4;               // [6][NT] float4: running column sums of the element-wise phase (dgamma2, dbeta2, db2)
 constexpr int OFF_STG = OFF_ACC + 6 * NT * 16;        // [6][NW][64] x 16 B: next tile's dy / n2 / n1 chunks, landed by LDS-DMA (thread-private slots)
 constexpr int OFF_RST = OFF_STG + 6 * NT * 16;       // [2][NT] floats: rstd2 of the next tile's two rows per thread (LDS-DMA, thread-private slots)
@@ -54,7 +56,13 @@ struct MlpBwdArgs {
     int M;
     bf16 *dx1;
     float *slabs;          // [gridDim.x][SL_TOTAL]
+    unsigned long long *dbg;   // -DMIVIT_PHASE_TIMING builds (scripts/phase_timing.py): per-wave cycle totals of the phases; else null
 };
+#ifdef MIVIT_PHASE_TIMING
+#define PT_MARK(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); pt[k] += t_ - pt_last; pt_last = t_; } while (0)
+#else
+#define PT_MARK(k) do { } while (0)
+#endif
 
 __device__ __forceinline__ bf16x8 pack8(const f32x4 a, const f32x4 b) {
     bf16x8 f;
@@ -70,6 +78,15 @@ __device__ __forceinline__ void unpack8(const uint4 &u, float (&v)[8]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
 }
+
+// dh image [hidden unit][tile row], unpadded 64-byte rows; the two 32-byte halves (tile rows 0-15 | 16-31) of hidden units 4..7
+// (mod 8) are exchanged: a transposing read touches 8 consecutive image rows x 32 bytes per 32 lanes, which then cover 256
+// distinct bytes.  The accumulators of dh = dz2 W2 hold 4 consecutive tile rows of ONE hidden unit per lane -> one 8-byte store
+// (the [row][hidden] image of round 2 took four 2-byte stores per accumulator: 32 ds_write_b16 + ~190 VALU per tile and wave,
+// 28 % of the kernel's LDS cycles in bank conflicts).  The kernel uses this map with the lane-dependent part factored out by
+// hand (dst_lane / dbase below): written through this function the compiler re-derives one address register per (ks, rt)
+// and hoists all 32 of them out of the tile loop -- 36 spilled registers.
+__device__ __forceinline__ int dht_off(int hidden, int row) { return hidden * R + ((((row >> 4) ^ (hidden >> 2)) & 1) << 4) + (row & 15); }
 
 // rows past the end were clamped to a real row: their staged chunks are zeroed IN REGISTERS.  (Written as `ok ? stg[i] : zero`
 // the compiler selects between the LDS pointer and the address of a constant zero and loads through the result: a generic
@@ -146,8 +163,8 @@ __global__ __launch_bounds__(NT) void mlp_block_bwd_kernel(const MlpBwdArgs a) {
     auto prefetch = [&](int t) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int64_t row = min((int64_t)t * R + r0 + 16 * i, (int64_t)a.M - 1);
-            const int64_t o = row * E + 8 * c;
+            const int row = min(t * R + r0 + 16 * i, a.M - 1);        // (64-bit only in the address)
+            const int64_t o = (int64_t)row * E + 8 * c;
             dma16_opaque(a.dy + o, stg + (3 * i + 0) * NT + wave * 64);
             dma16_opaque(a.n2 + o, stg + (3 * i + 1) * NT + wave * 64);
             dma16_opaque(a.n1 + o, stg + (3 * i + 2) * NT + wave * 64);
@@ -156,17 +173,31 @@ __global__ __launch_bounds__(NT) void mlp_block_bwd_kernel(const MlpBwdArgs a) {
     };
     if (tile < ntiles) prefetch(tile);
     bool first = true;
+#ifdef MIVIT_PHASE_TIMING
+    unsigned long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt_last = __builtin_amdgcn_s_memtime();
+#endif
     for (; tile < ntiles; tile += gridDim.x) {
-        const int64_t row0 = (int64_t)tile * R;
+        const int row0 = tile * R;
         // ---------------- phase 0: LayerNorm backward (element-wise), images X and DZ ----------------
         {
             float sg[8], sb[8], sz[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) sg[e] = sb[e] = sz[e] = 0.f;
-            // the staged rows were requested one tile ago; younger than them are only the four row stores of the last
-            // phase 2 (issued by every full tile -- the one partial tile is the last of the launch)
+            // this thread's constants: six 16-byte LDS reads issued as ONE batch before the wait for the staged rows, the running
+            // column sums as one batch of six at the end (read one float at a time where they are used -- and read-modify-written
+            // one by one -- they were 28 serialised LDS round trips per tile)
+            typedef __attribute__((address_space(3))) const f32x4 lds_cf4;
+            const f32x4 g2a = *(lds_cf4 *)(gam2), g2b = *(lds_cf4 *)(gam2 + 4), g1a = *(lds_cf4 *)(gam1), g1b = *(lds_cf4 *)(gam1 + 4);
+            const f32x4 b1a = *(lds_cf4 *)(bet1), b1b = *(lds_cf4 *)(bet1 + 4);
+            const float g2v[8] = {g2a[0], g2a[1], g2a[2], g2a[3], g2b[0], g2b[1], g2b[2], g2b[3]};
+            const float g1v[8] = {g1a[0], g1a[1], g1a[2], g1a[3], g1b[0], g1b[1], g1b[2], g1b[3]};
+            const float b1v[8] = {b1a[0], b1a[1], b1a[2], b1a[3], b1b[0], b1b[1], b1b[2], b1b[3]};
+            // VM program order of a wave: P(t) [8 DMA pieces: the staged rows of tile t] | 4 row stores of tile t-1's phase 2 | this
+            // wait.  P(t) was requested one tile ago; younger than it are only those four stores (every full tile issues them,
+            // scripts/isa_check.py counts them in the ISA; the one partial tile is the last of the launch): vmcnt(4) = P(t) landed.
             if (first) wait_vm<0>(); else wait_vm<4>();
             first = false;
+            PT_MARK(0);                                            // 0: wait for the staged rows
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 float d[8], nh[8], gdy[8];
@@ -177,7 +208,7 @@ __global__ __launch_bounds__(NT) void mlp_block_bwd_kernel(const MlpBwdArgs a) {
                 float s1 = 0.f, s2 = 0.f;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    gdy[e] = d[e] * gam2[e];
+                    gdy[e] = d[e] * g2v[e];
                     s1 += gdy[e]; s2 += gdy[e] * nh[e];
                     sg[e] += d[e] * nh[e]; sb[e] += d[e];
                 }
@@ -190,59 +221,80 @@ __global__ __launch_bounds__(NT) void mlp_block_bwd_kernel(const MlpBwdArgs a) {
                 float x1v[8];
                 unpack8(pn1, x1v);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) x1v[e] = ok ? x1v[e] * gam1[e] + bet1[e] : 0.f;
+                for (int e = 0; e < 8; ++e) x1v[e] = ok ? x1v[e] * g1v[e] + b1v[e] : 0.f;
                 store16(X + (r0 + 16 * i) * LDE + 8 * c, x1v);
             }
-            cacc[0 * NT + tid] += f32x4{sg[0], sg[1], sg[2], sg[3]}; cacc[1 * NT + tid] += f32x4{sg[4], sg[5], sg[6], sg[7]};
-            cacc[2 * NT + tid] += f32x4{sb[0], sb[1], sb[2], sb[3]}; cacc[3 * NT + tid] += f32x4{sb[4], sb[5], sb[6], sb[7]};
-            cacc[4 * NT + tid] += f32x4{sz[0], sz[1], sz[2], sz[3]}; cacc[5 * NT + tid] += f32x4{sz[4], sz[5], sz[6], sz[7]};
+            f32x4 ca[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) ca[k] = cacc[k * NT + tid];
+            __builtin_amdgcn_sched_barrier(0);          // (all six reads in flight before the first add)
+            cacc[0 * NT + tid] = ca[0] + f32x4{sg[0], sg[1], sg[2], sg[3]}; cacc[1 * NT + tid] = ca[1] + f32x4{sg[4], sg[5], sg[6], sg[7]};
+            cacc[2 * NT + tid] = ca[2] + f32x4{sb[0], sb[1], sb[2], sb[3]}; cacc[3 * NT + tid] = ca[3] + f32x4{sb[4], sb[5], sb[6], sb[7]};
+            cacc[4 * NT + tid] = ca[4] + f32x4{sz[0], sz[1], sz[2], sz[3]}; cacc[5 * NT + tid] = ca[5] + f32x4{sz[4], sz[5], sz[6], sz[7]};
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the staging slots have been read: they may be refilled
+        PT_MARK(1);                                             // 1: element-wise phase
         prefetch(min(tile + (int)gridDim.x, ntiles - 1));       // next tile's rows: in flight under phases 1 and 2
         barrier();          // raw s_barrier (LDS drained): __syncthreads() also waits vmcnt(0), i.e. for the row prefetch just issued and for store acks
+        PT_MARK(2);                                             // 2: prefetch issue + barrier
         // ---------------- phase 1: u, dh for this wave's 64 hidden units; dW1, dW2 ----------------
         bf16x8 hB[4], dhB[4];
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
+        {
             // u and dh for 32 of the wave's 64 hidden units at a time (register budget): un-transposed products, so the
-            // accumulators (lane = hidden unit, registers = rows) are the row-contraction operands of the weight gradients
-            f32x4 u[2][2], dh[2][2];
+            // accumulators (lane = hidden unit, registers = rows) are the row-contraction operands of the weight gradients.
+            // (Requesting a step's operand fragments one step ahead -- 16-24 more registers in flight, built in five forms: both row
+            // tiles, one row tile at a time with copied or alternating fragment sets, W1 fragments in-step, half-step skew -- makes the
+            // compiler spill 11-39 registers of the fc2^T slice at the 512 a wave has; their scratch reloads sit in vmcnt behind the
+            // row prefetch and the row stores.  The loop stays un-prefetched: one exposed LDS round trip per 8 MFMAs.)
+            typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+            const int dst_lane = (64 * wave + cq) * R + 4 * g, dst_sw0 = (q & 1) << 4, dst_sw1 = ((q & 1) ^ 1) << 4;
 #pragma unroll
-            for (int n2 = 0; n2 < 2; ++n2) {
-                const float bv = b1f[64 * wave + 32 * hf + 16 * n2 + cq];
+            for (int hf = 0; hf < 2; ++hf) {
+                f32x4 u[2][2], dh[2][2];
 #pragma unroll
-                for (int rt = 0; rt < 2; ++rt) { u[rt][n2] = f32x4{bv, bv, bv, bv}; dh[rt][n2] = zero; }
-            }
+                for (int n2 = 0; n2 < 2; ++n2) {
+                    const float bv = b1f[64 * wave + 32 * hf + 16 * n2 + cq];
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                for (int rt = 0; rt < 2; ++rt) {
-                    const bf16x8 xa = lds_frag(X + (16 * rt + cq) * LDE + ks * 32 + 8 * g);
-                    const bf16x8 za = lds_frag(DZ + (16 * rt + cq) * LDE + ks * 32 + 8 * g);
-#pragma unroll
-                    for (int n2 = 0; n2 < 2; ++n2) {
-                        const int nt = 2 * hf + n2;
-                        u[rt][n2] = mma(xa, lds_frag(W1i + (64 * wave + 16 * nt + cq) * LDE + ks * 32 + 8 * g), u[rt][n2]);
-                        dh[rt][n2] = mma(za, w2f[nt][ks], dh[rt][n2]);
-                    }
+                    for (int rt = 0; rt < 2; ++rt) { u[rt][n2] = f32x4{bv, bv, bv, bv}; dh[rt][n2] = zero; }
                 }
 #pragma unroll
-            for (int n2 = 0; n2 < 2; ++n2) {
-                const int nt = 2 * hf + n2;
+                for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-                for (int rt = 0; rt < 2; ++rt)
+                    for (int rt = 0; rt < 2; ++rt) {
+                        const bf16x8 xa = lds_frag(X + (16 * rt + cq) * LDE + ks * 32 + 8 * g);
+                        const bf16x8 za = lds_frag(DZ + (16 * rt + cq) * LDE + ks * 32 + 8 * g);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float uu = u[rt][n2][j];
-                        dh[rt][n2][j] *= act_bwd(ACT, ACT == MIVIT_ACT_GELU ? uu : act_fwd(ACT, uu));
-                        u[rt][n2][j] = act_fwd(ACT, uu);
-                        db1[nt] += dh[rt][n2][j];
-                        DH[(16 * rt + 4 * g + j) * LDF + 64 * wave + 32 * hf + 8 * (cq >> 2) + 4 * n2 + (cq & 3)] = from_f32<bf16>(dh[rt][n2][j]);
+                        for (int n2 = 0; n2 < 2; ++n2) {
+                            const int nt = 2 * hf + n2;
+                            u[rt][n2] = mma(xa, lds_frag(W1i + (64 * wave + 16 * nt + cq) * LDE + ks * 32 + 8 * g), u[rt][n2]);
+                            dh[rt][n2] = mma(za, w2f[nt][ks], dh[rt][n2]);
+                        }
                     }
-                hB[nt] = pack8(u[0][n2], u[1][n2]);
-                dhB[nt] = pack8(dh[0][n2], dh[1][n2]);
+#pragma unroll
+                for (int n2 = 0; n2 < 2; ++n2) {
+                    const int nt = 2 * hf + n2;
+#pragma unroll
+                    for (int rt = 0; rt < 2; ++rt) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float uu = u[rt][n2][j];
+                            dh[rt][n2][j] *= act_bwd(ACT, ACT == MIVIT_ACT_GELU ? uu : act_fwd(ACT, uu));
+                            u[rt][n2][j] = act_fwd(ACT, uu);
+                            db1[nt] += dh[rt][n2][j];
+                        }
+                        // rows 16 rt + 4 g .. + 3 of hidden unit 64 wave + 16 nt + cq: one 8-byte store at dht_off(64 wave + 16 nt + cq,
+                        // 16 rt + 4 g), lane-dependent part factored out (this unit's swizzle bit is q & 1) so that (nt, rt) only add
+                        // compile-time constants
+                        const f32x4 v = dh[rt][n2];
+                        const bf16x4 vb = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                        *reinterpret_cast<bf16x4 *>(DH + dst_lane + (rt ? dst_sw1 : dst_sw0) + 16 * nt * R) = vb;
+                    }
+                    hB[nt] = pack8(u[0][n2], u[1][n2]);
+                    dhB[nt] = pack8(dh[0][n2], dh[1][n2]);
+                }
             }
         }
+        PT_MARK(3);                                             // 3: u, dh
         // weight gradients: the contraction runs over the 32 rows of the tile (slots 0-3 = rows 4g.., slots 4-7 = rows 16+4g..)
         {   // (operands of column tile t+1 are requested before the MFMAs of tile t: one wave per SIMD has nobody else to hide LDS latency)
             bf16x8 xb = tr_pair(X + (4 * g + q) * LDE + 4 * pp, X + (16 + 4 * g + q) * LDE + 4 * pp);
@@ -262,7 +314,9 @@ __global__ __launch_bounds__(NT) void mlp_block_bwd_kernel(const MlpBwdArgs a) {
                 xb = xn; zb = zn;
             }
         }
+        PT_MARK(4);                                             // 4: dW1, dW2
         barrier();          // raw s_barrier (LDS drained): __syncthreads() also waits vmcnt(0), i.e. for the row prefetch just issued and for store acks
+        PT_MARK(5);                                             // 5: barrier
         // ---------------- phase 2: dx1^T for this wave's 32 input features ----------------
         f32x4 dx[2][2];
 #pragma unroll
@@ -270,19 +324,23 @@ __global__ __launch_bounds__(NT) void mlp_block_bwd_kernel(const MlpBwdArgs a) {
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) dx[kt][rt] = zero;
         // A = W1^T read transposed out of the W1 image: k-slots 0-3 = hidden units 32ks + 4g + {0..3}, slots 4-7 = 32ks + 16 + 4g + {0..3};
-        // the DH image stores hidden unit 32b + 16hi + 4gg + j at position 32b + 8gg + 4hi + j, so its plain 16-byte read matches
+        // B = dh^T by the same transposing read out of the [hidden][row] image: identical k-slot order on both operands
         {
             auto wfrag = [&](int ks, int kt) {
                 return tr_pair(W1i + (32 * ks + 4 * g + q) * LDE + 32 * wave + 16 * kt + 4 * pp,
                                W1i + (32 * ks + 16 + 4 * g + q) * LDE + 32 * wave + 16 * kt + 4 * pp);
             };
-            bf16x8 d0 = lds_frag(DH + cq * LDF + 8 * g), d1 = lds_frag(DH + (16 + cq) * LDF + 8 * g);
+            // = tr_pair(DH + dht_off(32 ks + 4 g + q, 16 rt + 4 pp), DH + dht_off(32 ks + 16 + 4 g + q, 16 rt + 4 pp)): the swizzle bit of
+            // hidden units 32 ks (+ 16) + 4 g + q is g & 1 -- two lane-dependent bases, everything else immediate offsets
+            const bf16 *dbase[2] = {DH + (4 * g + q) * R + ((g & 1) << 4) + 4 * pp, DH + (4 * g + q) * R + (((g & 1) ^ 1) << 4) + 4 * pp};
+            auto dfrag = [&](int ks, int rt) { return tr_pair(dbase[rt] + 32 * ks * R, dbase[rt] + (32 * ks + 16) * R); };
+            bf16x8 d0 = dfrag(0, 0), d1 = dfrag(0, 1);
             bf16x8 w0 = wfrag(0, 0), w1 = wfrag(0, 1);
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
                 bf16x8 e0 = d0, e1 = d1, v0 = w0, v1 = w1;
                 if (ks < 7) {
-                    e0 = lds_frag(DH + cq * LDF + (ks + 1) * 32 + 8 * g); e1 = lds_frag(DH + (16 + cq) * LDF + (ks + 1) * 32 + 8 * g);
+                    e0 = dfrag(ks + 1, 0); e1 = dfrag(ks + 1, 1);
                     v0 = wfrag(ks + 1, 0); v1 = wfrag(ks + 1, 1);
                 }
                 dx[0][0] = mma(w0, d0, dx[0][0]); dx[0][1] = mma(w0, d1, dx[0][1]);
@@ -292,7 +350,7 @@ __global__ __launch_bounds__(NT) void mlp_block_bwd_kernel(const MlpBwdArgs a) {
         }
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
-            const int64_t row = row0 + 16 * rt + cq;
+            const int row = row0 + 16 * rt + cq;
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt) {
                 const int col = 32 * wave + 16 * kt + 4 * g;
@@ -303,12 +361,18 @@ __global__ __launch_bounds__(NT) void mlp_block_bwd_kernel(const MlpBwdArgs a) {
                 if (row < a.M) {
                     typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
                     const bf16x4 ob = {(__bf16)o[0], (__bf16)o[1], (__bf16)o[2], (__bf16)o[3]};
-                    *reinterpret_cast<bf16x4 *>(a.dx1 + row * E + col) = ob;
+                    *reinterpret_cast<bf16x4 *>(a.dx1 + (int64_t)row * E + col) = ob;
                 }
             }
         }
+        PT_MARK(6);                                             // 6: dx1 + row stores
         barrier();          // raw s_barrier (LDS drained): __syncthreads() also waits vmcnt(0), i.e. for the row prefetch just issued and for store acks
+        PT_MARK(7);                                             // 7: barrier
     }
+#ifdef MIVIT_PHASE_TIMING
+    if (a.dbg && lane == 0)
+        for (int k = 0; k < 8; ++k) a.dbg[((int64_t)blockIdx.x * NW + wave) * 8 + k] = pt[k];
+#endif
 
     // ---------------- partial gradients -> this workgroup's slab ----------------
     float *sl = a.slabs + (int64_t)blockIdx.x * SL_TOTAL;
@@ -511,8 +575,13 @@ int launch_mlp_block_bwd(const void *dy, const void *n2, const float *rstd2, con
     MIVIT_CHECK(ws_bytes >= mlp_block_bwd_ws_bytes(M), "mlp_block_bwd: workspace too small");
     MlpBwdArgs a{static_cast<const bf16 *>(dy), static_cast<const bf16 *>(n2), rstd2, gamma2, static_cast<const bf16 *>(n1), gamma1,
                  beta1, static_cast<const bf16 *>(W1), b1, static_cast<const bf16 *>(W2), M, static_cast<bf16 *>(dx1),
-                 static_cast<float *>(ws)};
+                 static_cast<float *>(ws), nullptr};
     const int grid = grid_for(M);
+#ifdef MIVIT_PHASE_TIMING
+    static unsigned long long *dbg_buf = nullptr;
+    if (!dbg_buf) MIVIT_HIP(hipMalloc(&dbg_buf, 256 * NW * 8 * sizeof(unsigned long long)));
+    a.dbg = dbg_buf;
+#endif
     {
         ProfScope prof(s);
 #define BWD_LAUNCH(ACT_)                                                                                         \
@@ -530,6 +599,24 @@ int launch_mlp_block_bwd(const void *dy, const void *n2, const float *rstd2, con
 #undef BWD_LAUNCH
         MIVIT_LAUNCH_CHECK();
     }
+#ifdef MIVIT_PHASE_TIMING
+    {
+        static const char *names[8] = {"wait rows", "element-wise", "prefetch+barrier", "u, dh", "dW1, dW2", "barrier", "dx1 + stores", "barrier"};
+        std::vector<unsigned long long> h((size_t)grid * NW * 8);
+        MIVIT_HIP(hipStreamSynchronize(s));
+        MIVIT_HIP(hipMemcpy(h.data(), dbg_buf, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        const int tiles = ceil_div(M, R);
+        double tot = 0;
+        for (int k = 0; k < 8; ++k) {
+            double sum = 0;
+            for (int i = 0; i < grid * NW; ++i) sum += (double)h[(size_t)i * 8 + k];
+            const double per_tile = sum * grid / NW / tiles / grid;          // shader-clock cycles per tile of one workgroup, wave average
+            tot += per_tile;
+            fprintf(stderr, "[mlp_block_bwd phases] %-18s %8.1f cycles/tile\n", names[k], per_tile * grid);
+        }
+        fprintf(stderr, "[mlp_block_bwd phases] total %8.1f cycles/tile, %d tiles, grid %d\n", tot * grid, tiles, grid);
+    }
+#endif
     const float *sl = static_cast<const float *>(ws);
     if (db1 == dW1 + SL_B1 && dW2 == dW1 + SL_W2 && db2 == dW1 + SL_B2 && dgamma2 == dW1 + SL_G2 && dbeta2 == dW1 + SL_BE2)
         return launch_slab_reduce_strided(sl, grid, SL_TOTAL, SL_TOTAL, dW1, s);          // the arena's layout: one launch
