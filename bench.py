@@ -219,7 +219,8 @@ def main():
         for k, (ms, c) in sorted(cat.items(), key=lambda kv: -kv[1][0]):
             print(f"  {k:14s} {ms:9.3f} ms/step  {c:4d} launches/step  {100 * ms / max(tot, 1e-9):5.1f}%", file=sys.stderr)
     dom_tag = N.PROF_TAGS.index(dominant)
-    layer_tags = ("linear_fwd", "linear_dgrad", "linear_wgrad", "attn_fwd", "attn_bwd", "ln_fwd", "ln_bwd")
+    layer_tags = ("linear_fwd", "linear_dgrad", "linear_wgrad", "attn_fwd", "attn_bwd", "ln_fwd", "ln_bwd", "attn_block_fwd",
+                  "mlp_block_fwd", "mlp_block_bwd", "attn_out_bwd", "attn_core_bwd", "qkv_wgrad", "qkv_dgrad")
     N.lib.mivit_profile_enable(ctypes.c_uint64(1 << dom_tag))
 
     # ---- timed region: EXACTLY --steps steps ----
@@ -308,21 +309,54 @@ def main():
                     "launch_ms": round(k_ms, 4), "launches_timed": cnt.value,
                     "algorithmic_bytes_per_launch": byt}
         # encoder-layer family (everything between the embedding LayerNorm and the final norm, forward + backward): HBM-bound
-        # at these widths.  Algorithmic bytes = what the launches must move given what is kept for the backward, in units of
-        # U = one [tokens, E] activation: per layer forward 8 U (attention block: x in, n1 + ctx + q|k|v out; feed-forward
-        # block: n1 in, n2 out), backward 25 U (feed-forward block 4; LayerNorm-1 + out-projection wgrad + dgrad in one pass
-        # 5; attention 7; q|k|v wgrad 4 + dgrad 5) -- see DESIGN.md section 6.
+        # at these widths.  Two byte counts, in units of U = one [tokens, E] activation:
+        #  * design bytes -- what THIS design's launches must move given what it keeps for the backward: per layer forward 8 U
+        #    (attention block: x in, n1 + ctx + q|k|v out; feed-forward block: n1 in, n2 out), backward 25 U (feed-forward
+        #    block 4; LayerNorm-1 + out-projection 5; attention core 7; q|k|v wgrad 4 + dgrad 5) = 33 U;
+        #  * algorithmic floor -- inputs, outputs and the minimum saved set under full recompute: a layer reads x and writes
+        #    its output in the forward (2 U, the output being the next layer's saved input), and reads x and dy and writes dx
+        #    in the backward (3 U): 5 U per layer.  The gap between the two is activations this design saves instead of
+        #    recomputing; `frac_of_floor` is the honest distance from the roofline.
+        # The byte model belongs to the fused path (bf16, E 128 / F 256 / 4 heads, S <= 64): other paths report times only.
         S = T + 1
         U = Bg * S * E * ts
-        layer_bytes = L * 33 * U
-        layer_ms = sum(cat[k][0] for k in layer_tags)
-        roof_layers = {"kernels": list(layer_tags), "bound": "hbm", "achieved": round(layer_bytes / (layer_ms * 1e-3) / 1e9, 1),
-                       "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(layer_bytes / (layer_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                       "traffic": None, "ms_per_step": round(layer_ms, 4), "algorithmic_bytes_per_step": layer_bytes,
-                       "share_of_step": round(layer_ms / (1e3 * dt / args.steps), 3)} if layer_ms > 0 else None
+        Mtok = Bg * S
+        fused_path = bool(args.precision == "bf16" and N.lib.mivit_fused_layer_supported(N.BF16, E, Fh, H, S)
+                          and not os.environ.get("MIVIT_NO_FUSED_LAYER"))
+        layer_ms = sum(cat[k][0] for k in layer_tags if k in cat)
+        roof_layers = None
+        if layer_ms > 0:
+            roof_layers = {"kernels": [k for k in layer_tags if cat.get(k, (0, 0))[0] > 0], "path": "fused" if fused_path else "general",
+                           "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "ms_per_step": round(layer_ms, 4),
+                           "share_of_step": round(layer_ms / (1e3 * dt / args.steps), 3), "traffic": None}
+            if fused_path:
+                design, floor = L * 33 * U, L * 5 * U
+                roof_layers.update({
+                    "achieved": round(design / (layer_ms * 1e-3) / 1e9, 1), "frac": round(design / (layer_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    "algorithmic_bytes_per_step": design, "bytes_model": "design: 33 U per layer (what this design saves and re-reads)",
+                    "algorithmic_floor_bytes_per_step": floor, "floor_model": "5 U per layer (x, out | x, dy, dx; everything else recomputed)",
+                    "frac_of_floor": round(floor / (layer_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
+        # per-kernel table of the fused path: ms per step, design bytes, algorithmic FLOPs, fraction of both roofs
+        fused_kernels = None
+        if fused_path:
+            spec = {   # name: (U per layer, FLOPs per token and layer)
+                "attn_block_fwd": (6, 8 * E * E + 4 * S * E), "mlp_block_fwd": (2, 4 * E * Fh), "mlp_block_bwd": (4, 10 * E * Fh),
+                "attn_out_bwd": (5, 4 * E * E), "attn_core_bwd": (7, 10 * S * E), "qkv_wgrad": (4, 6 * E * E), "qkv_dgrad": (5, 6 * E * E)}
+            fused_kernels = {}
+            for k, (nu, fl_tok) in spec.items():
+                ms_k = cat.get(k, (0.0, 0))[0]
+                if ms_k <= 0:
+                    continue
+                byt_k, fl_k = L * nu * U, L * fl_tok * Mtok
+                fused_kernels[k] = {"ms": round(ms_k, 4), "bytes": byt_k, "flops": fl_k,
+                                    "frac_hbm": round(byt_k / (ms_k * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                    "frac_mfma": round(fl_k / (ms_k * 1e-3) / 1e12 / MFMA_PEAK["bf16"], 4)}
+            if fused_kernels:
+                worst = min(fused_kernels, key=lambda k: max(fused_kernels[k]["frac_hbm"], fused_kernels[k]["frac_mfma"]))
+                fused_kernels["furthest_below_its_roof"] = worst
         # HBM traffic from the PMC passes committed under profiles/ (rocprofv3 cannot run inside this process): used only
         # when it was collected at this per-GPU batch
-        for fname in ("r02_pmc.json", "r01_pmc_embed.json"):
+        for fname in ("r03_pmc.json", "r02_pmc.json", "r01_pmc_embed.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", fname)) as fh:
                     pmc = json.load(fh)
@@ -330,7 +364,7 @@ def main():
                     if roof is not None and roof["traffic"] is None and dominant in pmc.get("kernels", {}):
                         roof["traffic"] = pmc["kernels"][dominant]["hbm_bytes_per_launch"]
                         roof["traffic_source"] = "profiles/" + fname
-                    if roof_layers is not None and roof_layers["traffic"] is None and "layers_hbm_bytes_per_step" in pmc:
+                    if roof_layers is not None and fused_path and roof_layers["traffic"] is None and "layers_hbm_bytes_per_step" in pmc:
                         roof_layers["traffic"] = pmc["layers_hbm_bytes_per_step"]
                         roof_layers["traffic_source"] = "profiles/" + fname
             except (OSError, ValueError, KeyError):
@@ -351,6 +385,7 @@ def main():
             "attn_mlp_mfma_frac": round(3 * fl["attn_mlp_fwd"] * seqs / dt / 1e12 / world / MFMA_PEAK[args.precision], 5),
             "roofline": roof,
             "roofline_layers": roof_layers,
+            "fused_layer_kernels": fused_kernels,
             "kernel_ms_per_step": {k: round(v[0], 4) for k, v in cat.items()},
         }
         line.update(extras)

@@ -350,7 +350,15 @@ enum {
     MIVIT_PROF_LN_FWD = 7,
     MIVIT_PROF_LN_BWD = 8,
     MIVIT_PROF_OP = 9,
-    MIVIT_PROF_NUM_TAGS = 10
+    /* the launches of the fused encoder-layer path (bf16, E 128 / F 256 / 4 heads), one tag per kernel: */
+    MIVIT_PROF_ATTN_BLOCK_FWD = 10, /* LayerNorm affine + q|k|v + attention + out-proj + residual + LayerNorm-1 (fused_fwd.hip) */
+    MIVIT_PROF_MLP_BLOCK_FWD = 11,  /* fc1 + activation + fc2 + residual + LayerNorm-2                                    */
+    MIVIT_PROF_MLP_BLOCK_BWD = 12,  /* their backward incl. all six parameter gradients (fused_bwd.hip)                   */
+    MIVIT_PROF_ATTN_OUT_BWD = 13,   /* LayerNorm-1 backward + out-projection data / weight gradient                       */
+    MIVIT_PROF_ATTN_CORE_BWD = 14,  /* attention core backward (attention_fast.hip)                                       */
+    MIVIT_PROF_QKV_WGRAD = 15,      /* q|k|v weight gradient (wgrad_dma.hip) + affine fix-up                              */
+    MIVIT_PROF_QKV_DGRAD = 16,      /* q|k|v data gradient + residual gradient (rowstream.hip)                            */
+    MIVIT_PROF_NUM_TAGS = 17
 };
 int mivit_profile_enable(uint64_t tag_mask);   /* 0 disables */
 int mivit_profile_collect(int tag, double *total_ms, int *count);

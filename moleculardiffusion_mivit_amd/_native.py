@@ -128,7 +128,8 @@ SYMBOLS = {
     "mivit_profile_tag_name": (c_char_p, [c_int]),
 }
 PROF_TAGS = ["embed_fwd", "embed_wgrad", "linear_fwd", "linear_dgrad", "linear_wgrad", "attn_fwd", "attn_bwd",
-             "ln_fwd", "ln_bwd", "op"]
+             "ln_fwd", "ln_bwd", "op", "attn_block_fwd", "mlp_block_fwd", "mlp_block_bwd", "attn_out_bwd", "attn_core_bwd",
+             "qkv_wgrad", "qkv_dgrad"]
 
 
 class MivitError(RuntimeError):

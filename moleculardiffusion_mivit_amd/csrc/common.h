@@ -374,6 +374,7 @@ int launch_affine_fixup(float *dW, const float *db, const float *gamma, const fl
 
 // in-library kernel timing (misc.hip): the engine sets the category, launch sites bracket their main kernel
 void prof_set_tag(int tag);
+void prof_pin_tag(int tag);          // >= 0: every prof_set_tag until prof_pin_tag(-1) resolves to this tag
 bool prof_begin(hipStream_t s);
 void prof_end(hipStream_t s);
 struct ProfScope {

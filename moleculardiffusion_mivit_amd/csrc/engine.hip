@@ -466,11 +466,11 @@ static int forward_impl(const mivit_plan *plan, const float *params, const float
             const LayerParams &lp = plan->layers[l];
             const Ws::L &b = w.layer[l];
             const bool last = l + 1 == c.num_layers;
-            prof_set_tag(MIVIT_PROF_ATTN_FWD);
+            prof_set_tag(MIVIT_PROF_ATTN_BLOCK_FWD);
             RC(launch_attn_block_fwd(nin, gin, bin, WT(lp.qkv_w), P + lp.qkv_b, WT(lp.out_w), P + lp.out_b, P + lp.n1_w,
                                      P + lp.n1_b, B, S, at(ws, b.ctx), at(ws, b.z1), static_cast<float *>(at(ws, b.rstd1)),
                                      nullptr, nullptr, nullptr, need_backward ? at(ws, b.qkv) : nullptr, s));
-            prof_set_tag(MIVIT_PROF_LINEAR_FWD);
+            prof_set_tag(MIVIT_PROF_MLP_BLOCK_FWD);
             RC(launch_mlp_block_fwd(at(ws, b.z1), P + lp.n1_w, P + lp.n1_b, WT(lp.fc1_w), P + lp.fc1_b, WT(lp.fc2_w), P + lp.fc2_b,
                                     P + lp.n2_w, P + lp.n2_b, M, c.activation, at(ws, b.z2), static_cast<float *>(at(ws, b.rstd2)),
                                     last ? at(ws, w.xL) : nullptr, nullptr, nullptr, nullptr, nullptr, s));      // (h is recomputed by the fused backward)
@@ -631,7 +631,7 @@ static int backward_impl(const mivit_plan *plan, const float *params, const floa
             if (fz) {
                 // feed-forward block in one launch (fused_bwd.hip): d(x2) -> d(x1), all six parameter gradients
                 dx1 = at(ws, w.dxb); dz1 = at(ws, w.dF);
-                prof_set_tag(MIVIT_PROF_LINEAR_DGRAD);
+                prof_set_tag(MIVIT_PROF_MLP_BLOCK_BWD);
                 RC(launch_mlp_block_bwd(at(ws, w.dxa), at(ws, b.z2), static_cast<const float *>(at(ws, b.rstd2)), P + lp.n2_w,
                                         at(ws, b.z1), P + lp.n1_w, P + lp.n1_b, WT(lp.fc1_w), P + lp.fc1_b, WT(lp.fc2_w), M,
                                         c.activation, dx1, G + lp.fc1_w, G + lp.fc1_b, G + lp.fc2_w, G + lp.fc2_b, G + lp.n2_w,
@@ -647,7 +647,7 @@ static int backward_impl(const mivit_plan *plan, const float *params, const floa
             }
             if (fz) {
                 // LayerNorm-1 backward + out-projection weight / data gradient in one launch (fused_bwd.hip)
-                prof_set_tag(MIVIT_PROF_LINEAR_DGRAD);
+                prof_set_tag(MIVIT_PROF_ATTN_OUT_BWD);
                 RC(launch_attn_out_bwd(dx1, at(ws, b.z1), static_cast<const float *>(at(ws, b.rstd1)), P + lp.n1_w, at(ws, b.ctx),
                                        WT(lp.out_w), M, dz1, at(ws, w.dctx), G + lp.out_w, G + lp.out_b, G + lp.n1_w, G + lp.n1_b,
                                        wg, wgb, s));
@@ -661,12 +661,18 @@ static int backward_impl(const mivit_plan *plan, const float *params, const floa
             RC(lin_dgrad(dt, dz1, E, WT(lp.out_w), M, E, E, MIVIT_ACT_NONE, nullptr, 0, nullptr, 0,
                          at(ws, w.dctx), E, 0, s));
             }
-            prof_set_tag(MIVIT_PROF_ATTN_BWD); RC(launch_attention_bwd(dt, at(ws, b.qkv), at(ws, w.dctx), B, S, H, Dh, at(ws, w.dqkv), s));
-            RC(lin_wgrad(dt, at(ws, w.dqkv), 3 * E, xin, 0, E, M, 3 * E, E, G + lp.qkv_w, G + lp.qkv_b, wg, wgb, s));
-            if (fz && l > 0)
-                RC(launch_affine_fixup(G + lp.qkv_w, G + lp.qkv_b, P + plan->layers[l - 1].n2_w, P + plan->layers[l - 1].n2_b, 3 * E, E, s));
-            RC(lin_dgrad(dt, at(ws, w.dqkv), 3 * E, WT(lp.qkv_w), M, 3 * E, E, MIVIT_ACT_NONE, nullptr, 0, dz1,
-                         E, at(ws, w.dxa), E, 0, s));                                             // dxa = d(x_in)
+            prof_set_tag(fz ? MIVIT_PROF_ATTN_CORE_BWD : MIVIT_PROF_ATTN_BWD);
+            RC(launch_attention_bwd(dt, at(ws, b.qkv), at(ws, w.dctx), B, S, H, Dh, at(ws, w.dqkv), s));
+            if (fz) prof_pin_tag(MIVIT_PROF_QKV_WGRAD);
+            int rc_q = lin_wgrad(dt, at(ws, w.dqkv), 3 * E, xin, 0, E, M, 3 * E, E, G + lp.qkv_w, G + lp.qkv_b, wg, wgb, s);
+            if (!rc_q && fz && l > 0)
+                rc_q = launch_affine_fixup(G + lp.qkv_w, G + lp.qkv_b, P + plan->layers[l - 1].n2_w, P + plan->layers[l - 1].n2_b, 3 * E, E, s);
+            if (fz) prof_pin_tag(MIVIT_PROF_QKV_DGRAD);
+            if (!rc_q)
+                rc_q = lin_dgrad(dt, at(ws, w.dqkv), 3 * E, WT(lp.qkv_w), M, 3 * E, E, MIVIT_ACT_NONE, nullptr, 0, dz1,
+                                 E, at(ws, w.dxa), E, 0, s);                                      // dxa = d(x_in)
+            prof_pin_tag(-1);
+            RC(rc_q);
         } else {
             // ---- token assembly + embedding; dxa holds d(x0) [B,S,E] ----
             if (c.use_pos_encoding) {

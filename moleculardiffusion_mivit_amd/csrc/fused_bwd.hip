@@ -610,11 +610,11 @@ int launch_mlp_block_bwd(const void *dy, const void *n2, const float *rstd2, con
         for (int k = 0; k < 8; ++k) {
             double sum = 0;
             for (int i = 0; i < grid * NW; ++i) sum += (double)h[(size_t)i * 8 + k];
-            const double per_tile = sum * grid / NW / tiles / grid;          // shader-clock cycles per tile of one workgroup, wave average
+            const double per_tile = sum / NW / tiles;                       // shader-clock cycles per tile of one workgroup, wave average
             tot += per_tile;
-            fprintf(stderr, "[mlp_block_bwd phases] %-18s %8.1f cycles/tile\n", names[k], per_tile * grid);
+            fprintf(stderr, "[mlp_block_bwd phases] %-18s %8.1f cycles/tile\n", names[k], per_tile);
         }
-        fprintf(stderr, "[mlp_block_bwd phases] total %8.1f cycles/tile, %d tiles, grid %d\n", tot * grid, tiles, grid);
+        fprintf(stderr, "[mlp_block_bwd phases] total %8.1f cycles/tile, %d tiles, grid %d\n", tot, tiles, grid);
     }
 #endif
     const float *sl = static_cast<const float *>(ws);

@@ -40,12 +40,18 @@ struct ProfState {
 };
 ProfState g_prof;
 thread_local int t_tag = MIVIT_PROF_OP;
+thread_local int t_override = -1;             // >= 0: the engine pins the tag across helper calls that set their own
 thread_local hipEvent_t t_start = nullptr;
 const char *kTagNames[MIVIT_PROF_NUM_TAGS] = {"embed_fwd", "embed_wgrad", "linear_fwd", "linear_dgrad", "linear_wgrad",
-                                              "attn_fwd", "attn_bwd", "ln_fwd", "ln_bwd", "op"};
+                                              "attn_fwd", "attn_bwd", "ln_fwd", "ln_bwd", "op", "attn_block_fwd", "mlp_block_fwd",
+                                              "mlp_block_bwd", "attn_out_bwd", "attn_core_bwd", "qkv_wgrad", "qkv_dgrad"};
 }  // namespace
 
-void prof_set_tag(int tag) { t_tag = (tag >= 0 && tag < MIVIT_PROF_NUM_TAGS) ? tag : MIVIT_PROF_OP; }
+void prof_set_tag(int tag) {
+    if (t_override >= 0) tag = t_override;
+    t_tag = (tag >= 0 && tag < MIVIT_PROF_NUM_TAGS) ? tag : MIVIT_PROF_OP;
+}
+void prof_pin_tag(int tag) { t_override = tag; if (tag >= 0) t_tag = tag; }
 bool prof_begin(hipStream_t s) {
     if (!((g_prof.mask >> t_tag) & 1ull)) return false;
     std::lock_guard<std::mutex> lk(g_prof.mu);

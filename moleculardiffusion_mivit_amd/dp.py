@@ -23,6 +23,8 @@ class StagedGradReducer:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self._comm = None
         self._events = {}
+        self._done = {}
+        self._last_done = None
 
     def reduce_stage(self, grads: torch.Tensor, stage: int):
         b, e = self.stage_ranges[stage]
@@ -39,13 +41,23 @@ class StagedGradReducer:
             self._comm.wait_event(ev)
             with torch.cuda.stream(self._comm):
                 dist.all_reduce(grads[b:e], group=self.group)
+                done = self._done.get(stage)
+                if done is None:
+                    done = self._done[stage] = torch.cuda.Event()
+                done.record(self._comm)
+                self._last_done = done
         else:
             dist.all_reduce(grads[b:e], group=self.group)
 
     def finish(self, grads: torch.Tensor):
-        if grads.device.type == "cuda" and self._comm is not None:
-            torch.cuda.current_stream(grads.device).wait_stream(self._comm)
+        """Order whatever consumes the gradients (the optimizer step) after the LAST slice's all-reduce -- an event wait, not a
+        stream join: collectives of other models or of `finish_external_grads` queued on the communication stream later do
+        not hold the main stream back.  The last slice is the frame embedding's (its weight gradient is the last kernel of
+        backpropagation: nothing is left to overlap its 2.1 MB all-reduce with -- the one exposed collective of a step)."""
+        if grads.device.type == "cuda" and self._comm is not None and self._last_done is not None:
+            torch.cuda.current_stream(grads.device).wait_event(self._last_done)
             grads.record_stream(self._comm)
+            self._last_done = None
 
 
 def broadcast_parameters(model, src: int = 0, group=None):
