@@ -713,8 +713,11 @@ static int backward_impl(const mivit_plan *plan, const float *params, const floa
 // C-ABI entry points.  Small problems are launch-bound (~100 short kernels per call): a call whose arguments were seen
 // before is captured once into a hipGraph on an internal stream and replayed on the caller's stream afterwards.
 // ------------------------------------------------------------------------------------------------
+// "Small" = launch-bound: the kernels of a narrow model are short at row counts where those of a wide one are not, so the
+// limit is on activation ELEMENTS (token rows x embedding width; 65 536 rows at E = 128, 131 072 at the reference's E = 64:
+// its Framerate shape at 4096 sequences per step, ~100 launches of 10-30 us each, is replayed instead of launched).
 static bool graph_sized(const mivit_plan *plan, int B, int T) {
-    return plan && (int64_t)B * (T + 1) <= 65536;
+    return plan && (int64_t)B * (T + 1) * plan->c.embed_dim <= 65536LL * 128;
 }
 
 extern "C" int mivit_forward(const mivit_plan *plan, const float *params, const float *x, const float *features, int B,
