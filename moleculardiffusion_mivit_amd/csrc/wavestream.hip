@@ -1,4 +1,5 @@
-// bf16 "wave-stream" GEMMs of the encoder-layer projections (K = 64 / 128 / 256 contraction, 128- or 64-column slices):
+// bf16 "wave-stream" GEMMs of the encoder-layer projections (K = 64 / 128 / 256 contraction -- 192 for the q|k|v data gradient
+// of 64-wide models --, 128- or 64-column slices):
 //      forward : C = act(A W^T + b) (+ residual) (+ fused post-norm LayerNorm when the slice is the whole row)
 //      dgrad   : C = (A W) * act'(saved)  |  + residual gradient
 // Same arithmetic and interface as the row-stream kernels (rowstream.hip), different data movement: these launches are
@@ -212,7 +213,9 @@ bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 
 bool wavestream_supported(int M, int N, int K, bool dgrad, int64_t lda, int64_t ldw, const void *A, const void *W) {
     static const bool off = getenv("MIVIT_NO_WAVESTREAM") != nullptr;
     if (off) return false;
-    if (!(K == 64 || K == 128 || K == 256) || N % 64 != 0 || M < 256) return false;
+    // (K = 192: the q|k|v data gradient of the 64-wide models -- contraction over 3 E = 192, 64 output columns; it ran on the
+    //  general register-staged GEMM before: 54 us per layer at the Framerate shape against ~20 us for its neighbours)
+    if (!(K == 64 || K == 128 || K == 256 || (K == 192 && dgrad && N == 64)) || N % 64 != 0 || M < 256) return false;
     if (K == 256 && N % 128 != 0) return false;
     if (lda % 8 || ldw % 8 || !aligned16(A) || !aligned16(W)) return false;
     return true;
@@ -240,6 +243,12 @@ int launch_wavestream(bool dgrad, const void *A, int64_t lda, const void *W_bf16
         return ws_dispatch<256, 128>(a, dgrad, ln, s);
     }
     if (K == 64) return ws_dispatch<64, 64>(a, dgrad, ln, s);
+    if (K == 192) {
+        MIVIT_CHECK(dgrad, "wavestream: K = 192 is a data-gradient shape");
+        if (a.dact) return ws_launch<192, 64, true, false, 2>(a, s);
+        if (a.resid) return ws_launch<192, 64, true, false, 3>(a, s);
+        return ws_launch<192, 64, true, false, 0>(a, s);
+    }
     return ws_dispatch<128, 64>(a, dgrad, ln, s);
 }
 

@@ -228,7 +228,8 @@ def test_rowstream_forward_exact(M, N, K, variant, family):
 
 
 @pytest.mark.parametrize("M,N,K", [(264, 128, 128), (1000, 128, 256), (4130, 256, 128), (900, 384, 128),
-                                   (300, 64, 64), (1000, 64, 192), (515, 128, 64), (700, 64, 128)])
+                                   (300, 64, 64), (1000, 64, 192), (515, 128, 64), (700, 64, 128),
+                                   (1000, 192, 64), (4133, 192, 64)])      # q|k|v data gradient of the 64-wide models
 @pytest.mark.parametrize("variant", ["plain", "dact_relu", "dres"])
 @pytest.mark.parametrize("family", ["rowstream", "wavestream"])
 def test_rowstream_dgrad_exact(M, N, K, variant, family):
