@@ -428,7 +428,8 @@ int attention_max_seq(int dtype, int Dh) {
     int best = 0;
     for (int S = 1; S <= 128; ++S) {
         const AttnDims d = dtype == MIVIT_F32 ? make_dims<float>(1, S, 1, Dh, true) : make_dims<bf16>(1, S, 1, Dh, true);
-        if ((size_t)d.per_wave * dtype_size(dtype) <= LDS_LIMIT || attention_fast_supported(dtype, S, Dh)) best = S;
+        if ((size_t)d.per_wave * dtype_size(dtype) <= LDS_LIMIT || attention_fast_supported(dtype, S, Dh) ||
+            attention_fast_supported_f16(dtype, S, Dh)) best = S;
     }
     return best;
 }
@@ -436,6 +437,7 @@ int attention_max_seq(int dtype, int Dh) {
 int launch_attention_fwd(int dtype, const void *qkv, int B, int S, int H, int Dh, void *ctx, hipStream_t s) {
     MIVIT_CHECK(B > 0 && S > 0 && H > 0 && Dh > 0, "attention_fwd: empty problem");
     if (attention_fast_supported(dtype, S, Dh)) return launch_attention_fwd_fast(qkv, B, S, H, Dh, ctx, s);
+    if (attention_fast_supported_f16(dtype, S, Dh)) return launch_attention_fwd_fast_f16(qkv, B, S, H, Dh, ctx, s);     // (elem.h: the same unit compiled for IEEE half)
     return dtype == MIVIT_F32 ? attn_fwd_t<float>(qkv, B, S, H, Dh, ctx, s)
          : dtype == MIVIT_BF16 ? attn_fwd_t<bf16>(qkv, B, S, H, Dh, ctx, s) : attn_fwd_t<f16>(qkv, B, S, H, Dh, ctx, s);
 }
@@ -443,6 +445,7 @@ int launch_attention_bwd(int dtype, const void *qkv, const void *dctx, int B, in
                          hipStream_t s) {
     MIVIT_CHECK(B > 0 && S > 0 && H > 0 && Dh > 0, "attention_bwd: empty problem");
     if (attention_fast_supported(dtype, S, Dh)) return launch_attention_bwd_fast(qkv, dctx, B, S, H, Dh, dqkv, s);
+    if (attention_fast_supported_f16(dtype, S, Dh)) return launch_attention_bwd_fast_f16(qkv, dctx, B, S, H, Dh, dqkv, s);
     return dtype == MIVIT_F32 ? attn_bwd_t<float>(qkv, dctx, B, S, H, Dh, dqkv, s)
          : dtype == MIVIT_BF16 ? attn_bwd_t<bf16>(qkv, dctx, B, S, H, Dh, dqkv, s) : attn_bwd_t<f16>(qkv, dctx, B, S, H, Dh, dqkv, s);
 }

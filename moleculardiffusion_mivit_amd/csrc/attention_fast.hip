@@ -16,6 +16,7 @@
 #include "common.h"
 #include <stdlib.h>
 #include "stream_prims.h"
+#include "elem.h"          // element type of this translation unit (bf16, or f16 under -DMIVIT_ELEM_F16): after every other include
 
 namespace {
 
@@ -385,7 +386,7 @@ __device__ __forceinline__ k16_t tr4(const bf16 *img, int ld, int trow, int col0
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4 *)(img + row * ld + (SWZ ? (col ^ (((row >> 2) & 1) << 4)) : col)));
 }
 __device__ __forceinline__ f32x4 mma16(k16_t a, k16_t b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+    return ELEM_MFMA_16x16x16(a, b, c);
 }
 
 template <int NT, int ND>
@@ -629,7 +630,7 @@ int bwd_launch(const bf16 *qkv, const bf16 *dctx, bf16 *dqkv, const FastDims &d,
 
 bool attention_fast_supported(int dtype, int S, int Dh) {
     // one wavefront holds the whole (batch, head) problem in registers: the backward's register budget sets the limit
-    if (dtype != MIVIT_BF16 || S < 1) return false;
+    if (dtype != MIVIT_ELEM_DTYPE || S < 1) return false;
     // (up to 5 token tiles at Dh = 64 / 7 at 32 / 8 at 16 compile without scratch; the longer ones spill a little in the
     //  backward but keep every sequence the reference's 128-entry positional table allows on this path)
     const int NT = (S + 15) / 16;

@@ -11,7 +11,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 ROOT = os.path.dirname(PKG)
 SOURCES = ["gemm.hip", "norm.hip", "attention.hip", "attention_fast.hip", "embed.hip", "rowstream.hip", "wavestream.hip", "gemm_dma.hip", "wgrad_dma.hip", "wgrad_small.hip", "fused_fwd.hip", "fused_bwd.hip", "render.hip", "deepresnet.hip", "deepresnet_train.hip", "misc.hip", "engine.hip"]
-HEADERS = [os.path.join(HERE, "common.h"), os.path.join(HERE, "stream_prims.h"), os.path.join(ROOT, "include", "mivit_hip.h")]
+HEADERS = [os.path.join(HERE, "common.h"), os.path.join(HERE, "stream_prims.h"), os.path.join(HERE, "elem.h"),
+           os.path.join(ROOT, "include", "mivit_hip.h")]
+# the streaming kernels whose element type is chosen per translation unit (elem.h): each is compiled a second time with
+# -DMIVIT_ELEM_F16 (IEEE half instead of bf16, every external suffixed _f16) and both objects go into the library
+ELEM_SOURCES = ["rowstream.hip", "wavestream.hip", "wgrad_dma.hip", "wgrad_small.hip", "attention_fast.hip", "embed.hip"]
 LIB = os.path.join(PKG, "libmivit_hip.so")
 # the same library with every counted s_waitcnt vmcnt(N) of stream_prims.h::wait_vm turned into vmcnt(0) (-DMIVIT_STRICT_WAITS).
 # TEST INFRASTRUCTURE ONLY: tests/test_strict_waits_gpu.py runs the bench-scale shapes through both and requires bitwise-equal
@@ -25,7 +29,7 @@ OBJDIR = os.path.join(HERE, "build")
 # wgrad / gemm kernels 144-252 -> 94-186 registers.  Kernels that need more than 256 accumulators + operands (mlp_block_bwd,
 # the 128 x 128 wave tile) still get AGPRs for the part that does not fit.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
-         "-Wno-unused-variable", "-fno-gpu-rdc", "-mllvm", "-amdgpu-mfma-vgpr-form"]
+         "-Wno-unused-variable", "-Wno-inline-asm", "-fno-gpu-rdc", "-mllvm", "-amdgpu-mfma-vgpr-form"]
 
 
 def _hipcc():
@@ -51,10 +55,15 @@ def build(force=False, verbose=True, strict=True):
         o = os.path.join(OBJDIR, src.replace(".hip", ".o"))
         if force or _stale(o, [s, os.path.abspath(__file__)] + HEADERS):        # the flags live in this file
             jobs.append((s, o, []))
-        if strict and src in WAIT_SOURCES:
-            o = os.path.join(OBJDIR, src.replace(".hip", ".strict.o"))
+        variants = [(".strict.o", ["-DMIVIT_STRICT_WAITS"])] if strict and src in WAIT_SOURCES else []
+        if src in ELEM_SOURCES:
+            variants.append((".f16.o", ["-DMIVIT_ELEM_F16"]))
+            if strict and src in WAIT_SOURCES:
+                variants.append((".f16.strict.o", ["-DMIVIT_ELEM_F16", "-DMIVIT_STRICT_WAITS"]))
+        for ext, extra in variants:
+            o = os.path.join(OBJDIR, src.replace(".hip", ext))
             if force or _stale(o, [s, os.path.abspath(__file__)] + HEADERS):
-                jobs.append((s, o, ["-DMIVIT_STRICT_WAITS"]))
+                jobs.append((s, o, extra))
 
     def compile_one(job):
         s, o, extra = job
@@ -70,7 +79,9 @@ def build(force=False, verbose=True, strict=True):
     with ThreadPoolExecutor(max_workers=min(os.cpu_count() or 4, 8, max(1, len(jobs)))) as ex:
         list(ex.map(compile_one, jobs))
     objs = [os.path.join(OBJDIR, s.replace(".hip", ".o")) for s in SOURCES]
+    objs += [os.path.join(OBJDIR, s.replace(".hip", ".f16.o")) for s in ELEM_SOURCES]
     sobjs = [os.path.join(OBJDIR, s.replace(".hip", ".strict.o" if s in WAIT_SOURCES else ".o")) for s in SOURCES]
+    sobjs += [os.path.join(OBJDIR, s.replace(".hip", ".f16.strict.o" if s in WAIT_SOURCES else ".f16.o")) for s in ELEM_SOURCES]
     for lib, ob in ((LIB, objs), (LIB_STRICT, sobjs)) if strict else ((LIB, objs),):
         if force or jobs or _stale(lib, ob):
             cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + ob

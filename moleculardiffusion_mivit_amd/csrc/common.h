@@ -346,6 +346,34 @@ size_t wgrad_small_ws_bytes(int M, int N, int K);
 int launch_wgrad_small(const void *dy, int64_t lddy, const void *x, int64_t ldx, int M, int N, int K, float *dW, float *db,
                        void *ws, size_t ws_bytes, hipStream_t s);
 
+// the same seven units compiled with -DMIVIT_ELEM_F16 (elem.h): IEEE-half operands and stored activations, same contracts
+bool attention_fast_supported_f16(int dtype, int S, int Dh);
+int launch_attention_fwd_fast_f16(const void *qkv, int B, int S, int H, int Dh, void *ctx, hipStream_t s);
+int launch_attention_bwd_fast_f16(const void *qkv, const void *dctx, int B, int S, int H, int Dh, void *dqkv, hipStream_t s);
+bool embed_dma_supported_f16(int dtype, int M, int K, int E);
+int launch_embed_fwd_dma_f16(const float *X, const void *W_bf16, const float *bias, void *Y, int M, int K, int E, hipStream_t s);
+size_t embed_wgrad_dma_ws_bytes_f16(int M, int K, int E);
+int launch_embed_wgrad_dma_f16(const void *dY_bf16, const float *X, float *dW, int M, int K, int E, void *ws, size_t ws_bytes,
+                           hipStream_t s);
+bool rowstream_supported_f16(int M, int N, int K, bool dgrad, int64_t lda, int64_t ldw, const void *A, const void *W);
+int launch_rowstream_f16(bool dgrad, const void *A, int64_t lda, const void *W_bf16, int64_t ldw, int M, int N, int K,
+                     const float *bias, int act, const void *dact, int64_t ldd, int dact_kind, const void *resid,
+                     int64_t ldr, void *Cout, int64_t ldc, void *C2, const float *gamma, const float *beta, void *Y,
+                     int64_t ldy, float *mean, float *rstd, hipStream_t s);
+bool wavestream_supported_f16(int M, int N, int K, bool dgrad, int64_t lda, int64_t ldw, const void *A, const void *W);
+int launch_wavestream_f16(bool dgrad, const void *A, int64_t lda, const void *W_bf16, int64_t ldw, int M, int N, int K,
+                      const float *bias, int act, const void *dact, int64_t ldd, int dact_kind, const void *resid,
+                      int64_t ldr, void *Cout, int64_t ldc, void *C2, const float *gamma, const float *beta, void *Y,
+                      int64_t ldy, float *mean, float *rstd, hipStream_t s);
+bool wgrad_dma_supported_f16(int M, int N, int K, int64_t lddy, int64_t ldx, const void *dy, const void *x);
+size_t wgrad_dma_ws_bytes_f16(int M, int N, int K);
+int launch_wgrad_dma_f16(const void *dy, int64_t lddy, const void *x, int64_t ldx, int M, int N, int K, float *dW, float *db,
+                     void *ws, size_t ws_bytes, hipStream_t s);
+bool wgrad_small_supported_f16(int M, int N, int K, int64_t lddy, int64_t ldx, const void *dy, const void *x);
+size_t wgrad_small_ws_bytes_f16(int M, int N, int K);
+int launch_wgrad_small_f16(const void *dy, int64_t lddy, const void *x, int64_t ldx, int M, int N, int K, float *dW, float *db,
+                       void *ws, size_t ws_bytes, hipStream_t s);
+
 // small elementwise / reduction helpers (misc.hip)
 // out[n] (+)= sum_p part[p*n_stride + n]   (deterministic slab reduce)
 int launch_slab_reduce(const float *part, int nparts, int64_t n, float *out, int accumulate, hipStream_t s);

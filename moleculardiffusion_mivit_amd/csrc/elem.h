@@ -1,0 +1,44 @@
+// Element type of the streaming kernels, chosen PER TRANSLATION UNIT.
+//
+// rowstream.hip, wavestream.hip, wgrad_dma.hip, wgrad_small.hip, attention_fast.hip and embed.hip are written against the
+// 16-bit storage type `bf16` (struct h16<0>), its vector form `bf16x8` and the compiler's `__bf16`.  csrc/build.py compiles
+// each of them twice: as is, and with -DMIVIT_ELEM_F16, where the three names below stand for IEEE half (`f16`, `f16x8`,
+// `_Float16`) and every external function of the unit carries the suffix _f16.  Everything type-specific in those files goes
+// through overloads that exist for both types (to_f32 / from_f32 / load16 / store16 in common.h, mma / tr_pair in
+// stream_prims.h) or through the two macros at the end; nothing in them manipulates bf16 bit patterns by hand.  The engine
+// picks the bf16 or the _f16 set by the plan's dtype (engine.hip::stream_ops): BASELINE config 5's "fp16 with loss scaling"
+// then runs on the same streaming kernels as bf16 instead of the general register-staged ones.
+// Include AFTER common.h and stream_prims.h.
+#pragma once
+#ifdef MIVIT_ELEM_F16
+#define MIVIT_ELEM_DTYPE MIVIT_F16
+#define bf16 f16
+#define bf16x8 f16x8
+#define __bf16 _Float16
+#define tr_pair tr_pair_f16
+// externals of the six units
+#define rowstream_supported rowstream_supported_f16
+#define launch_rowstream launch_rowstream_f16
+#define wavestream_supported wavestream_supported_f16
+#define launch_wavestream launch_wavestream_f16
+#define wgrad_dma_supported wgrad_dma_supported_f16
+#define wgrad_dma_ws_bytes wgrad_dma_ws_bytes_f16
+#define launch_wgrad_dma launch_wgrad_dma_f16
+#define wgrad_small_supported wgrad_small_supported_f16
+#define wgrad_small_ws_bytes wgrad_small_ws_bytes_f16
+#define launch_wgrad_small launch_wgrad_small_f16
+#define attention_fast_supported attention_fast_supported_f16
+#define launch_attention_fwd_fast launch_attention_fwd_fast_f16
+#define launch_attention_bwd_fast launch_attention_bwd_fast_f16
+#define embed_dma_supported embed_dma_supported_f16
+#define launch_embed_fwd_dma launch_embed_fwd_dma_f16
+#define embed_wgrad_dma_ws_bytes embed_wgrad_dma_ws_bytes_f16
+#define launch_embed_wgrad_dma launch_embed_wgrad_dma_f16
+// the 16-deep MFMA of attention_fast.hip's backward (operands travel as 4 x 16-bit lanes)
+#define ELEM_MFMA_16x16x16(a, b, c)                                                                                       \
+    __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(__attribute__((ext_vector_type(4))) _Float16, a),            \
+                                          __builtin_bit_cast(__attribute__((ext_vector_type(4))) _Float16, b), c, 0, 0, 0)
+#else
+#define MIVIT_ELEM_DTYPE MIVIT_BF16
+#define ELEM_MFMA_16x16x16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0)
+#endif

@@ -15,6 +15,7 @@
 #include "common.h"
 #include "stream_prims.h"
 #include <stdlib.h>
+#include "elem.h"          // element type of this translation unit (bf16, or f16 under -DMIVIT_ELEM_F16): after every other include
 
 namespace {
 
@@ -715,10 +716,12 @@ int fwd_dma_launch(const EmbFwdArgs &a, hipStream_t s) {
 // forward tiling, selectable for A/B runs and so that the tests reach every launcher branch at small sizes:
 // MIVIT_EMBED_FWD_VARIANT / mivit_embed_set_variant (0 = by problem size)
 static int g_embed_variant = getenv("MIVIT_EMBED_FWD_VARIANT") ? atoi(getenv("MIVIT_EMBED_FWD_VARIANT")) : 0;
+#ifndef MIVIT_ELEM_F16
 extern "C" int mivit_embed_set_variant(int v) { const int old = g_embed_variant; g_embed_variant = v; return old; }
+#endif
 
 bool embed_dma_supported(int dtype, int M, int K, int E) {
-    return dtype == MIVIT_BF16 && E % 128 == 0 && K % 128 == 0 && K >= 256 && M >= 128;
+    return dtype == MIVIT_ELEM_DTYPE && E % 128 == 0 && K % 128 == 0 && K >= 256 && M >= 128;
 }
 
 int launch_embed_fwd_dma(const float *X, const void *W_bf16, const float *bias, void *Y, int M, int K, int E,
@@ -793,6 +796,7 @@ int launch_embed_wgrad_dma(const void *dY_bf16, const float *X, float *dW, int M
     return launch_slab_reduce(static_cast<const float *>(ws), nz, (int64_t)E * K, dW, 0, s);
 }
 
+#ifndef MIVIT_ELEM_F16      // operator-level C-ABI: declared for bf16 (include/mivit_hip.h)
 extern "C" int mivit_embed_fwd_bf16(const float *x, const void *W_bf16, const float *bias, int M, int K, int E,
                                     void *y_bf16, void *stream) {
     MIVIT_CHECK(x && W_bf16 && y_bf16, "embed_fwd_bf16: null pointer");
@@ -810,3 +814,4 @@ extern "C" int mivit_embed_wgrad_bf16(const void *dy_bf16, const float *x, int M
     prof_set_tag(MIVIT_PROF_OP);
     return launch_embed_wgrad_dma(dy_bf16, x, dW, M, K, E, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
 }
+#endif

@@ -135,16 +135,17 @@ Ws make_ws(const mivit_plan *p, int B, int T, bool bwd) {
         size_t wg = 0;
         auto mx = [&](int m, int n, int k) {
             size_t b = linear_wgrad_ws_bytes(m, n, k);
-            if (c.dtype == MIVIT_BF16 && n % 128 == 0 && k % 128 == 0 && m >= 256) b += wgrad_dma_ws_bytes(m, n, k);
-            if (c.dtype == MIVIT_BF16 && m >= 256) b = std::max(b, wgrad_small_ws_bytes(m, n, k));
+            // (the bf16 and f16 builds of the weight-gradient kernels size their workspaces identically)
+            if (c.dtype != MIVIT_F32 && n % 128 == 0 && k % 128 == 0 && m >= 256) b += wgrad_dma_ws_bytes(m, n, k);
+            if (c.dtype != MIVIT_F32 && m >= 256) b = std::max(b, wgrad_small_ws_bytes(m, n, k));
             if (b > wg) wg = b;
         };
         mx((int)M, 3 * E, E); mx((int)M, E, E); mx((int)M, F, E); mx((int)M, E, F);
         if (fused) wg = std::max(std::max(wg, mlp_block_bwd_ws_bytes((int)M)), attn_out_bwd_ws_bytes((int)M));
         if (c.embedding != MIVIT_EMBED_EXTERNAL) {
             mx((int)Mt, E, c.patch_size * c.patch_size);
-            if (embed_dma_supported(c.dtype, (int)Mt, c.patch_size * c.patch_size, E)) {
-                const size_t b = embed_wgrad_dma_ws_bytes((int)Mt, c.patch_size * c.patch_size, E);
+            if ((c.dtype == MIVIT_F16 ? embed_dma_supported_f16 : embed_dma_supported)(c.dtype, (int)Mt, c.patch_size * c.patch_size, E)) {
+                const size_t b = embed_wgrad_dma_ws_bytes((int)Mt, c.patch_size * c.patch_size, E);      // (same for both element types)
                 if (b > wg) wg = b;
             }
         }
@@ -165,17 +166,46 @@ inline void *col_ptr(void *p, size_t cols, int dtype) { return static_cast<char 
 
 #define RC(call) do { int rc_ = (call); if (rc_) return rc_; } while (0)
 
+// The streaming kernels exist once per 16-bit element type (elem.h: each unit is compiled for bf16 and, with
+// -DMIVIT_ELEM_F16, for IEEE half): the plan's dtype picks the set.  fp32 (parity mode) has none: general kernels.
+struct StreamOps {
+    decltype(&rowstream_supported) rowstream_ok;
+    decltype(&wavestream_supported) wavestream_ok;
+    decltype(&launch_rowstream) rowstream;
+    decltype(&wgrad_dma_supported) wgrad_dma_ok;
+    decltype(&wgrad_dma_ws_bytes) wgrad_dma_ws;
+    decltype(&launch_wgrad_dma) wgrad_dma;
+    decltype(&wgrad_small_supported) wgrad_small_ok;
+    decltype(&wgrad_small_ws_bytes) wgrad_small_ws;
+    decltype(&launch_wgrad_small) wgrad_small;
+    decltype(&embed_dma_supported) embed_ok;
+    decltype(&launch_embed_fwd_dma) embed_fwd;
+    decltype(&embed_wgrad_dma_ws_bytes) embed_wgrad_ws;
+    decltype(&launch_embed_wgrad_dma) embed_wgrad;
+};
+static const StreamOps kStreamBf16 = {rowstream_supported, wavestream_supported, launch_rowstream, wgrad_dma_supported, wgrad_dma_ws_bytes,
+                                      launch_wgrad_dma, wgrad_small_supported, wgrad_small_ws_bytes, launch_wgrad_small,
+                                      embed_dma_supported, launch_embed_fwd_dma, embed_wgrad_dma_ws_bytes, launch_embed_wgrad_dma};
+static const StreamOps kStreamF16 = {rowstream_supported_f16, wavestream_supported_f16, launch_rowstream_f16, wgrad_dma_supported_f16,
+                                     wgrad_dma_ws_bytes_f16, launch_wgrad_dma_f16, wgrad_small_supported_f16, wgrad_small_ws_bytes_f16,
+                                     launch_wgrad_small_f16, embed_dma_supported_f16, launch_embed_fwd_dma_f16,
+                                     embed_wgrad_dma_ws_bytes_f16, launch_embed_wgrad_dma_f16};
+static const StreamOps *stream_ops(int dtype) {
+    static const bool f16_off = getenv("MIVIT_NO_F16_STREAM") != nullptr;        // (A/B: fp16 on the general kernels, as in rounds 1-2)
+    return dtype == MIVIT_BF16 ? &kStreamBf16 : (dtype == MIVIT_F16 && !f16_off ? &kStreamF16 : nullptr);
+}
 // row-stream (DMA ring) or wave-stream kernels: launch_rowstream picks between the two families
-static bool stream_gemm_supported(int M, int N, int K, bool dgrad, int64_t lda, int64_t ldw, const void *A, const void *W) {
-    return rowstream_supported(M, N, K, dgrad, lda, ldw, A, W) || wavestream_supported(M, N, K, dgrad, lda, ldw, A, W);
+static bool stream_gemm_supported(const StreamOps *so, int M, int N, int K, bool dgrad, int64_t lda, int64_t ldw, const void *A, const void *W) {
+    return so && (so->rowstream_ok(M, N, K, dgrad, lda, ldw, A, W) || so->wavestream_ok(M, N, K, dgrad, lda, ldw, A, W));
 }
 
 int lin_fwd(int dtype, const void *x, int x_f32, int64_t ldx, const void *W, const float *b, int M, int N, int K,
             int act, const void *resid, int64_t ldr, void *y, int64_t ldy, void *pre, int y_f32, hipStream_t s) {
-    if (dtype == MIVIT_BF16 && !x_f32 && !y_f32 && stream_gemm_supported(M, N, K, false, ldx, K, x, W) &&
+    const StreamOps *so = stream_ops(dtype);
+    if (!x_f32 && !y_f32 && stream_gemm_supported(so, M, N, K, false, ldx, K, x, W) &&
         (!resid || ldr % 8 == 0) && ldy % 8 == 0) {
         prof_set_tag(MIVIT_PROF_LINEAR_FWD);
-        return launch_rowstream(false, x, ldx, W, K, M, N, K, b, act, nullptr, 0, 0, resid, ldr, y, ldy, pre, nullptr,
+        return so->rowstream(false, x, ldx, W, K, M, N, K, b, act, nullptr, 0, 0, resid, ldr, y, ldy, pre, nullptr,
                                 nullptr, nullptr, 0, nullptr, nullptr, s);
     }
     if (dtype == MIVIT_BF16 && !x_f32 && !y_f32 && gemm_dma_supported(M, N, K, false) && ldx % 8 == 0 && ldy % 8 == 0 &&
@@ -194,10 +224,11 @@ int lin_fwd(int dtype, const void *x, int x_f32, int64_t ldx, const void *W, con
 }
 int lin_dgrad(int dtype, const void *dy, int64_t lddy, const void *W, int M, int N, int K, int act, const void *saved,
               int64_t lds, const void *dres, int64_t lddr, void *dx, int64_t lddx, int dx_f32, hipStream_t s) {
-    if (dtype == MIVIT_BF16 && !dx_f32 && stream_gemm_supported(M, K, N, true, lddy, K, dy, W) && lddx % 8 == 0 &&
+    const StreamOps *so = stream_ops(dtype);
+    if (!dx_f32 && stream_gemm_supported(so, M, K, N, true, lddy, K, dy, W) && lddx % 8 == 0 &&
         (!dres || lddr % 8 == 0) && (act == MIVIT_ACT_NONE || lds % 8 == 0)) {
         prof_set_tag(MIVIT_PROF_LINEAR_DGRAD);
-        return launch_rowstream(true, dy, lddy, W, K, M, K, N, nullptr, MIVIT_ACT_NONE, act != MIVIT_ACT_NONE ? saved : nullptr,
+        return so->rowstream(true, dy, lddy, W, K, M, K, N, nullptr, MIVIT_ACT_NONE, act != MIVIT_ACT_NONE ? saved : nullptr,
                                 lds, act, dres, lddr, dx, lddx, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, s);
     }
     if (dtype == MIVIT_BF16 && !dx_f32 && gemm_dma_supported(M, K, N, true) && lddy % 8 == 0 && lddx % 8 == 0 &&
@@ -216,15 +247,16 @@ int lin_dgrad(int dtype, const void *dy, int64_t lddy, const void *W, int M, int
 }
 int lin_wgrad(int dtype, const void *dy, int64_t lddy, const void *x, int x_f32, int64_t ldx, int M, int N, int K,
               float *dW, float *db, void *ws, size_t wsb, hipStream_t s) {
-    if (dtype == MIVIT_BF16 && !x_f32 && dW && wgrad_dma_supported(M, N, K, lddy, ldx, dy, x) &&
-        wsb >= wgrad_dma_ws_bytes(M, N, K) + linear_wgrad_ws_bytes(M, N, K)) {
+    const StreamOps *so = stream_ops(dtype);
+    if (so && !x_f32 && dW && so->wgrad_dma_ok(M, N, K, lddy, ldx, dy, x) &&
+        wsb >= so->wgrad_dma_ws(M, N, K) + linear_wgrad_ws_bytes(M, N, K)) {
         prof_set_tag(MIVIT_PROF_LINEAR_WGRAD);
-        return launch_wgrad_dma(dy, lddy, x, ldx, M, N, K, dW, db, ws, wsb, s);      // db (optional) from the same pass
+        return so->wgrad_dma(dy, lddy, x, ldx, M, N, K, dW, db, ws, wsb, s);      // db (optional) from the same pass
     }
-    if (dtype == MIVIT_BF16 && !x_f32 && dW && wgrad_small_supported(M, N, K, lddy, ldx, dy, x) &&
-        wsb >= wgrad_small_ws_bytes(M, N, K) && wsb >= linear_wgrad_ws_bytes(M, N, K)) {
+    if (so && !x_f32 && dW && so->wgrad_small_ok(M, N, K, lddy, ldx, dy, x) &&
+        wsb >= so->wgrad_small_ws(M, N, K) && wsb >= linear_wgrad_ws_bytes(M, N, K)) {
         prof_set_tag(MIVIT_PROF_LINEAR_WGRAD);
-        return launch_wgrad_small(dy, lddy, x, ldx, M, N, K, dW, db, ws, wsb, s);      // db (optional) from the same pass
+        return so->wgrad_small(dy, lddy, x, ldx, M, N, K, dW, db, ws, wsb, s);      // db (optional) from the same pass
     }
     LinearWgradArgs a = {};
     a.dtype = dtype; a.dy = dy; a.dy_is_f32 = dtype == MIVIT_F32; a.lddy = lddy; a.x = x;
@@ -238,9 +270,10 @@ int lin_wgrad(int dtype, const void *dy, int64_t lddy, const void *x, int x_f32,
 // block owns whole rows, otherwise GEMM + LayerNorm kernel.
 int lin_res_ln(int dtype, const void *x, int64_t ldx, const void *W, const float *b, int M, int N, int K, const void *resid,
                void *z, const float *gamma, const float *beta, void *y, float *mean, float *rstd, hipStream_t s) {
-    if (dtype == MIVIT_BF16 && (N == 128 || N == 64) && stream_gemm_supported(M, N, K, false, ldx, K, x, W)) {
+    const StreamOps *so = stream_ops(dtype);
+    if ((N == 128 || N == 64) && stream_gemm_supported(so, M, N, K, false, ldx, K, x, W)) {
         prof_set_tag(MIVIT_PROF_LINEAR_FWD);
-        return launch_rowstream(false, x, ldx, W, K, M, N, K, b, MIVIT_ACT_NONE, nullptr, 0, 0, resid, N, z, N, nullptr, gamma,
+        return so->rowstream(false, x, ldx, W, K, M, N, K, b, MIVIT_ACT_NONE, nullptr, 0, 0, resid, N, z, N, nullptr, gamma,
                                 beta, y, N, mean, rstd, s);
     }
     RC(lin_fwd(dtype, x, 0, ldx, W, b, M, N, K, MIVIT_ACT_NONE, resid, N, z, N, nullptr, 0, s));
@@ -423,9 +456,10 @@ static int forward_impl(const mivit_plan *plan, const float *params, const float
         RC(launch_convert(1, x, E, dt == MIVIT_F32, at(ws, w.emb), E, Mt, E, 0, s, dt));
     } else {
         const int K = c.patch_size * c.patch_size;
-        if (embed_dma_supported(dt, Mt, K, E)) {
+        const StreamOps *so = stream_ops(dt);
+        if (so && so->embed_ok(dt, Mt, K, E)) {
             prof_set_tag(MIVIT_PROF_EMBED_FWD);
-            RC(launch_embed_fwd_dma(x, WT(plan->emb_w), P + plan->emb_b, at(ws, w.emb), Mt, K, E, s));
+            RC(so->embed_fwd(x, WT(plan->emb_w), P + plan->emb_b, at(ws, w.emb), Mt, K, E, s));
         } else {
             RC(lin_fwd(dt, x, 1, K, WT(plan->emb_w), P + plan->emb_b, Mt, E, K, MIVIT_ACT_NONE, nullptr, 0, at(ws, w.emb), E,
                        nullptr, 0, s));
@@ -696,9 +730,10 @@ static int backward_impl(const mivit_plan *plan, const float *params, const floa
                 bool cs = false;
                 RC(ln_bwd_bias(a, G + plan->emb_b, &cs, s));                                      // dxb = d(embedding out)
                 const int K = c.patch_size * c.patch_size;
-                if (embed_dma_supported(dt, Mt, K, E)) {
+                const StreamOps *so = stream_ops(dt);
+                if (so && so->embed_ok(dt, Mt, K, E)) {
                     prof_set_tag(MIVIT_PROF_EMBED_WGRAD);
-                    RC(launch_embed_wgrad_dma(at(ws, w.dxb), x, G + plan->emb_w, Mt, K, E, wg, wgb, s));
+                    RC(so->embed_wgrad(at(ws, w.dxb), x, G + plan->emb_w, Mt, K, E, wg, wgb, s));
                     if (cs) RC(lin_wgrad(dt, at(ws, w.dxb), E, x, 1, K, Mt, E, K, nullptr, G + plan->emb_b, wg, wgb, s));
                 } else {
                     RC(lin_wgrad(dt, at(ws, w.dxb), E, x, 1, K, Mt, E, K, G + plan->emb_w, cs ? G + plan->emb_b : nullptr, wg, wgb, s));

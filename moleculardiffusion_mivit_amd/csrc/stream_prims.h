@@ -58,6 +58,9 @@ __device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmc
 __device__ __forceinline__ f32x4 mma(bf16x8 a, bf16x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
+__device__ __forceinline__ f32x4 mma(f16x8 a, f16x8 b, f32x4 c) {          // (the -DMIVIT_ELEM_F16 builds of the streaming kernels: elem.h)
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
 // MFMA operand whose k index runs over ROWS of a natural [row][col] bf16 LDS image: each lane passes the address of
 // (row base + q, column base + 4p) for the low and the high half of its 8 k slots (q = (lane & 15) >> 2, p = lane & 3)
 // and receives column base + (lane & 15) of those rows (ds_read_b64_tr_b16)
@@ -67,4 +70,11 @@ __device__ __forceinline__ bf16x8 tr_pair(const bf16 *lo, const bf16 *hi) {
     const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4 *)(hi));
     struct { s16x4 a, b; } pr = {a, b};
     return __builtin_bit_cast(bf16x8, pr);
+}
+__device__ __forceinline__ f16x8 tr_pair_f16(const f16 *lo, const f16 *hi) {
+    typedef __attribute__((address_space(3))) s16x4 lds_v4;
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4 *)(lo));
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4 *)(hi));
+    struct { s16x4 a, b; } pr = {a, b};
+    return __builtin_bit_cast(f16x8, pr);
 }

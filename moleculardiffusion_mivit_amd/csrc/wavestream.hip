@@ -13,6 +13,7 @@
 #include "common.h"
 #include "stream_prims.h"
 #include <stdlib.h>
+#include "elem.h"          // element type of this translation unit (bf16, or f16 under -DMIVIT_ELEM_F16): after every other include
 
 namespace {
 
@@ -252,6 +253,7 @@ int launch_wavestream(bool dgrad, const void *A, int64_t lda, const void *W_bf16
     return ws_dispatch<128, 64>(a, dgrad, ln, s);
 }
 
+#ifndef MIVIT_ELEM_F16      // operator-level C-ABI: declared for bf16 (include/mivit_hip.h)
 extern "C" int mivit_wavestream_fwd(const void *x, int64_t ldx, const void *W_bf16, const float *bias, int M, int N, int K,
                                     int act, const void *resid, int64_t ldr, void *y, int64_t ldy, void *y_preact,
                                     const float *ln_gamma, const float *ln_beta, void *ln_out, float *mean, float *rstd,
@@ -272,3 +274,4 @@ extern "C" int mivit_wavestream_dgrad(const void *dy, int64_t lddy, const void *
                              lds, act, dres, lddr, dx, lddx, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr,
                              static_cast<hipStream_t>(stream));
 }
+#endif

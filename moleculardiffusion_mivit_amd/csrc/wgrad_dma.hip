@@ -5,6 +5,7 @@
 #include "common.h"
 #include "stream_prims.h"
 #include <stdlib.h>
+#include "elem.h"          // element type of this translation unit (bf16, or f16 under -DMIVIT_ELEM_F16): after every other include
 
 namespace {
 
@@ -218,6 +219,7 @@ int launch_wgrad_dma(const void *dy, int64_t lddy, const void *x, int64_t ldx, i
     return launch_slab_reduce(bias_part, nz, N, db, 0, s);
 }
 
+#ifndef MIVIT_ELEM_F16      // operator-level C-ABI: declared for bf16 (include/mivit_hip.h)
 extern "C" size_t mivit_wgrad_bf16_workspace_bytes(int M, int N, int K) {
     return (N % TILE == 0 && K % TILE == 0) ? wgrad_dma_ws_bytes(M, N, K) : 0;
 }
@@ -228,3 +230,4 @@ extern "C" int mivit_wgrad_bf16(const void *dy, int64_t lddy, const void *x, int
     prof_set_tag(MIVIT_PROF_OP);
     return launch_wgrad_dma(dy, lddy, x, ldx, M, N, K, dW, db, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
 }
+#endif

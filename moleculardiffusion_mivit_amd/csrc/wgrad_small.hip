@@ -8,6 +8,7 @@
 #include "stream_prims.h"
 #include <stdlib.h>
 #include <algorithm>
+#include "elem.h"          // element type of this translation unit (bf16, or f16 under -DMIVIT_ELEM_F16): after every other include
 
 namespace {
 
@@ -191,6 +192,7 @@ int launch_wgrad_small(const void *dy, int64_t lddy, const void *x, int64_t ldx,
     return db ? launch_slab_reduce(bias_slabs, parts, N, db, 0, s) : 0;
 }
 
+#ifndef MIVIT_ELEM_F16      // operator-level C-ABI: declared for bf16 (include/mivit_hip.h)
 extern "C" size_t mivit_wgrad_small_workspace_bytes(int M, int N, int K) {
     return window_of(N, K) ? wgrad_small_ws_bytes(M, N, K) : 0;
 }
@@ -201,3 +203,4 @@ extern "C" int mivit_wgrad_small(const void *dy, int64_t lddy, const void *x, in
     prof_set_tag(MIVIT_PROF_OP);
     return launch_wgrad_small(dy, lddy, x, ldx, M, N, K, dW, db, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
 }
+#endif

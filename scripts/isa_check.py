@@ -27,13 +27,13 @@ CSRC = os.path.join(ROOT, "moleculardiffusion_mivit_amd", "csrc")
 sys.path.insert(0, ROOT)
 
 
-def device_asm(src):
+def device_asm(src, extra=()):
     from moleculardiffusion_mivit_amd.csrc import build as b
-    out = os.path.join(tempfile.gettempdir(), "mivit_isa_" + os.path.basename(src).replace(".hip", ".s"))
+    out = os.path.join(tempfile.gettempdir(), "mivit_isa_" + os.path.basename(src).replace(".hip", "".join(extra).replace("-D", "_") + ".s"))
     srcp = os.path.join(CSRC, src)
-    deps = [srcp, os.path.join(CSRC, "common.h"), os.path.join(CSRC, "stream_prims.h"), b.__file__]
+    deps = [srcp, os.path.join(CSRC, "common.h"), os.path.join(CSRC, "stream_prims.h"), os.path.join(CSRC, "elem.h"), b.__file__]
     if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
-        cmd = [b._hipcc()] + b.FLAGS + ["--cuda-device-only", "-S", srcp, "-o", out]
+        cmd = [b._hipcc()] + b.FLAGS + list(extra) + ["--cuda-device-only", "-S", srcp, "-o", out]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc -S failed for {src}:\n{r.stderr[-2000:]}")
@@ -201,17 +201,18 @@ def count_in_loop(lines, pat):
 
 def main():
     errs = []
-    # ---- embed.hip ----
-    ke = kernels(device_asm("embed.hip"))
-    d2 = [n for n in ke if "embed_fwd_direct2" in n]
-    if not d2:
-        errs.append("embed.hip: embed_fwd_direct2 not found")
-    for n in d2:
-        sb = scratch_bytes(ke[n][1])
-        if sb is None or sb != 0:
-            errs.append(f"{n}: scratch bytes = {sb} (must be 0: a spill of a load destination is invisible to the hand-placed waits)")
-        errs += check_inflight(n, ke[n][0])
-    errs += check_m0_nop("embed.hip", ke)
+    # ---- embed.hip, both element types (elem.h) ----
+    for extra in ((), ("-DMIVIT_ELEM_F16",)):
+        ke = kernels(device_asm("embed.hip", extra))
+        d2 = [n for n in ke if "embed_fwd_direct2" in n]
+        if not d2:
+            errs.append(f"embed.hip {extra}: embed_fwd_direct2 not found")
+        for n in d2:
+            sb = scratch_bytes(ke[n][1])
+            if sb is None or sb != 0:
+                errs.append(f"{n} {extra}: scratch bytes = {sb} (must be 0: a spill of a load destination is invisible to the hand-placed waits)")
+            errs += check_inflight(n, ke[n][0])
+        errs += check_m0_nop("embed.hip", ke)
     # ---- the other users of the written-out DMA ----
     for src in ("rowstream.hip", "gemm_dma.hip", "wgrad_dma.hip", "fused_bwd.hip"):
         kd = kernels(device_asm(src))
