@@ -314,8 +314,10 @@ int launch_rowstream(bool dgrad, const void *A, int64_t lda, const void *W_bf16,
     // K = 256 dgrad 71 -> 68 us; the plain forward slices and FC2 + LayerNorm stay on the DMA ring: 61 vs 70, 88 vs 94 us)
     static const int use_ws = getenv("MIVIT_WAVESTREAM") ? atoi(getenv("MIVIT_WAVESTREAM")) : 2;
     const bool rs_shape = (K == 128 || K == 256 || (K == 384 && dgrad)) && N % 128 == 0;     // what the DMA-ring kernels cover
-    const bool ws_pick = !rs_shape || use_ws == 1 || (use_ws == 2 && ((K == 128 && !dgrad && gamma) || (K == 128 && dgrad && dact) ||
-                                                                      (K == 256 && dgrad)));
+    static const int ws_mask = getenv("MIVIT_WAVESTREAM_MASK") ? atoi(getenv("MIVIT_WAVESTREAM_MASK")) : 7;      // (A/B: which of the three picks)
+    const bool ws_pick = !rs_shape || use_ws == 1 || (use_ws == 2 && (((ws_mask & 1) && K == 128 && !dgrad && gamma) ||
+                                                                      ((ws_mask & 2) && K == 128 && dgrad && dact) ||
+                                                                      ((ws_mask & 4) && K == 256 && dgrad)));
     if (ws_pick && wavestream_supported(M, N, K, dgrad, lda, ldw, A, W_bf16))
         return launch_wavestream(dgrad, A, lda, W_bf16, ldw, M, N, K, bias, act, dact, ldd, dact_kind, resid, ldr, Cout, ldc, C2,
                                  gamma, beta, Y, ldy, mean, rstd, s);
