@@ -15,7 +15,8 @@ HEADERS = [os.path.join(HERE, "common.h"), os.path.join(HERE, "stream_prims.h"),
            os.path.join(ROOT, "include", "mivit_hip.h")]
 # the streaming kernels whose element type is chosen per translation unit (elem.h): each is compiled a second time with
 # -DMIVIT_ELEM_F16 (IEEE half instead of bf16, every external suffixed _f16) and both objects go into the library
-ELEM_SOURCES = ["rowstream.hip", "wavestream.hip", "wgrad_dma.hip", "wgrad_small.hip", "attention_fast.hip", "embed.hip"]
+ELEM_SOURCES = ["rowstream.hip", "wavestream.hip", "wgrad_dma.hip", "wgrad_small.hip", "attention_fast.hip", "embed.hip",
+                "fused_fwd.hip", "fused_bwd.hip"]
 LIB = os.path.join(PKG, "libmivit_hip.so")
 # the same library with every counted s_waitcnt vmcnt(N) of stream_prims.h::wait_vm turned into vmcnt(0) (-DMIVIT_STRICT_WAITS).
 # TEST INFRASTRUCTURE ONLY: tests/test_strict_waits_gpu.py runs the bench-scale shapes through both and requires bitwise-equal

@@ -1,11 +1,12 @@
 // Element type of the streaming kernels, chosen PER TRANSLATION UNIT.
 //
-// rowstream.hip, wavestream.hip, wgrad_dma.hip, wgrad_small.hip, attention_fast.hip and embed.hip are written against the
+// rowstream.hip, wavestream.hip, wgrad_dma.hip, wgrad_small.hip, attention_fast.hip, embed.hip and the fused encoder-layer
+// blocks fused_fwd.hip / fused_bwd.hip are written against the
 // 16-bit storage type `bf16` (struct h16<0>), its vector form `bf16x8` and the compiler's `__bf16`.  csrc/build.py compiles
 // each of them twice: as is, and with -DMIVIT_ELEM_F16, where the three names below stand for IEEE half (`f16`, `f16x8`,
 // `_Float16`) and every external function of the unit carries the suffix _f16.  Everything type-specific in those files goes
 // through overloads that exist for both types (to_f32 / from_f32 / load16 / store16 in common.h, mma / tr_pair in
-// stream_prims.h) or through the two macros at the end; nothing in them manipulates bf16 bit patterns by hand.  The engine
+// stream_prims.h) or through the macro and the two unpack helpers at the end; nothing else in them manipulates 16-bit patterns by hand.  The engine
 // picks the bf16 or the _f16 set by the plan's dtype (engine.hip::stream_ops): BASELINE config 5's "fp16 with loss scaling"
 // then runs on the same streaming kernels as bf16 instead of the general register-staged ones.
 // Include AFTER common.h and stream_prims.h.
@@ -34,11 +35,23 @@
 #define launch_embed_fwd_dma launch_embed_fwd_dma_f16
 #define embed_wgrad_dma_ws_bytes embed_wgrad_dma_ws_bytes_f16
 #define launch_embed_wgrad_dma launch_embed_wgrad_dma_f16
+#define fused_layer_supported fused_layer_supported_f16
+#define launch_attn_block_fwd launch_attn_block_fwd_f16
+#define launch_mlp_block_fwd launch_mlp_block_fwd_f16
+#define mlp_block_bwd_ws_bytes mlp_block_bwd_ws_bytes_f16
+#define launch_mlp_block_bwd launch_mlp_block_bwd_f16
+#define attn_out_bwd_ws_bytes attn_out_bwd_ws_bytes_f16
+#define launch_attn_out_bwd launch_attn_out_bwd_f16
 // the 16-deep MFMA of attention_fast.hip's backward (operands travel as 4 x 16-bit lanes)
 #define ELEM_MFMA_16x16x16(a, b, c)                                                                                       \
     __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(__attribute__((ext_vector_type(4))) _Float16, a),            \
                                           __builtin_bit_cast(__attribute__((ext_vector_type(4))) _Float16, b), c, 0, 0, 0)
+// the two 16-bit elements packed in one 32-bit word, widened to fp32 (the fused blocks unpack 8- and 16-byte loads by hand)
+__device__ __forceinline__ float elem_lo(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(w & 0xffffu)); }
+__device__ __forceinline__ float elem_hi(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(w >> 16)); }
 #else
 #define MIVIT_ELEM_DTYPE MIVIT_BF16
 #define ELEM_MFMA_16x16x16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0)
+__device__ __forceinline__ float elem_lo(uint32_t w) { return __uint_as_float(w << 16); }            // bf16 = the high half of an fp32
+__device__ __forceinline__ float elem_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 #endif

@@ -29,6 +29,44 @@ int launch_mlp_block_bwd(const void *dy, const void *n2, const float *rstd2, con
                          void *dx1, float *dW1, float *db1, float *dW2, float *db2, float *dgamma2, float *dbeta2, void *ws,
                          size_t ws_bytes, hipStream_t s);
 
+// ... and the same two units compiled with -DMIVIT_ELEM_F16 (elem.h)
+bool fused_layer_supported_f16(int dtype, int E, int F, int H, int S);
+int launch_attn_block_fwd_f16(const void *nin, const float *gin, const float *bin, const void *Wqkv, const float *bqkv,
+                          const void *Wo, const float *bo, const float *gout, const float *bout, int B, int S, void *ctx,
+                          void *nout, float *rstd, void *xout, void *zout, float *mean, void *qkvout, hipStream_t s);
+int launch_mlp_block_fwd_f16(const void *nin, const float *gin, const float *bin, const void *W1, const float *b1, const void *W2,
+                         const float *b2, const float *gout, const float *bout, int M, int act, void *nout, float *rstd,
+                         void *xout, void *zout, float *mean, void *hout, void *uout, hipStream_t s);
+
+size_t mlp_block_bwd_ws_bytes_f16(int M);
+size_t attn_out_bwd_ws_bytes_f16(int M);
+int launch_attn_out_bwd_f16(const void *dy, const void *n1, const float *rstd1, const float *gamma1, const void *ctx, const void *Wo, int M,
+                        void *dz1, void *dctx, float *dWo, float *dbo, float *dgamma1, float *dbeta1, void *ws, size_t ws_bytes,
+                        hipStream_t s);
+int launch_mlp_block_bwd_f16(const void *dy, const void *n2, const float *rstd2, const float *gamma2, const void *n1,
+                         const float *gamma1, const float *beta1, const void *W1, const float *b1, const void *W2, int M, int act,
+                         void *dx1, float *dW1, float *db1, float *dW2, float *db2, float *dgamma2, float *dbeta2, void *ws,
+                         size_t ws_bytes, hipStream_t s);
+
+struct FusedOps {
+    decltype(&fused_layer_supported) ok;
+    decltype(&launch_attn_block_fwd) attn_fwd;
+    decltype(&launch_mlp_block_fwd) mlp_fwd;
+    decltype(&launch_mlp_block_bwd) mlp_bwd;
+    decltype(&launch_attn_out_bwd) attn_out_bwd;
+};
+static const FusedOps kFusedBf16 = {fused_layer_supported, launch_attn_block_fwd, launch_mlp_block_fwd, launch_mlp_block_bwd, launch_attn_out_bwd};
+static const FusedOps kFusedF16 = {fused_layer_supported_f16, launch_attn_block_fwd_f16, launch_mlp_block_fwd_f16, launch_mlp_block_bwd_f16,
+                                   launch_attn_out_bwd_f16};
+static const FusedOps *fused_ops(int dtype) {
+    static const bool f16_off = getenv("MIVIT_NO_F16_STREAM") != nullptr;
+    return dtype == MIVIT_BF16 ? &kFusedBf16 : (dtype == MIVIT_F16 && !f16_off ? &kFusedF16 : nullptr);
+}
+static bool fused_ok(int dtype, int E, int F, int H, int S) {
+    const FusedOps *f = fused_ops(dtype);
+    return f && f->ok(dtype, E, F, H, S);
+}
+
 struct ParamInfo {
     std::string name;
     int64_t offset, numel;
@@ -98,7 +136,7 @@ Ws make_ws(const mivit_plan *p, int B, int T, bool bwd) {
     w.emb = take(Mt * E * ts); w.mean0 = take(Mt * 4); w.rstd0 = take(Mt * 4);
     w.x0 = take(M * E * ts);
     const int nsets = bwd ? L : 1;
-    const bool fused = L > 0 && fused_layer_supported(c.dtype, E, F, c.num_heads, S);
+    const bool fused = L > 0 && fused_ok(c.dtype, E, F, c.num_heads, S);
     for (int l = 0; l < nsets; ++l) {
         Ws::L s;
         if (fused) {
@@ -489,7 +527,7 @@ static int forward_impl(const mivit_plan *plan, const float *params, const float
                                  c.use_pos_encoding ? P + plan->pos : nullptr, s));
     // 4. encoder layers (post-norm, models.py:97-108)
     const void *xin = at(ws, w.x0);
-    const bool fused = c.num_layers > 0 && fused_layer_supported(dt, E, F, H, S);
+    const bool fused = c.num_layers > 0 && fused_ok(dt, E, F, H, S);
     if (fused) {
         // fused layer blocks (fused_fwd.hip): the layers hand each other NORMALISED tokens, the consumer applies the producing
         // LayerNorm's affine (folded into its weights); training keeps q|k|v and h for the backward kernels, inference
@@ -501,11 +539,11 @@ static int forward_impl(const mivit_plan *plan, const float *params, const float
             const Ws::L &b = w.layer[l];
             const bool last = l + 1 == c.num_layers;
             prof_set_tag(MIVIT_PROF_ATTN_BLOCK_FWD);
-            RC(launch_attn_block_fwd(nin, gin, bin, WT(lp.qkv_w), P + lp.qkv_b, WT(lp.out_w), P + lp.out_b, P + lp.n1_w,
+            RC(fused_ops(dt)->attn_fwd(nin, gin, bin, WT(lp.qkv_w), P + lp.qkv_b, WT(lp.out_w), P + lp.out_b, P + lp.n1_w,
                                      P + lp.n1_b, B, S, at(ws, b.ctx), at(ws, b.z1), static_cast<float *>(at(ws, b.rstd1)),
                                      nullptr, nullptr, nullptr, need_backward ? at(ws, b.qkv) : nullptr, s));
             prof_set_tag(MIVIT_PROF_MLP_BLOCK_FWD);
-            RC(launch_mlp_block_fwd(at(ws, b.z1), P + lp.n1_w, P + lp.n1_b, WT(lp.fc1_w), P + lp.fc1_b, WT(lp.fc2_w), P + lp.fc2_b,
+            RC(fused_ops(dt)->mlp_fwd(at(ws, b.z1), P + lp.n1_w, P + lp.n1_b, WT(lp.fc1_w), P + lp.fc1_b, WT(lp.fc2_w), P + lp.fc2_b,
                                     P + lp.n2_w, P + lp.n2_b, M, c.activation, at(ws, b.z2), static_cast<float *>(at(ws, b.rstd2)),
                                     last ? at(ws, w.xL) : nullptr, nullptr, nullptr, nullptr, nullptr, s));      // (h is recomputed by the fused backward)
             nin = at(ws, b.z2); gin = P + lp.n2_w; bin = P + lp.n2_b;
@@ -613,7 +651,7 @@ static int backward_impl(const mivit_plan *plan, const float *params, const floa
         if (st == 0) {
             // ---- head + final norm ----
             const int Hh = c.head_hidden, Hin = plan->head_in, O = c.output_dim;
-            const bool fusedL = L > 0 && fused_layer_supported(dt, E, F, H, S);
+            const bool fusedL = L > 0 && fused_ok(dt, E, F, H, S);
             const void *xL = L > 0 ? (fusedL ? at(ws, w.xL) : at(ws, w.layer[L - 1].x2)) : at(ws, w.x0);
             const void *head_in = c.fusion == MIVIT_FUSION_LATE ? at(ws, w.head_in) : at(ws, w.pooled);
             const void *dy = dout;
@@ -653,7 +691,7 @@ static int backward_impl(const mivit_plan *plan, const float *params, const floa
             const Ws::L &b = w.layer[l];
             // fused layer blocks: z1 / z2 hold xhat (no means), the Linear inputs x1 / x_in exist only as xhat of the
             // producing norm: their weight gradients are taken against xhat and corrected by launch_affine_fixup
-            const bool fz = fused_layer_supported(dt, E, F, H, S);
+            const bool fz = fused_ok(dt, E, F, H, S);
             const void *xin = l > 0 ? (fz ? at(ws, w.layer[l - 1].z2) : at(ws, w.layer[l - 1].x2)) : at(ws, w.x0);
             LayerNormBwdArgs n2 = {};
             n2.dtype = dt; n2.dy = at(ws, w.dxa); n2.lddy = E; n2.z = at(ws, b.z2); n2.ldz = E; n2.gamma = P + lp.n2_w;
@@ -666,7 +704,7 @@ static int backward_impl(const mivit_plan *plan, const float *params, const floa
                 // feed-forward block in one launch (fused_bwd.hip): d(x2) -> d(x1), all six parameter gradients
                 dx1 = at(ws, w.dxb); dz1 = at(ws, w.dF);
                 prof_set_tag(MIVIT_PROF_MLP_BLOCK_BWD);
-                RC(launch_mlp_block_bwd(at(ws, w.dxa), at(ws, b.z2), static_cast<const float *>(at(ws, b.rstd2)), P + lp.n2_w,
+                RC(fused_ops(dt)->mlp_bwd(at(ws, w.dxa), at(ws, b.z2), static_cast<const float *>(at(ws, b.rstd2)), P + lp.n2_w,
                                         at(ws, b.z1), P + lp.n1_w, P + lp.n1_b, WT(lp.fc1_w), P + lp.fc1_b, WT(lp.fc2_w), M,
                                         c.activation, dx1, G + lp.fc1_w, G + lp.fc1_b, G + lp.fc2_w, G + lp.fc2_b, G + lp.n2_w,
                                         G + lp.n2_b, wg, wgb, s));
@@ -682,7 +720,7 @@ static int backward_impl(const mivit_plan *plan, const float *params, const floa
             if (fz) {
                 // LayerNorm-1 backward + out-projection weight / data gradient in one launch (fused_bwd.hip)
                 prof_set_tag(MIVIT_PROF_ATTN_OUT_BWD);
-                RC(launch_attn_out_bwd(dx1, at(ws, b.z1), static_cast<const float *>(at(ws, b.rstd1)), P + lp.n1_w, at(ws, b.ctx),
+                RC(fused_ops(dt)->attn_out_bwd(dx1, at(ws, b.z1), static_cast<const float *>(at(ws, b.rstd1)), P + lp.n1_w, at(ws, b.ctx),
                                        WT(lp.out_w), M, dz1, at(ws, w.dctx), G + lp.out_w, G + lp.out_b, G + lp.n1_w, G + lp.n1_b,
                                        wg, wgb, s));
             } else {

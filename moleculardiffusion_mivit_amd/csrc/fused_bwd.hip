@@ -23,6 +23,8 @@
 #include <algorithm>
 #include <vector>
 #include <stdio.h>
+#include <type_traits>
+#include "elem.h"          // element type of this translation unit (bf16, or f16 under -DMIVIT_ELEM_F16): after every other include
 
 #define RC(call) do { int rc_ = (call); if (rc_) return rc_; } while (0)
 
@@ -76,7 +78,7 @@ __device__ __forceinline__ bf16x8 lds_frag(const bf16 *p) { return *reinterpret_
 __device__ __forceinline__ void unpack8(const uint4 &u, float (&v)[8]) {
     const uint32_t w[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+    for (int i = 0; i < 4; ++i) { v[2 * i] = elem_lo(w[i]); v[2 * i + 1] = elem_hi(w[i]); }
 }
 
 // dh image [hidden unit][tile row], unpadded 64-byte rows; the two 32-byte halves (tile rows 0-15 | 16-31) of hidden units 4..7
@@ -356,8 +358,8 @@ __global__ __launch_bounds__(NT) void mlp_block_bwd_kernel(const MlpBwdArgs a) {
                 const int col = 32 * wave + 16 * kt + 4 * g;
                 const uint2 zr = *reinterpret_cast<const uint2 *>(DZ + (16 * rt + cq) * LDE + col);
                 f32x4 o = dx[kt][rt];
-                o[0] += __uint_as_float(zr.x << 16); o[1] += __uint_as_float(zr.x & 0xffff0000u);
-                o[2] += __uint_as_float(zr.y << 16); o[3] += __uint_as_float(zr.y & 0xffff0000u);
+                o[0] += elem_lo(zr.x); o[1] += elem_hi(zr.x);
+                o[2] += elem_lo(zr.y); o[3] += elem_hi(zr.y);
                 if (row < a.M) {
                     typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
                     const bf16x4 ob = {(__bf16)o[0], (__bf16)o[1], (__bf16)o[2], (__bf16)o[3]};
@@ -626,6 +628,7 @@ int launch_mlp_block_bwd(const void *dy, const void *n2, const float *rstd2, con
     return 0;
 }
 
+#ifndef MIVIT_ELEM_F16      // operator-level C-ABI: declared for bf16 (include/mivit_hip.h)
 extern "C" size_t mivit_mlp_block_bwd_workspace_bytes(int M) { return mlp_block_bwd_ws_bytes(M); }
 extern "C" int mivit_mlp_block_bwd(const void *dy, const void *n2, const float *rstd2, const float *gamma2, const void *n1,
                                    const float *gamma1, const float *beta1, const void *W1_bf16, const float *b1,
@@ -637,6 +640,7 @@ extern "C" int mivit_mlp_block_bwd(const void *dy, const void *n2, const float *
                                 dbeta2, workspace, workspace_bytes, s);
 }
 
+#endif
 size_t attn_out_bwd_ws_bytes(int M) { return align_up((size_t)std::min(512, ceil_div(std::max(M, 1), R)) * AO_SL_TOTAL * sizeof(float), 256); }
 
 // dz1, dctx [M,E] bf16; dWo [E,E], dbo, dgamma1, dbeta1 [E] fp32 (overwritten)
@@ -665,6 +669,7 @@ int launch_attn_out_bwd(const void *dy, const void *n1, const float *rstd1, cons
     return 0;
 }
 
+#ifndef MIVIT_ELEM_F16
 extern "C" size_t mivit_attn_out_bwd_workspace_bytes(int M) { return attn_out_bwd_ws_bytes(M); }
 extern "C" int mivit_attn_out_bwd(const void *dy, const void *n1, const float *rstd1, const float *gamma1, const void *ctx,
                                   const void *Wo_bf16, int M, void *dz1, void *dctx, float *dWo, float *dbo, float *dgamma1,
@@ -673,3 +678,4 @@ extern "C" int mivit_attn_out_bwd(const void *dy, const void *n1, const float *r
     return launch_attn_out_bwd(dy, n1, rstd1, gamma1, ctx, Wo_bf16, M, dz1, dctx, dWo, dbo, dgamma1, dbeta1, workspace, workspace_bytes,
                                static_cast<hipStream_t>(stream));
 }
+#endif

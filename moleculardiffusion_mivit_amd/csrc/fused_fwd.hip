@@ -24,6 +24,7 @@
 #include "stream_prims.h"
 #include <stdlib.h>
 #include <algorithm>
+#include "elem.h"          // element type of this translation unit (bf16, or f16 under -DMIVIT_ELEM_F16): after every other include
 
 #define RC(call) do { int rc_ = (call); if (rc_) return rc_; } while (0)
 
@@ -49,8 +50,7 @@ __device__ __forceinline__ bf16x8 lds_frag(const bf16 *p) { return *reinterpret_
 // 4 consecutive bf16 -> fp32 / fp32 -> 4 consecutive bf16 (8-byte global accesses)
 __device__ __forceinline__ f32x4 load4_bf16(const bf16 *p) {
     const uint2 v = *reinterpret_cast<const uint2 *>(p);
-    return f32x4{__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
-                 __uint_as_float(v.y & 0xffff0000u)};
+    return f32x4{elem_lo(v.x), elem_hi(v.x), elem_lo(v.y), elem_hi(v.y)};
 }
 __device__ __forceinline__ void store4_bf16(bf16 *p, const f32x4 v) {
     typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
@@ -135,7 +135,7 @@ __device__ __forceinline__ void stage_folded(bf16 *img, const bf16 *W, int rows,
                 const uint32_t w[4] = {raw[u].x, raw[u].y, raw[u].z, raw[u].w};
                 float v[8];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { v[2 * e] = __uint_as_float(w[e] << 16); v[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u); }
+                for (int e = 0; e < 4; ++e) { v[2 * e] = elem_lo(w[e]); v[2 * e + 1] = elem_hi(w[e]); }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] *= gam[c * 8 + e] * rsc;
                 store16(img + r * LD + c * 8, v);
@@ -549,7 +549,7 @@ int set_lds(Kern k, int bytes) {
 
 bool fused_layer_supported(int dtype, int E_, int F_, int H_, int S) {
     static const bool off = getenv("MIVIT_NO_FUSED_LAYER") != nullptr;
-    return !off && dtype == MIVIT_BF16 && E_ == E && F_ == F && H_ == H && S >= 1 && S <= 64;
+    return !off && dtype == MIVIT_ELEM_DTYPE && E_ == E && F_ == F && H_ == H && S >= 1 && S <= 64;
 }
 
 int launch_mlp_block_fwd(const void *nin, const float *gin, const float *bin, const void *W1, const float *b1, const void *W2,
@@ -633,6 +633,7 @@ int launch_attn_block_fwd(const void *nin, const float *gin, const float *bin, c
     return 0;
 }
 
+#ifndef MIVIT_ELEM_F16      // operator-level C-ABI: declared for bf16 (include/mivit_hip.h)
 // ---- operator-level C-ABI (tests, external callers) ----
 extern "C" int mivit_fused_layer_supported(int dtype, int embed_dim, int hidden_dim, int num_heads, int tokens) {
     return fused_layer_supported(dtype, embed_dim, hidden_dim, num_heads, tokens) ? 1 : 0;
@@ -653,3 +654,4 @@ extern "C" int mivit_attn_block_fwd(const void *n_in, const float *gamma_in, con
     return launch_attn_block_fwd(n_in, gamma_in, beta_in, Wqkv_bf16, bqkv, Wo_bf16, bo, gamma_out, beta_out, B, S, ctx, n_out,
                                  rstd, x_out, z_out, mean, qkv_out, static_cast<hipStream_t>(stream));
 }
+#endif

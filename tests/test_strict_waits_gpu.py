@@ -109,15 +109,28 @@ def _run_everything():
     for k, v in ops.attn_out_bwd(args[0], args[1], args[2], args[3], args[4], _bf(_randn((E, E), 31, 0.1))).items():
         out["attn_out_bwd_" + k] = v
     # --- the whole model at the bench shape, B = 4096: forward, loss, backward ---
+    # (bf16, and fp16: the same kernels compiled for IEEE half -- elem.h -- with their own counted waits in the object code)
     cfg = orc.MiViTConfig(embedding="linear", patch_size=64, embed_dim=128, num_heads=4, hidden_dim=256, num_layers=4)
-    m = build_product_model(cfg, "bf16", orc.closed_form_params(cfg))
     xs = 0.2 + 0.06 * _randn((4096, 32, 64, 64), 41)
     ls = torch.rand(4096, 1, generator=torch.Generator(device="cuda").manual_seed(42), device="cuda")
-    o = m(xs)
+    for prec in ("bf16", "fp16"):
+        m = build_product_model(cfg, prec, orc.closed_form_params(cfg))
+        o = m(xs)
+        (F.mse_loss(o, ls) * 256.0).backward()
+        out[f"model_{prec}_out"] = o.detach()
+        for k, p in m.named_parameters():
+            out[f"model_{prec}_grad_" + k] = p.grad.detach().clone()
+        torch.cuda.synchronize()
+        del m
+    # the 64-wide model (wave-stream K = 64 / 192, wgrad_small) at the Framerate shape
+    cfg3 = orc.MiViTConfig(embedding="linear", patch_size=13, embed_dim=64, num_heads=4, hidden_dim=128, num_layers=2)
+    m = build_product_model(cfg3, "bf16", orc.closed_form_params(cfg3))
+    x3 = 0.2 + 0.06 * _randn((4096, 30, 13, 13), 43)
+    o = m(x3)
     F.mse_loss(o, ls).backward()
-    out["model_out"] = o.detach()
+    out["model_c3_out"] = o.detach()
     for k, p in m.named_parameters():
-        out["model_grad_" + k] = p.grad.detach().clone()
+        out["model_c3_grad_" + k] = p.grad.detach().clone()
     torch.cuda.synchronize()
     del m
     return out
