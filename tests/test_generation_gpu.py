@@ -70,3 +70,48 @@ def test_noise_terms_have_the_reference_moments_on_gpu():
     # no particle, constant background: pixel = bm * Poisson(100) / 100 -> mean bm, std bm / sqrt(100)
     assert vid.shape == (200, 3, 16, 16)
     assert abs(float(vid.mean()) - bm) < 0.002 * bm and abs(float(vid.std()) - bm / 10) < 0.02 * bm / 10
+
+
+# ---- SURVEY section 8 row f4 on the GPU: real-data patch extraction and the ResNet comparison baselines -------------------
+def test_patch_extraction_on_gpu_tensors_matches_cpu():
+    """helpers/tracking.extract_particle_patches (reference helpersTracking.py:513-550) on a GPU movie: the gather runs on the
+    device and returns device tensors equal to the CPU (numpy) result, border positions zero-padded."""
+    from moleculardiffusion_mivit_amd.helpers.tracking import extract_particle_patches
+    g = torch.Generator().manual_seed(5)
+    movie = torch.rand(12, 40, 52, generator=g)
+    tracks = {0: [(0, 3.2, 4.7), (1, 0.4, 51.6), (2, 39.5, 0.2)], "b": [(t, 20.0 + 1.3 * t, 25.0 - 0.9 * t) for t in range(12)], 7: []}
+    want = extract_particle_patches(movie.numpy(), tracks, patch_size=9)
+    got = extract_particle_patches(movie.cuda(), tracks, patch_size=9)
+    for k in tracks:
+        assert got[k].is_cuda
+        assert got[k].shape[0] == len(tracks[k])
+        if len(tracks[k]):
+            assert torch.equal(got[k].cpu(), torch.as_tensor(want[k]))
+
+
+@pytest.mark.parametrize("kind", ["images", "images_features"])
+def test_resnet_baselines_train_on_gpu_like_on_cpu(kind):
+    """MultiImageResNet / MultiImageFeatureResNet (reference helpers/models.py:600-772; NOT on the MiViT path: stock PyTorch-ROCm
+    modules kept so that every factory of getTrainingModels builds): forward, loss and one AdamW step on the GPU track the CPU run
+    of the same module (MIOpen convolutions vs CPU: 1e-3)."""
+    import torch.nn.functional as F
+    from moleculardiffusion_mivit_amd.helpers.models import MultiImageFeatureResNet, MultiImageResNet
+    torch.manual_seed(3)
+    m = MultiImageResNet(9) if kind == "images" else MultiImageFeatureResNet(9, 25)
+    m.train()
+    x, f, y = torch.rand(6, 30, 9, 9), torch.randn(6, 25), torch.rand(6, 1)
+    import copy
+    mg = copy.deepcopy(m).cuda()
+    outs = []
+    for mod, dev in ((m, "cpu"), (mg, "cuda")):
+        opt = torch.optim.AdamW(mod.parameters(), lr=1e-3)
+        args = (x.to(dev),) if kind == "images" else (x.to(dev), f.to(dev))
+        out = mod(*args)
+        loss = F.mse_loss(out, y.to(dev))
+        loss.backward()
+        opt.step()
+        outs.append((out.detach().cpu(), float(loss.detach()), mod(*args).detach().cpu()))
+    (o0, l0, s0), (o1, l1, s1) = outs
+    assert o1.shape == (6, 1)
+    assert float((o0 - o1).abs().max()) < 1e-3 * max(1.0, float(o0.abs().max())) and abs(l0 - l1) < 1e-3 * max(1.0, abs(l0))
+    assert float((s0 - s1).abs().max()) < 5e-2 * max(1.0, float(s0.abs().max()))       # after one optimizer step (BatchNorm batch statistics of 6 sequences)
