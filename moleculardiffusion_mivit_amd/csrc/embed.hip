@@ -363,15 +363,21 @@ __global__ __launch_bounds__(NW * 64) void embed_fwd_direct(const EmbFwdArgs a) 
     // epilogue: + bias, through LDS as fp32, one 16-row tile per wave per pass, 16-byte bf16 stores
     constexpr int LDC = C::BN + 4;
     float *Cs = reinterpret_cast<float *>(smem) + wave * 16 * LDC;
+    float bv[8];                   // (one batch of loads: see embed_fwd_direct2)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bv[j] = 0.f;
+    if (a.bias) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bv[j] = a.bias[n0 + j * 16 + cq];
+    }
 #pragma unroll
     for (int i = 0; i < TMW; ++i) {
         barrier();
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int lc = j * 16 + cq;
-            const float bv = a.bias ? a.bias[n0 + lc] : 0.f;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) Cs[(4 * g + r) * LDC + lc] = acc[i][j][r] + bv;
+            for (int r = 0; r < 4; ++r) Cs[(4 * g + r) * LDC + lc] = acc[i][j][r] + bv[j];
         }
         barrier();
         for (int c = lane; c < 16 * (C::BN / 8); c += 64) {

@@ -133,6 +133,15 @@ __global__ __launch_bounds__(NT) void rowstream_kernel(const RsArgs a) {
     const bf16 *E = E_KIND == 2 ? a.dact : a.resid;
     const int64_t lde = E_KIND == 2 ? a.ldd : a.ldr;
 
+    // this lane's bias values, loaded once (inside the tile loop, under `a.bias ? ... : 0`, each was an L2 round trip behind a
+    // vmcnt(0) -- which also drained the next tile's DMA prefetch in every epilogue pass)
+    float bias_v[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bias_v[j] = 0.f;
+    if (a.bias) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bias_v[j] = a.bias[n0 + wn * WCOLS + j * 16 + cq];
+    }
     issue_w<K, DGRAD, HAS_E>(a, Wimg, n0, wave, lane);
 #pragma unroll
     for (int s = 0; s < D; ++s)
@@ -221,9 +230,8 @@ __global__ __launch_bounds__(NT) void rowstream_kernel(const RsArgs a) {
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
                         const int lc = wn * WCOLS + j * 16 + cq;
-                        const float bv = a.bias ? a.bias[n0 + lc] : 0.f;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) Cs[(i * 16 + 4 * g + r) * BN + lc] = acc[i][j][r] + bv;
+                        for (int r = 0; r < 4; ++r) Cs[(i * 16 + 4 * g + r) * BN + lc] = acc[i][j][r] + bias_v[j];
                     }
             }
             barrier();

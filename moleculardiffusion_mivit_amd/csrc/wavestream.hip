@@ -43,7 +43,8 @@ struct WsCfg {
     static constexpr int W_ROWS = DGRAD ? K : BN;
     static constexpr int W_BYTES = W_ROWS * W_LD * 2;
     static constexpr int SCRATCH = 16 * LDC * 4;
-    static constexpr int LDS = W_BYTES + NWV * SCRATCH;
+    static constexpr int GB_BYTES = 2 * BN * 4;                          // LayerNorm gamma | beta of the slice (fused-LayerNorm launches)
+    static constexpr int LDS = W_BYTES + NWV * SCRATCH + GB_BYTES;
     static_assert(LDS <= 160 * 1024, "LDS budget");
 };
 
@@ -65,6 +66,10 @@ __global__ __launch_bounds__((K == 64 ? 16 : (K == 128 ? 12 : 8)) * 64) void wav
     const int n0 = bx * BN;
     bf16 *Wimg = reinterpret_cast<bf16 *>(smem);
     float *Cs = reinterpret_cast<float *>(smem + C::W_BYTES) + wave * 16 * LDC;
+    float *gb = reinterpret_cast<float *>(smem + C::W_BYTES + C::NWV * C::SCRATCH);          // [gamma BN | beta BN]
+    if (LN) {        // staged once: read from global memory in the epilogue they were 2 x 8 x NCH loads per 16-row tile and lane
+        for (int i = tid; i < BN; i += NT) { gb[i] = a.gamma[i]; gb[BN + i] = a.beta[i]; }
+    }
 
     // ---- weight slice -> LDS, once ----
     if (!DGRAD) {       // rows n0 .. n0+127 of W [N, K]: k-contiguous
@@ -80,6 +85,15 @@ __global__ __launch_bounds__((K == 64 ? 16 : (K == 128 ? 12 : 8)) * 64) void wav
     }
     __syncthreads();
 
+    // this lane's bias values, loaded once per wave (read inside the tile loop under `a.bias ? ... : 0` they were TN serialised
+    // L2 round trips per 16-row tile, each behind a wait that also drained the row prefetch)
+    float bias_v[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bias_v[j] = 0.f;
+    if (a.bias) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bias_v[j] = a.bias[n0 + j * 16 + cq];
+    }
     const int ntiles = (a.M + 15) / 16, stride = gridDim.y * C::NWV;
     int tile = by * C::NWV + wave;
     const bf16 *E = E_KIND == 2 ? a.dact : a.resid;
@@ -122,9 +136,8 @@ __global__ __launch_bounds__((K == 64 ? 16 : (K == 128 ? 12 : 8)) * 64) void wav
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int lc = j * 16 + cq;
-            const float bv = a.bias ? a.bias[n0 + lc] : 0.f;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) Cs[(4 * g + r) * LDC + lc] = acc[j][r] + bv;
+            for (int r = 0; r < 4; ++r) Cs[(4 * g + r) * LDC + lc] = acc[j][r] + bias_v[j];
         }
         wave_lds_fence();
         const int lr = lane >> 2, row = tile * 16 + lr;
@@ -170,7 +183,7 @@ __global__ __launch_bounds__((K == 64 ? 16 : (K == 128 ? 12 : 8)) * 64) void wav
                     const int lc = c * 32 + (lane & 3) * 8;
                     float o8[8];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) o8[e] = (v[c][e] - mu) * rs * a.gamma[lc + e] + a.beta[lc + e];
+                    for (int e = 0; e < 8; ++e) o8[e] = (v[c][e] - mu) * rs * gb[lc + e] + gb[BN + lc + e];
                     store16(a.Y + (int64_t)row * a.ldy + lc, o8);
                 }
                 if ((lane & 3) == 0) { a.mean[row] = mu; a.rstd[row] = rs; }
