@@ -401,6 +401,298 @@ __global__ __launch_bounds__(NT) void mlp_block_bwd_kernel(const MlpBwdArgs a) {
 }
 
 // ================================================================================================================
+// The same block with the hidden units split EIGHT ways (8 waves = two per SIMD, 256 registers each): a wave keeps the
+// [32 x 128] + [128 x 32] blocks of dW1 / dW2 of ITS 32 hidden units (128 accumulator registers) and the matching fc2^T slice
+// (32 registers), so a second wave fits on every SIMD and covers the other's LDS round trips -- the four-wave kernel above has
+// nobody to cover them (3.6 k of its 10.6 k cycles per tile are the un-prefetched u / dh loop, scripts/phase_timing.py).
+// The element-wise phase is split by ROLE: waves 0-3 turn dy / n2 into the dz2 image and the three column-sum vectors, waves 4-7
+// turn n1 into the x1 image; each wave DMA-prefetches only what its role consumes (6 / 2 pieces per tile).  Phase 2: wave w owns
+// input features 16 w .. 16 w + 15 (one 8-byte row store per row tile: the count behind wait_vm<2>).  Same LDS layout, same
+// slab layout, same arithmetic per element (dW / db accumulate the same products in the same row order per hidden unit).
+// ================================================================================================================
+constexpr int NW8 = 8, NT8 = NW8 * 64, NH = NT8 / 2;         // NH = 256 threads per role
+
+template <int ACT>
+__global__ __launch_bounds__(NT8) void mlp_block_bwd8_kernel(const MlpBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16 *W1i = reinterpret_cast<bf16 *>(smem + OFF_W1);
+    bf16 *X = reinterpret_cast<bf16 *>(smem + OFF_X), *DZ = reinterpret_cast<bf16 *>(smem + OFF_DZ), *DH = reinterpret_cast<bf16 *>(smem + OFF_DH);
+    float *b1f = reinterpret_cast<float *>(smem + OFF_VEC);
+    f32x4 *cacc = reinterpret_cast<f32x4 *>(smem + OFF_ACC);
+    uint4 *stg = reinterpret_cast<uint4 *>(smem + OFF_STG);
+    float *rst = reinterpret_cast<float *>(smem + OFF_RST);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, cq = lane & 15, q = cq >> 2, pp = cq & 3;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);       // (scalar: role tests and DMA destinations stay in SGPRs)
+    const bool ew = wave_u < 4;                      // role: element-wise LayerNorm backward (dz2, column sums) | x1 image
+    const int th = tid & (NH - 1), wh = wave_u & 3;  // thread / wave index inside the role
+    const unsigned stg_a = __builtin_amdgcn_readfirstlane(lds_addr(stg)) + wh * 1024u, rst_a = __builtin_amdgcn_readfirstlane(lds_addr(rst)) + wh * 256u;
+
+    // ---- one-time staging ----
+    static_assert((F * (E / 8)) % (4 * NT8) == 0, "W1 staging batches");
+    for (int i0 = tid; i0 < F * (E / 8); i0 += 4 * NT8) {
+        uint4 v0, v1, v2, v3;
+        {
+            const int i = i0, n = i / (E / 8), cc = i - n * (E / 8);
+            v0 = *reinterpret_cast<const uint4 *>(a.W1 + (int64_t)n * E + cc * 8);
+        }
+        { const int i = i0 + NT8, n = i / (E / 8), cc = i - n * (E / 8); v1 = *reinterpret_cast<const uint4 *>(a.W1 + (int64_t)n * E + cc * 8); }
+        { const int i = i0 + 2 * NT8, n = i / (E / 8), cc = i - n * (E / 8); v2 = *reinterpret_cast<const uint4 *>(a.W1 + (int64_t)n * E + cc * 8); }
+        { const int i = i0 + 3 * NT8, n = i / (E / 8), cc = i - n * (E / 8); v3 = *reinterpret_cast<const uint4 *>(a.W1 + (int64_t)n * E + cc * 8); }
+        { const int i = i0, n = i / (E / 8), cc = i - n * (E / 8); *reinterpret_cast<uint4 *>(W1i + n * LDE + cc * 8) = v0; }
+        { const int i = i0 + NT8, n = i / (E / 8), cc = i - n * (E / 8); *reinterpret_cast<uint4 *>(W1i + n * LDE + cc * 8) = v1; }
+        { const int i = i0 + 2 * NT8, n = i / (E / 8), cc = i - n * (E / 8); *reinterpret_cast<uint4 *>(W1i + n * LDE + cc * 8) = v2; }
+        { const int i = i0 + 3 * NT8, n = i / (E / 8), cc = i - n * (E / 8); *reinterpret_cast<uint4 *>(W1i + n * LDE + cc * 8) = v3; }
+    }
+    for (int n = tid; n < F; n += NT8) b1f[n] = a.b1[n];
+    for (int i = tid; i < E; i += NT8) { b1f[F + i] = a.gamma2[i]; b1f[F + E + i] = a.gamma1[i]; b1f[F + 2 * E + i] = a.beta1[i]; }
+    // fc2^T slice of this wave's hidden units n = 32 wave + 16 nt + cq: w2f[nt][ks] = W2[32 ks + 8 g .. + 7][n]
+    bf16x8 w2f[2][4];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int n = 32 * wave + 16 * nt + cq;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 t;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t[e] = __builtin_bit_cast(__bf16, a.W2[(int64_t)(ks * 32 + 8 * g + e) * F + n].v);
+            w2f[nt][ks] = t;
+        }
+    }
+    typedef __attribute__((address_space(3))) const float lds_cf;
+    if (ew) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) cacc[i * NH + th] = f32x4{0.f, 0.f, 0.f, 0.f};       // (thread-private slots)
+    }
+    f32x4 dW1[2][8], dW2[8][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { dW1[i][j] = zero; dW2[j][i] = zero; }
+    float db1[2] = {0.f, 0.f};
+    __syncthreads();
+
+    const int ntiles = (a.M + R - 1) / R;
+    int tile = blockIdx.x;
+    // staging slots (thread-private, [slot][NH] x 16 B): 0-3 = dy, n2 of the two rows (role ew), 4-5 = n1 of the two rows (role xw)
+    auto prefetch = [&](int t, int r0, int c) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            // (wave-uniform base + 32-bit byte offset: M * E * 2 < 2^32 is checked by the launcher)
+            const int row = min(t * R + r0 + 16 * i, a.M - 1);
+            const unsigned o = ((unsigned)row * E + 8 * c) * 2u;
+            if (ew) {
+                dma16_sbase(a.dy, o, stg_a + (2 * i + 0) * NH * 16u);
+                dma16_sbase(a.n2, o, stg_a + (2 * i + 1) * NH * 16u);
+                dma4_sbase(a.rstd2, (unsigned)row * 4u, rst_a + i * NH * 4u);
+            } else {
+                dma16_sbase(a.n1, o, stg_a + (4 + i) * NH * 16u);
+            }
+        }
+    };
+    if (tile < ntiles) prefetch(tile, th >> 4, th & 15);
+    bool first = true;
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int row0 = tile * R;
+        // ---------------- phase 0 (by role) ----------------
+        // The element-wise slice of a thread (inside its role): columns 8c .. 8c+7 of rows r0 and r0 + 16 of the tile.  Everything
+        // addressed from it (staging slots, column-sum slots, image rows, constants) is re-derived from an OPAQUE copy of the
+        // thread index every tile: derived once before the loop, the compiler keeps a dozen loop-invariant LDS address registers
+        // alive across all three phases -- and at the 256 registers a two-waves-per-SIMD kernel has, spills them (their scratch
+        // reloads sit in vmcnt behind the row prefetch).
+        int thv = th;
+        asm volatile("" : "+v"(thv));
+        const int c = thv & 15, r0 = thv >> 4;
+        lds_cf *gam2 = (lds_cf *)(b1f + F + 8 * c), *gam1 = (lds_cf *)(b1f + F + E + 8 * c), *bet1 = (lds_cf *)(b1f + F + 2 * E + 8 * c);
+        // VM program order of a wave: P(t) [6 (ew) / 2 (xw) DMA pieces: its staged rows of tile t] | the 2 row stores of tile
+        // t-1's phase 2 (one 8-byte store per row tile, issued by every wave of a full tile; the one partial tile is the last of
+        // the launch) | this wait: vmcnt(2) = P(t) landed.
+        if (first) wait_vm<0>(); else wait_vm<2>();
+        first = false;
+        if (ew) {
+            float sg[8], sb[8], sz[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sg[e] = sb[e] = sz[e] = 0.f;
+            typedef __attribute__((address_space(3))) const f32x4 lds_cf4;
+            const f32x4 g2a = *(lds_cf4 *)(gam2), g2b = *(lds_cf4 *)(gam2 + 4);
+            const float g2v[8] = {g2a[0], g2a[1], g2a[2], g2a[3], g2b[0], g2b[1], g2b[2], g2b[3]};
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                float d[8], nh[8];
+                const bool ok = row0 + r0 + 16 * i < a.M;          // rows past the end were clamped to a real row: cancel them
+                const uint4 pdy = keep_if(stg[(2 * i + 0) * NH + thv], ok), pn2 = stg[(2 * i + 1) * NH + thv];
+                unpack8(pdy, d); unpack8(pn2, nh);
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    sg[e] += d[e] * nh[e]; sb[e] += d[e];
+                    d[e] *= g2v[e];                                // d now holds gamma2 * dy
+                    s1 += d[e]; s2 += d[e] * nh[e];
+                }
+                s1 = g16_sum(s1) * (1.f / E); s2 = g16_sum(s2) * (1.f / E);
+                const float prs = __uint_as_float(__float_as_uint(rst[i * NH + thv]) & (ok ? 0xffffffffu : 0u));
+                float dz[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { dz[e] = prs * (d[e] - s1 - nh[e] * s2); sz[e] += dz[e]; }
+                store16(DZ + (r0 + 16 * i) * LDE + 8 * c, dz);
+                __builtin_amdgcn_sched_barrier(0);       // one row at a time (interleaving the two doubles the working set)
+            }
+            {   // the running column sums, two batches of three 16-byte reads (register budget)
+                f32x4 ca[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) ca[k] = cacc[k * NH + thv];
+                __builtin_amdgcn_sched_barrier(0);
+                cacc[0 * NH + thv] = ca[0] + f32x4{sg[0], sg[1], sg[2], sg[3]}; cacc[1 * NH + thv] = ca[1] + f32x4{sg[4], sg[5], sg[6], sg[7]};
+                cacc[2 * NH + thv] = ca[2] + f32x4{sb[0], sb[1], sb[2], sb[3]};
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) ca[k] = cacc[(3 + k) * NH + thv];
+                __builtin_amdgcn_sched_barrier(0);
+                cacc[3 * NH + thv] = ca[0] + f32x4{sb[4], sb[5], sb[6], sb[7]};
+                cacc[4 * NH + thv] = ca[1] + f32x4{sz[0], sz[1], sz[2], sz[3]}; cacc[5 * NH + thv] = ca[2] + f32x4{sz[4], sz[5], sz[6], sz[7]};
+            }
+        } else {
+            typedef __attribute__((address_space(3))) const f32x4 lds_cf4;
+            const f32x4 g1a = *(lds_cf4 *)(gam1), g1b = *(lds_cf4 *)(gam1 + 4), b1a = *(lds_cf4 *)(bet1), b1b = *(lds_cf4 *)(bet1 + 4);
+            const float g1v[8] = {g1a[0], g1a[1], g1a[2], g1a[3], g1b[0], g1b[1], g1b[2], g1b[3]};
+            const float b1v[8] = {b1a[0], b1a[1], b1a[2], b1a[3], b1b[0], b1b[1], b1b[2], b1b[3]};
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const bool ok = row0 + r0 + 16 * i < a.M;
+                const uint4 pn1 = keep_if(stg[(4 + i) * NH + thv], ok);
+                float x1v[8];
+                unpack8(pn1, x1v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x1v[e] = ok ? x1v[e] * g1v[e] + b1v[e] : 0.f;
+                store16(X + (r0 + 16 * i) * LDE + 8 * c, x1v);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the staging slots have been read: they may be refilled
+        prefetch(min(tile + (int)gridDim.x, ntiles - 1), r0, c);       // next tile's rows: in flight under phases 1 and 2
+        barrier();
+        // ---------------- phase 1: u, dh for this wave's 32 hidden units; dW1, dW2 ----------------
+        bf16x8 hB[2], dhB[2];
+        {
+            typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+            const int dst_lane = (32 * wave + cq) * R + 4 * g, dst_sw0 = (q & 1) << 4, dst_sw1 = ((q & 1) ^ 1) << 4;
+            bf16x4 hlo[2], dlo[2];                  // rows 0-15 of h / dh, packed, while rows 16-31 are computed (register budget)
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                f32x4 u[2], dh[2];
+#pragma unroll
+                for (int n2 = 0; n2 < 2; ++n2) {
+                    const float bv = b1f[32 * wave + 16 * n2 + cq];
+                    u[n2] = f32x4{bv, bv, bv, bv}; dh[n2] = zero;
+                }
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const bf16x8 xa = lds_frag(X + (16 * rt + cq) * LDE + ks * 32 + 8 * g);
+                    const bf16x8 za = lds_frag(DZ + (16 * rt + cq) * LDE + ks * 32 + 8 * g);
+#pragma unroll
+                    for (int n2 = 0; n2 < 2; ++n2) {
+                        u[n2] = mma(xa, lds_frag(W1i + (32 * wave + 16 * n2 + cq) * LDE + ks * 32 + 8 * g), u[n2]);
+                        dh[n2] = mma(za, w2f[n2][ks], dh[n2]);
+                    }
+                }
+#pragma unroll
+                for (int n2 = 0; n2 < 2; ++n2) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float uu = u[n2][j];
+                        dh[n2][j] *= act_bwd(ACT, ACT == MIVIT_ACT_GELU ? uu : act_fwd(ACT, uu));
+                        u[n2][j] = act_fwd(ACT, uu);
+                        db1[n2] += dh[n2][j];
+                    }
+                    const bf16x4 hb = {(__bf16)u[n2][0], (__bf16)u[n2][1], (__bf16)u[n2][2], (__bf16)u[n2][3]};
+                    const bf16x4 db = {(__bf16)dh[n2][0], (__bf16)dh[n2][1], (__bf16)dh[n2][2], (__bf16)dh[n2][3]};
+                    // rows 16 rt + 4 g .. + 3 of hidden unit 32 wave + 16 n2 + cq (dht_off with the lane part factored out:
+                    // this unit's swizzle bit is q & 1)
+                    *reinterpret_cast<bf16x4 *>(DH + dst_lane + (rt ? dst_sw1 : dst_sw0) + 16 * n2 * R) = db;
+                    if (rt == 0) { hlo[n2] = hb; dlo[n2] = db; }
+                    else {
+                        struct { bf16x4 lo, hi; } ph = {hlo[n2], hb}, pd = {dlo[n2], db};
+                        hB[n2] = __builtin_bit_cast(bf16x8, ph);
+                        dhB[n2] = __builtin_bit_cast(bf16x8, pd);
+                    }
+                }
+            }
+        }
+        {
+            bf16x8 xb = tr_pair(X + (4 * g + q) * LDE + 4 * pp, X + (16 + 4 * g + q) * LDE + 4 * pp);
+            bf16x8 zb = tr_pair(DZ + (4 * g + q) * LDE + 4 * pp, DZ + (16 + 4 * g + q) * LDE + 4 * pp);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                bf16x8 xn = xb, zn = zb;
+                if (t < 7) {
+                    xn = tr_pair(X + (4 * g + q) * LDE + 16 * (t + 1) + 4 * pp, X + (16 + 4 * g + q) * LDE + 16 * (t + 1) + 4 * pp);
+                    zn = tr_pair(DZ + (4 * g + q) * LDE + 16 * (t + 1) + 4 * pp, DZ + (16 + 4 * g + q) * LDE + 16 * (t + 1) + 4 * pp);
+                }
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    dW1[nt][t] = mma(dhB[nt], xb, dW1[nt][t]);       // [n][k] += dh^T x1
+                    dW2[t][nt] = mma(zb, hB[nt], dW2[t][nt]);        // [e][n] += dz2^T h
+                }
+                xb = xn; zb = zn;
+            }
+        }
+        barrier();
+        // ---------------- phase 2: dx1^T for this wave's 16 input features ----------------
+        f32x4 dx[2] = {zero, zero};
+        {
+            auto wfrag = [&](int ks) {
+                return tr_pair(W1i + (32 * ks + 4 * g + q) * LDE + 16 * wave + 4 * pp, W1i + (32 * ks + 16 + 4 * g + q) * LDE + 16 * wave + 4 * pp);
+            };
+            const bf16 *dbase[2] = {DH + (4 * g + q) * R + ((g & 1) << 4) + 4 * pp, DH + (4 * g + q) * R + (((g & 1) ^ 1) << 4) + 4 * pp};
+            auto dfrag = [&](int ks, int rt) { return tr_pair(dbase[rt] + 32 * ks * R, dbase[rt] + (32 * ks + 16) * R); };
+            bf16x8 d0 = dfrag(0, 0), d1 = dfrag(0, 1), w0 = wfrag(0);
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                bf16x8 e0 = d0, e1 = d1, v0 = w0;
+                if (ks < 7) { e0 = dfrag(ks + 1, 0); e1 = dfrag(ks + 1, 1); v0 = wfrag(ks + 1); }
+                dx[0] = mma(w0, d0, dx[0]); dx[1] = mma(w0, d1, dx[1]);
+                d0 = e0; d1 = e1; w0 = v0;
+            }
+        }
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            const int row = row0 + 16 * rt + cq, col = 16 * wave + 4 * g;
+            const uint2 zr = *reinterpret_cast<const uint2 *>(DZ + (16 * rt + cq) * LDE + col);
+            f32x4 o = dx[rt];
+            o[0] += elem_lo(zr.x); o[1] += elem_hi(zr.x);
+            o[2] += elem_lo(zr.y); o[3] += elem_hi(zr.y);
+            if (row < a.M) {
+                typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+                const bf16x4 ob = {(__bf16)o[0], (__bf16)o[1], (__bf16)o[2], (__bf16)o[3]};
+                *reinterpret_cast<bf16x4 *>(a.dx1 + (int64_t)row * E + col) = ob;
+            }
+        }
+        barrier();
+    }
+
+    // ---------------- partial gradients -> this workgroup's slab ----------------
+    float *sl = a.slabs + (int64_t)blockIdx.x * SL_TOTAL;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                sl[SL_W1 + (32 * wave + 16 * nt + 4 * g + j) * E + 16 * t + cq] = dW1[nt][t][j];
+                sl[SL_W2 + (16 * t + 4 * g + j) * F + 32 * wave + 16 * nt + cq] = dW2[t][nt][j];
+            }
+        const float sv = x4_sum(db1[nt]);
+        if (g == 0) sl[SL_B1 + 32 * wave + 16 * nt + cq] = sv;
+    }
+    __syncthreads();
+    for (int i = tid; i < 3 * E; i += NT8) {
+        const int which = i / E, col = i - which * E, cc = col >> 3, e = col & 7;
+        float sv = 0.f;
+        for (int rr = 0; rr < 16; ++rr) sv += cacc[(2 * which + (e >> 2)) * NH + cc + 16 * rr][e & 3];
+        sl[(which == 0 ? SL_G2 : which == 1 ? SL_BE2 : SL_B2) + col] = sv;
+    }
+}
+
+// ================================================================================================================
 // LayerNorm-1 backward + out-projection backward (autograd of x1 = LN1(x + out_proj(ctx)), models.py:57,100-102, up to the
 // attention core):   in : dy = dL/dx1, n1 / rstd1 (LN1's normalised output, 1/std), ctx (the out-projection's input)
 //                    out: dz1 = dL/d(pre-norm sum) [the residual branch's gradient], dctx = dz1 Wo, dWo = dz1^T ctx, dbo, dgamma1, dbeta1
@@ -586,11 +878,19 @@ int launch_mlp_block_bwd(const void *dy, const void *n2, const float *rstd2, con
 #endif
     {
         ProfScope prof(s);
+        // MIVIT_MLP_BWD_WAVES = 4: the first kernel (hidden units split four ways, one wave per SIMD); 8 (default): split eight ways
+        static const int waves = [] { const char *e = getenv("MIVIT_MLP_BWD_WAVES"); return e && atoi(e) == 4 ? 4 : 8; }();
 #define BWD_LAUNCH(ACT_)                                                                                         \
     do {                                                                                                         \
-        auto kern = mlp_block_bwd_kernel<ACT_>;                                                                  \
-        MIVIT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES)); \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), LDS_BYTES, s, a);                                         \
+        if (waves == 8) {                                                                                        \
+            auto kern = mlp_block_bwd8_kernel<ACT_>;                                                             \
+            MIVIT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES)); \
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(NT8), LDS_BYTES, s, a);                                    \
+        } else {                                                                                                 \
+            auto kern = mlp_block_bwd_kernel<ACT_>;                                                              \
+            MIVIT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES)); \
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), LDS_BYTES, s, a);                                     \
+        }                                                                                                        \
     } while (0)
         switch (act) {
             case MIVIT_ACT_RELU: BWD_LAUNCH(MIVIT_ACT_RELU); break;

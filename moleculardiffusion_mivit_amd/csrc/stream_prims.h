@@ -20,6 +20,18 @@ __device__ __forceinline__ void dma16(const void *g, void *l) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(base) : "memory", "m0");
 }
 __device__ __forceinline__ void dma16_opaque(const void *g, void *l) { dma16(g, l); }
+// the same with the source as a wave-uniform 64-bit base (SGPR pair) + a 32-bit per-lane byte offset: no 64-bit per-lane
+// pointer has to live in VGPRs across a loop (kernels at their register limit: mlp_block_bwd8)
+__device__ __forceinline__ void dma16_sbase(const void *base_uniform, unsigned off_bytes, unsigned lds_addr_uniform) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off_bytes), "s"(base_uniform), "s"(lds_addr_uniform) : "memory", "m0");
+}
+__device__ __forceinline__ void dma4_sbase(const void *base_uniform, unsigned off_bytes, unsigned lds_addr_uniform) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(off_bytes), "s"(base_uniform), "s"(lds_addr_uniform) : "memory", "m0");
+}
+__device__ __forceinline__ unsigned lds_addr(const void *l) {          // 32-bit LDS byte address of a shared-memory pointer
+    typedef __attribute__((address_space(3))) void lptr_t;
+    return (unsigned)(size_t)(lptr_t *)l;
+}
 // the builtin form (the compiler tracks it).  Kept for the frame-embedding weight gradient, the one kernel that measured
 // SLOWER with the written-out form (1.39 -> 1.53 ms: its loop only reads LDS, nothing was being over-waited, and the
 // compiler's own placement of the M0 set-up and waits is the better schedule there).
