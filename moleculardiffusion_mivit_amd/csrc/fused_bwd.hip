@@ -492,6 +492,9 @@ __global__ __launch_bounds__(NT8) void mlp_block_bwd8_kernel(const MlpBwdArgs a)
     };
     if (tile < ntiles) prefetch(tile, th >> 4, th & 15);
     bool first = true;
+#ifdef MIVIT_PHASE_TIMING
+    unsigned long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt_last = __builtin_amdgcn_s_memtime();
+#endif
     for (; tile < ntiles; tile += gridDim.x) {
         const int row0 = tile * R;
         // ---------------- phase 0 (by role) ----------------
@@ -509,6 +512,7 @@ __global__ __launch_bounds__(NT8) void mlp_block_bwd8_kernel(const MlpBwdArgs a)
         // the launch) | this wait: vmcnt(2) = P(t) landed.
         if (first) wait_vm<0>(); else wait_vm<2>();
         first = false;
+        PT_MARK(0);
         if (ew) {
             float sg[8], sb[8], sz[8];
 #pragma unroll
@@ -568,8 +572,10 @@ __global__ __launch_bounds__(NT8) void mlp_block_bwd8_kernel(const MlpBwdArgs a)
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the staging slots have been read: they may be refilled
+        PT_MARK(1);
         prefetch(min(tile + (int)gridDim.x, ntiles - 1), r0, c);       // next tile's rows: in flight under phases 1 and 2
         barrier();
+        PT_MARK(2);
         // ---------------- phase 1: u, dh for this wave's 32 hidden units; dW1, dW2 ----------------
         bf16x8 hB[2], dhB[2];
         {
@@ -617,6 +623,7 @@ __global__ __launch_bounds__(NT8) void mlp_block_bwd8_kernel(const MlpBwdArgs a)
                 }
             }
         }
+        PT_MARK(3);
         {
             bf16x8 xb = tr_pair(X + (4 * g + q) * LDE + 4 * pp, X + (16 + 4 * g + q) * LDE + 4 * pp);
             bf16x8 zb = tr_pair(DZ + (4 * g + q) * LDE + 4 * pp, DZ + (16 + 4 * g + q) * LDE + 4 * pp);
@@ -635,7 +642,9 @@ __global__ __launch_bounds__(NT8) void mlp_block_bwd8_kernel(const MlpBwdArgs a)
                 xb = xn; zb = zn;
             }
         }
+        PT_MARK(4);
         barrier();
+        PT_MARK(5);
         // ---------------- phase 2: dx1^T for this wave's 16 input features ----------------
         f32x4 dx[2] = {zero, zero};
         {
@@ -666,8 +675,14 @@ __global__ __launch_bounds__(NT8) void mlp_block_bwd8_kernel(const MlpBwdArgs a)
                 *reinterpret_cast<bf16x4 *>(a.dx1 + (int64_t)row * E + col) = ob;
             }
         }
+        PT_MARK(6);
         barrier();
+        PT_MARK(7);
     }
+#ifdef MIVIT_PHASE_TIMING
+    if (a.dbg && lane == 0)
+        for (int kk = 0; kk < 8; ++kk) a.dbg[((int64_t)blockIdx.x * NW8 + wave) * 8 + kk] = pt[kk];
+#endif
 
     // ---------------- partial gradients -> this workgroup's slab ----------------
     float *sl = a.slabs + (int64_t)blockIdx.x * SL_TOTAL;
@@ -871,15 +886,16 @@ int launch_mlp_block_bwd(const void *dy, const void *n2, const float *rstd2, con
                  beta1, static_cast<const bf16 *>(W1), b1, static_cast<const bf16 *>(W2), M, static_cast<bf16 *>(dx1),
                  static_cast<float *>(ws), nullptr};
     const int grid = grid_for(M);
+    // MIVIT_MLP_BWD_WAVES = 4: the first kernel (hidden units split four ways, one wave per SIMD); 8 (default): split eight ways
+    static const int waves = [] { const char *e = getenv("MIVIT_MLP_BWD_WAVES"); return e && atoi(e) == 4 ? 4 : 8; }();
+    MIVIT_CHECK((int64_t)M * E * 2 < (1ll << 32), "mlp_block_bwd: %d rows exceed the 32-bit byte offsets of the row prefetch", M);
 #ifdef MIVIT_PHASE_TIMING
     static unsigned long long *dbg_buf = nullptr;
-    if (!dbg_buf) MIVIT_HIP(hipMalloc(&dbg_buf, 256 * NW * 8 * sizeof(unsigned long long)));
+    if (!dbg_buf) MIVIT_HIP(hipMalloc(&dbg_buf, 256 * NW8 * 8 * sizeof(unsigned long long)));
     a.dbg = dbg_buf;
 #endif
     {
         ProfScope prof(s);
-        // MIVIT_MLP_BWD_WAVES = 4: the first kernel (hidden units split four ways, one wave per SIMD); 8 (default): split eight ways
-        static const int waves = [] { const char *e = getenv("MIVIT_MLP_BWD_WAVES"); return e && atoi(e) == 4 ? 4 : 8; }();
 #define BWD_LAUNCH(ACT_)                                                                                         \
     do {                                                                                                         \
         if (waves == 8) {                                                                                        \
@@ -904,15 +920,21 @@ int launch_mlp_block_bwd(const void *dy, const void *n2, const float *rstd2, con
 #ifdef MIVIT_PHASE_TIMING
     {
         static const char *names[8] = {"wait rows", "element-wise", "prefetch+barrier", "u, dh", "dW1, dW2", "barrier", "dx1 + stores", "barrier"};
-        std::vector<unsigned long long> h((size_t)grid * NW * 8);
+        const int nwv = waves == 8 ? NW8 : NW;
+        std::vector<unsigned long long> h((size_t)grid * nwv * 8);
         MIVIT_HIP(hipStreamSynchronize(s));
         MIVIT_HIP(hipMemcpy(h.data(), dbg_buf, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         const int tiles = ceil_div(M, R);
         double tot = 0;
         for (int k = 0; k < 8; ++k) {
             double sum = 0;
-            for (int i = 0; i < grid * NW; ++i) sum += (double)h[(size_t)i * 8 + k];
-            const double per_tile = sum / NW / tiles;                       // shader-clock cycles per tile of one workgroup, wave average
+            double sum_ew = 0, sum_xw = 0;
+            for (int i = 0; i < grid * nwv; ++i) {
+                sum += (double)h[(size_t)i * 8 + k];
+                ((i % nwv) < 4 ? sum_ew : sum_xw) += (double)h[(size_t)i * 8 + k];
+            }
+            if (nwv == 8) fprintf(stderr, "[mlp_block_bwd phases]   waves 0-3 %8.1f   waves 4-7 %8.1f\n", sum_ew / 4 / tiles, sum_xw / 4 / tiles);
+            const double per_tile = sum / nwv / tiles;                       // shader-clock cycles per tile of one workgroup, wave average
             tot += per_tile;
             fprintf(stderr, "[mlp_block_bwd phases] %-18s %8.1f cycles/tile\n", names[k], per_tile);
         }

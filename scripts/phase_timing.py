@@ -17,6 +17,7 @@ lib = os.path.join(b.PKG, "libmivit_hip_timing.so")
 subprocess.check_call([b._hipcc()] + b.FLAGS + ["-DMIVIT_PHASE_TIMING", "-c", os.path.join(b.HERE, "fused_bwd.hip"), "-o", obj],
                       stderr=subprocess.DEVNULL)
 objs = [os.path.join(b.OBJDIR, s.replace(".hip", ".o")) if s != "fused_bwd.hip" else obj for s in b.SOURCES]
+objs += [os.path.join(b.OBJDIR, s.replace(".hip", ".f16.o")) for s in b.ELEM_SOURCES]          # the IEEE-half builds of the streaming units
 subprocess.check_call([b._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
 
 import torch  # noqa: E402
