@@ -149,6 +149,10 @@ int mivit_mlp_block_fwd(const void *n_in, const float *gamma_in, const float *be
  * The hidden activations are recomputed; h, dh and the pre-norm gradient never reach HBM (three row reads, one row write).
  * Deterministic (per-workgroup slabs + fixed-order reduction).  workspace: mivit_mlp_block_bwd_workspace_bytes(M). */
 size_t mivit_mlp_block_bwd_workspace_bytes(int M);
+/* Which kernel runs it: 8 (default) = hidden units split over eight waves, two per SIMD; 4 = the first kernel, four waves each
+ * owning a SIMD's whole register file (kept for A/B runs; same results up to the fp32 summation order of the column sums).
+ * Returns the previous value. */
+int mivit_mlp_block_bwd_set_waves(int waves);
 int mivit_mlp_block_bwd(const void *dy, const void *n2, const float *rstd2, const float *gamma2, const void *n1,
                         const float *gamma1, const float *beta1, const void *W1_bf16, const float *b1, const void *W2_bf16,
                         int M, int act, void *dx1, float *dW1, float *db1, float *dW2, float *db2, float *dgamma2,

@@ -119,6 +119,7 @@ SYMBOLS = {
     "mivit_attn_block_fwd": (c_int, [c_void_p] * 9 + [c_int, c_int] + [c_void_p] * 8),
     "mivit_mlp_block_fwd": (c_int, [c_void_p] * 9 + [c_int, c_int] + [c_void_p] * 8),
     "mivit_mlp_block_bwd_workspace_bytes": (c_size_t, [c_int]),
+    "mivit_mlp_block_bwd_set_waves": (c_int, [c_int]),
     "mivit_mlp_block_bwd": (c_int, [c_void_p] * 10 + [c_int, c_int] + [c_void_p] * 8 + [c_size_t, c_void_p]),
     "mivit_render_frames": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "mivit_attn_out_bwd_workspace_bytes": (c_size_t, [c_int]),

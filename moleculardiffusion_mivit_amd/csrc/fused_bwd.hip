@@ -871,6 +871,15 @@ int grid_for(int M) { return std::min(256, ceil_div(M, R)); }
 
 }  // namespace
 
+static int g_mlp_bwd_waves = [] { const char *e = getenv("MIVIT_MLP_BWD_WAVES"); return e && atoi(e) == 4 ? 4 : 8; }();
+#ifndef MIVIT_ELEM_F16
+extern "C" int mivit_mlp_block_bwd_set_waves(int waves) {
+    const int old = g_mlp_bwd_waves;
+    if (waves == 4 || waves == 8) g_mlp_bwd_waves = waves;
+    return old;
+}
+#endif
+
 size_t mlp_block_bwd_ws_bytes(int M) { return align_up((size_t)grid_for(std::max(M, 1)) * SL_TOTAL * sizeof(float), 256); }
 
 // dW1 [F,E], db1 [F], dW2 [E,F], db2 [E], dgamma2, dbeta2 [E]: overwritten
@@ -886,8 +895,9 @@ int launch_mlp_block_bwd(const void *dy, const void *n2, const float *rstd2, con
                  beta1, static_cast<const bf16 *>(W1), b1, static_cast<const bf16 *>(W2), M, static_cast<bf16 *>(dx1),
                  static_cast<float *>(ws), nullptr};
     const int grid = grid_for(M);
-    // MIVIT_MLP_BWD_WAVES = 4: the first kernel (hidden units split four ways, one wave per SIMD); 8 (default): split eight ways
-    static const int waves = [] { const char *e = getenv("MIVIT_MLP_BWD_WAVES"); return e && atoi(e) == 4 ? 4 : 8; }();
+    // MIVIT_MLP_BWD_WAVES / mivit_mlp_block_bwd_set_waves: 4 = the first kernel (hidden units split four ways, one wave per SIMD);
+    // 8 (default) = split eight ways
+    const int waves = g_mlp_bwd_waves;
     MIVIT_CHECK((int64_t)M * E * 2 < (1ll << 32), "mlp_block_bwd: %d rows exceed the 32-bit byte offsets of the row prefetch", M);
 #ifdef MIVIT_PHASE_TIMING
     static unsigned long long *dbg_buf = nullptr;

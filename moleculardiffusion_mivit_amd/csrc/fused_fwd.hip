@@ -45,6 +45,21 @@ __device__ __forceinline__ bf16x8 pack8(const f32x4 a, const f32x4 b) {
 __device__ __forceinline__ float x4_sum(float v) { return rows4_sum(v); }   // across the 4 lane groups (same lane & 15): common.h
 __device__ __forceinline__ float x4_max(float v) { return rows4_max(v); }
 __device__ __forceinline__ f32x4 ld4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
+// max of three without the canonicalising v_max_f32 x, x, x that fmaxf costs per operand in IEEE mode (216 of them per sequence
+// in the softmax's running maximum: the scores are MFMA outputs or -inf, never signalling NaNs)
+__device__ __forceinline__ float max3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// the two 8-byte halves of a packed fragment (4 + 4 elements): row stores reuse the registers the MFMA operand was packed
+// into instead of converting the same accumulators a second time
+__device__ __forceinline__ void store_halves(bf16 *p_lo, bf16 *p_hi, const bf16x8 f) {
+    struct H { uint2 lo, hi; };
+    const H h = __builtin_bit_cast(H, f);
+    *reinterpret_cast<uint2 *>(p_lo) = h.lo;
+    *reinterpret_cast<uint2 *>(p_hi) = h.hi;
+}
 __device__ __forceinline__ bf16x8 lds_frag(const bf16 *p) { return *reinterpret_cast<const bf16x8 *>(p); }
 
 // 4 consecutive bf16 -> fp32 / fp32 -> 4 consecutive bf16 (8-byte global accesses)
@@ -414,8 +429,8 @@ __global__ __launch_bounds__(NW * 64) void attn_block_fwd_kernel(const AttnFwdAr
                     else kf[rt] = pack8(pa[0][rt], pa[1][rt]);
                     if (EXTRAS && a.qkvout && rt * 16 + cq < S) {          // (q leaves unscaled, as the reference's q_proj output)
                         bf16 *dst = a.qkvout + (base + rt * 16 + cq) * (3 * E) + which * E + h * DH + 4 * g;
-                        const float us = which == 0 ? 1.f / QSCALE : 1.f;
-                        store4_bf16(dst, pa[0][rt] * us); store4_bf16(dst + 16, pa[1][rt] * us);
+                        if (which == 0) { store4_bf16(dst, pa[0][rt] * (1.f / QSCALE)); store4_bf16(dst + 16, pa[1][rt] * (1.f / QSCALE)); }
+                        else store_halves(dst, dst + 16, kf[rt]);          // k: exactly the packed operand
                     }
                 }
             }
@@ -474,7 +489,7 @@ __global__ __launch_bounds__(NW * 64) void attn_block_fwd_kernel(const AttnFwdAr
 #pragma unroll
                         for (int r = 0; r < 4; ++r) st[j][r] = (j * 16 + 4 * g + r < S) ? st[j][r] : -INFINITY;
                     }
-                    m = fmaxf(m, fmaxf(fmaxf(st[j][0], st[j][1]), fmaxf(st[j][2], st[j][3])));
+                    m = max3(max3(st[j][0], st[j][1], st[j][2]), st[j][3], m);
                 }
                 m = x4_max(m);
                 float sum = 0.f;
@@ -498,7 +513,7 @@ __global__ __launch_bounds__(NW * 64) void attn_block_fwd_kernel(const AttnFwdAr
                 cf[h][it] = pack8(ot[0], ot[1]);
                 if (it * 16 + cq < S) {
                     bf16 *dst = a.ctx + (base + it * 16 + cq) * E + h * DH + 4 * g;
-                    store4_bf16(dst, ot[0]); store4_bf16(dst + 16, ot[1]);
+                    store_halves(dst, dst + 16, cf[h][it]);
                 }
             }
         }

@@ -290,8 +290,16 @@ def _act_grad(act, u):
     return 0.5 * (1 + torch.erf(u / math.sqrt(2.0))) + u * torch.exp(-0.5 * u * u) / math.sqrt(2 * math.pi)
 
 
+@pytest.fixture(params=[8, 4])
+def mlp_bwd_waves(request):
+    from moleculardiffusion_mivit_amd import _native as N
+    old = N.lib.mivit_mlp_block_bwd_set_waves(request.param)
+    yield request.param
+    N.lib.mivit_mlp_block_bwd_set_waves(old)
+
+
 @pytest.mark.parametrize("act", [1, 3])
-def test_mlp_block_bwd_bench_scale(act):
+def test_mlp_block_bwd_bench_scale(act, mlp_bwd_waves):
     """256 persistent workgroups x 32-row tiles: 140 017 rows = 17+ tiles per workgroup, ragged last tile (reference autograd of
     models.py:72-77,104-106 written out in fp32, all rows)."""
     from moleculardiffusion_mivit_amd import ops

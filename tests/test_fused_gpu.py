@@ -159,9 +159,18 @@ def _act_grad(act, u):
     return 0.5 * (1 + torch.erf(u / math.sqrt(2.0))) + u * torch.exp(-0.5 * u * u) / math.sqrt(2 * math.pi)
 
 
+@pytest.fixture(params=[8, 4])
+def mlp_bwd_waves(request):
+    """both kernels behind mivit_mlp_block_bwd: hidden units split over 8 waves (default) / 4 waves (csrc/fused_bwd.hip)"""
+    from moleculardiffusion_mivit_amd import _native as N
+    old = N.lib.mivit_mlp_block_bwd_set_waves(request.param)
+    yield request.param
+    N.lib.mivit_mlp_block_bwd_set_waves(old)
+
+
 @pytest.mark.parametrize("M", [1, 31, 264, 1000, 8200])
 @pytest.mark.parametrize("act", [1, 2, 3])
-def test_mlp_block_bwd(M, act):
+def test_mlp_block_bwd(M, act, mlp_bwd_waves):
     """Fused feed-forward backward vs the chain rule of x2 = LN2(x1 + fc2(act(fc1 x1))), x1 = gamma1 * n1 + beta1, written
     out in fp32.  The pre-activations are taken as the kernel forms them (x1 rounded to bf16 times the bf16 weights): a ReLU unit whose pre-activation lies within bf16 rounding of zero would otherwise take the other branch in
     one of the two computations -- the function is discontinuous there."""
@@ -189,7 +198,7 @@ def test_mlp_block_bwd(M, act):
         assert _rel(out[k].float(), r) < 3e-2, k
 
 
-def test_mlp_block_bwd_is_deterministic():
+def test_mlp_block_bwd_is_deterministic(mlp_bwd_waves):
     from moleculardiffusion_mivit_amd import ops
     M = 5000
     args = [_bf(_mk((M, E), 31)).cuda(), _bf(_mk((M, E), 32)).cuda(), (1 + 0.1 * _mk((M,), 33).abs()).cuda(), (1 + 0.1 * _mk((E,), 34)).cuda(),

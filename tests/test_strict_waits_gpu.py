@@ -104,8 +104,11 @@ def _run_everything():
     args = (_bf(_randn((M, E), 21)), _bf(_randn((M, E), 22)), 1 + 0.1 * _randn((M,), 23).abs(), 1 + 0.1 * _randn((E,), 24),
             _bf(_randn((M, E), 25)), 1 + 0.1 * _randn((E,), 26), 0.1 * _randn((E,), 27), _bf(_randn((FH, E), 28, 0.1)),
             0.1 * _randn((FH,), 29), _bf(_randn((E, FH), 30, 0.1)))
-    for k, v in ops.mlp_block_bwd(*args).items():
-        out["mlp_bwd_" + k] = v
+    for waves in (8, 4):           # both kernels behind the entry (hidden units split over 8 / 4 waves)
+        old = N.lib.mivit_mlp_block_bwd_set_waves(waves)
+        for k, v in ops.mlp_block_bwd(*args).items():
+            out[f"mlp_bwd{waves}_" + k] = v
+        N.lib.mivit_mlp_block_bwd_set_waves(old)
     for k, v in ops.attn_out_bwd(args[0], args[1], args[2], args[3], args[4], _bf(_randn((E, E), 31, 0.1))).items():
         out["attn_out_bwd_" + k] = v
     # --- the whole model at the bench shape, B = 4096: forward, loss, backward ---
