@@ -45,13 +45,11 @@ __device__ __forceinline__ bf16x8 pack8(const f32x4 a, const f32x4 b) {
 __device__ __forceinline__ float x4_sum(float v) { return rows4_sum(v); }   // across the 4 lane groups (same lane & 15): common.h
 __device__ __forceinline__ float x4_max(float v) { return rows4_max(v); }
 __device__ __forceinline__ f32x4 ld4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
-// max of three without the canonicalising v_max_f32 x, x, x that fmaxf costs per operand in IEEE mode (216 of them per sequence
-// in the softmax's running maximum: the scores are MFMA outputs or -inf, never signalling NaNs)
-__device__ __forceinline__ float max3(float a, float b, float c) {
-    float r;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
+// (A hand-written v_max3_f32 for the softmax's running maximum -- fmaxf costs a canonicalising v_max_f32 x, x, x per operand in
+//  IEEE mode, 216 of them per sequence -- was tried in round 3 and REMOVED: an inline-asm VALU instruction that reads MFMA results
+//  is invisible to the compiler's hazard recogniser, no wait states were inserted behind the MFMA, and the maximum was read
+//  before the matrix pipe had written it.  The softmax is invariant to the value of the maximum up to rounding, so every
+//  tolerance test passed; the bitwise-repeatability and strict-waits tests caught it.)
 // the two 8-byte halves of a packed fragment (4 + 4 elements): row stores reuse the registers the MFMA operand was packed
 // into instead of converting the same accumulators a second time
 __device__ __forceinline__ void store_halves(bf16 *p_lo, bf16 *p_hi, const bf16x8 f) {
@@ -489,7 +487,7 @@ __global__ __launch_bounds__(NW * 64) void attn_block_fwd_kernel(const AttnFwdAr
 #pragma unroll
                         for (int r = 0; r < 4; ++r) st[j][r] = (j * 16 + 4 * g + r < S) ? st[j][r] : -INFINITY;
                     }
-                    m = max3(max3(st[j][0], st[j][1], st[j][2]), st[j][3], m);
+                    m = fmaxf(m, fmaxf(fmaxf(st[j][0], st[j][1]), fmaxf(st[j][2], st[j][3])));
                 }
                 m = x4_max(m);
                 float sum = 0.f;
