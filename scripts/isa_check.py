@@ -11,7 +11,7 @@ Run by `__graft_entry__.build()` and by tests/test_isa_invariants.py (CPU, needs
      `global_load_lds_*`), in every kernel of every source that includes stream_prims.h.
   3. The store counts that `wait_vm<N>` call sites count on as a LOWER bound: mlp_block_bwd / attn_out_bwd issue (at least) four
      8-byte row stores per tile and wave; a rowstream epilogue pass issues at least one 16-byte store.
-  4. No kernel that orders memory by hand uses scratch (spill reloads would count in vmcnt).
+  4. No inline-asm VALU instruction is the first reader of an MFMA result (no hazard wait states would separate them).
 
 Exit status 0 = all invariants hold; otherwise the violations are listed and the status is 1.
 """
@@ -178,6 +178,37 @@ def check_inflight(name, lines):
     return errs
 
 
+def check_asm_reads_mfma(src, kdict):
+    """An inline-asm VALU instruction must never be the FIRST reader of an MFMA result: the hazard recogniser cannot see inside
+    an asm string, so no wait states are inserted behind the MFMA (round 3: a hand-written v_max3_f32 in the attention block's
+    softmax read its scores before the matrix pipe had written them -- every tolerance test passed, the bitwise ones did not)."""
+    errs = []
+    for name, (lines, _) in kdict.items():
+        fresh = set()          # registers written by an MFMA and not yet read by a compiler-scheduled instruction
+        in_asm = False
+        for ln, l in enumerate(lines):
+            t = l.strip()
+            if t.startswith(";;#ASMSTART"):
+                in_asm = True
+                continue
+            if t.startswith(";;#ASMEND"):
+                in_asm = False
+                continue
+            if not is_inst(l):
+                continue
+            op = t.split()[0]
+            ops = t[len(op):].split(",")
+            if op.startswith("v_mfma"):
+                fresh -= vregs(",".join(ops[1:]))       # (reads by another MFMA are interlocked by the hardware)
+                fresh |= vregs(ops[0])
+                continue
+            reads = vregs(",".join(ops[1:])) if not op.startswith(("global_store", "ds_write", "buffer_store")) else vregs(t)
+            if in_asm and op.startswith("v_") and reads & fresh:
+                errs.append(f"{src}:{name}:{ln}: inline-asm `{t[:60]}` is the first reader of MFMA results v{sorted(reads & fresh)[:4]}")
+            fresh -= vregs(t)
+    return errs
+
+
 def check_m0_nop(src, kdict):
     errs = []
     for name, (lines, _) in kdict.items():
@@ -214,17 +245,21 @@ def main():
             errs += check_inflight(n, ke[n][0])
         errs += check_m0_nop("embed.hip", ke)
     # ---- the other users of the written-out DMA ----
+    for src in ("fused_fwd.hip", "attention_fast.hip"):
+        errs += check_asm_reads_mfma(src, kernels(device_asm(src)))
     for src in ("rowstream.hip", "gemm_dma.hip", "wgrad_dma.hip", "fused_bwd.hip"):
         kd = kernels(device_asm(src))
         errs += check_m0_nop(src, kd)
+        errs += check_asm_reads_mfma(src, kd)
         for n, (lines, meta) in kd.items():
             sb = scratch_bytes(meta)
             # (scratch traffic in these kernels is a performance matter only: extra VM operations can only make a counted wait
             #  stricter, never looser)
             if "mlp_block_bwd" in n or "attn_out_bwd" in n:
                 c = count_in_loop(lines, r"^global_store_dwordx2\b")
-                if c < 4:
-                    errs.append(f"{n}: {c} global_store_dwordx2 in the tile loop; wait_vm<4> counts on >= 4 row stores per tile")
+                need = 2 if "mlp_block_bwd8" in n else 4          # (the eight-wave kernel: one row store per row tile and wave)
+                if c < need:
+                    errs.append(f"{n}: {c} global_store_dwordx2 in the tile loop; wait_vm<{need}> counts on >= {need} row stores per tile")
             if "rowstream_kernel" in n:
                 c = count_in_loop(lines, r"^global_store_dwordx4\b")
                 m = re.search(r"rowstream_kernelILi(\d+)", n)

@@ -180,6 +180,23 @@ def test_fused_bwd(early):
         fused_bwd(n, early, row_stores=6)        # more stores than counted: still safe
 
 
+def fused_bwd8(ntiles, pieces):
+    """mlp_block_bwd8_kernel: 6 (waves 0-3) / 2 (waves 4-7) DMA pieces per tile, two row stores per wave and full tile, wait_vm<2>."""
+    w = Wave()
+    w.issue(("P", 0), pieces)
+    for t in range(ntiles):
+        w.wait(0 if t == 0 else 2)
+        w.need(("P", t))
+        w.issue(("P", t + 1), pieces)
+        w.issue(("st", t), 2)
+
+
+@pytest.mark.parametrize("pieces", [6, 2])
+def test_fused_bwd8(pieces):
+    for n in range(1, 7):
+        fused_bwd8(n, pieces)
+
+
 # ---------------------------------------------------------------- gemm_pers_kernel --------------------------------------
 def gemm_pers(ntile, nst, D, per_stage, epi_ops=5):
     w = Wave()
