@@ -238,8 +238,9 @@ constexpr int MLP_VEC = E * 5 + F;               // gin, bin, b2, gout, bout [E]
 constexpr int MLP_LDS = MLP_LDS_W1 + MLP_LDS_W2 + MLP_VEC * 4;
 static_assert(MLP_LDS <= 160 * 1024, "LDS budget");
 
-template <int NR, int ACT, bool EXTRAS>      // EXTRAS: the optional h / pre-activation outputs are compiled in
-__global__ __launch_bounds__(NTHREADS) void mlp_block_fwd_kernel(const MlpFwdArgs a) {
+template <int NR, int ACT, bool EXTRAS, int NWV = NWAVES>      // EXTRAS: the optional h / pre-activation outputs are compiled in; NWV waves per workgroup
+__global__ __launch_bounds__(NWV * 64) void mlp_block_fwd_kernel(const MlpFwdArgs a) {
+    constexpr int NTH = NWV * 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16 *W1i = reinterpret_cast<bf16 *>(smem);
     bf16 *W2i = reinterpret_cast<bf16 *>(smem + MLP_LDS_W1);
@@ -247,19 +248,19 @@ __global__ __launch_bounds__(NTHREADS) void mlp_block_fwd_kernel(const MlpFwdArg
     float *gin = vec, *bin = vec + E, *b2 = vec + 2 * E, *gout = vec + 3 * E, *bout = vec + 4 * E, *b1 = vec + 5 * E;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, cq = lane & 15;
     const bool affine_in = a.gin != nullptr;
-    stage_vec(gin, a.gin, E, 1.f, tid); stage_vec(bin, a.bin, E, 0.f, tid);
-    stage_vec(gout, a.gout, E, 1.f, tid); stage_vec(bout, a.bout, E, 0.f, tid);
+    stage_vec(gin, a.gin, E, 1.f, tid, NTH); stage_vec(bin, a.bin, E, 0.f, tid, NTH);
+    stage_vec(gout, a.gout, E, 1.f, tid, NTH); stage_vec(bout, a.bout, E, 0.f, tid, NTH);
     __syncthreads();
-    if (affine_in) stage_folded<E, LDE>(W1i, a.W1, F, gin, tid); else stage_natural<E, LDE>(W1i, a.W1, F, tid);
-    stage_permuted<F, LDF>(W2i, a.W2, E, tid);
-    fold_bias<E>(b1, a.b1, a.W1, F, bin, affine_in, tid);
-    for (int i = tid; i < E; i += NTHREADS) b2[i] = a.b2[i] + bin[i];          // fc2 bias + the residual's beta
+    if (affine_in) stage_folded<E, LDE>(W1i, a.W1, F, gin, tid, NTH); else stage_natural<E, LDE>(W1i, a.W1, F, tid, NTH);
+    stage_permuted<F, LDF>(W2i, a.W2, E, tid, NTH);
+    fold_bias<E>(b1, a.b1, a.W1, F, bin, affine_in, tid, NTH);
+    for (int i = tid; i < E; i += NTH) b2[i] = a.b2[i] + bin[i];          // fc2 bias + the residual's beta
     __syncthreads();
     const int ntiles = (a.M + 16 * NR - 1) / (16 * NR);
     const bf16x8 id0 = idfrag(0, cq, g), id1 = idfrag(1, cq, g);
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    int tile = blockIdx.x * NWAVES + wave;
-    const int tstride = gridDim.x * NWAVES;
+    int tile = blockIdx.x * NWV + wave;
+    const int tstride = gridDim.x * NWV;
     uint4 nx[NR][4];
     if (tile < ntiles) {
 #pragma unroll
@@ -579,6 +580,9 @@ int launch_mlp_block_fwd(const void *nin, const float *gin, const float *bin, co
     a.gout = gout; a.bout = bout; a.M = M; a.act = act;
     a.o = LnOut{static_cast<bf16 *>(nout), rstd, static_cast<bf16 *>(xout), static_cast<bf16 *>(zout), mean};
     a.hout = static_cast<bf16 *>(hout); a.uout = static_cast<bf16 *>(uout);
+    // 32 rows per wave, 8 waves per workgroup (two per SIMD, 230 registers).  Round 3 measured the other end of the trade: 16 rows
+    // per wave with 12 waves (161 registers, three per SIMD; every weight fragment then feeds one MFMA instead of two, twice the
+    // LDS reads per row): 99.4 against 101.5 us per layer -- no difference; with 16 waves (128 registers) it spills 31: 126.7 us.
     constexpr int NR = 2;
     const int ntiles = ceil_div(M, 16 * NR);
     const int grid = std::min(256, ceil_div(ntiles, NWAVES));
