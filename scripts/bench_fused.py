@@ -38,11 +38,26 @@ def timeit(fn, n=20):
 
 
 U = M * E * 2
+import ctypes
+from moleculardiffusion_mivit_amd import _native as N
+_ab = dict(ctx=torch.empty(B, S, E, dtype=torch.bfloat16, device=dev), n=torch.empty(B, S, E, dtype=torch.bfloat16, device=dev),
+           rstd=torch.empty(B, S, device=dev), qkv=torch.empty(B, S, 3 * E, dtype=torch.bfloat16, device=dev))
+_p = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+_bq, _bo = bqkv.float(), bo.float()
+
+
+def attn_train():       # what the engine launches in training: ctx, n, rstd + the q|k|v store, nothing else
+    N.check(N.lib.mivit_attn_block_fwd(_p(n_in), _p(gi), _p(bi), _p(Wqkv), _p(_bq), _p(Wo), _p(_bo), _p(gi), _p(bi), B, S, _p(_ab["ctx"]),
+                                       _p(_ab["n"]), _p(_ab["rstd"]), None, None, None, _p(_ab["qkv"]),
+                                       ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "attn_block_fwd")
+
+
 cases = {
     "attn_block_fwd lean": (lambda: ops.attn_block_fwd(n_in, gi, bi, Wqkv, bqkv, Wo, bo, gi, bi), 3 * U,
                             M * (8 * E * E + 4 * S * E)),
     "attn_block_fwd +legacy outputs": (lambda: ops.attn_block_fwd(n_in, gi, bi, Wqkv, bqkv, Wo, bo, gi, bi, extras=True), 8 * U,
                                        M * (8 * E * E + 4 * S * E)),
+    "attn_block_fwd + q|k|v (training)": (lambda: attn_train(), 6 * U, M * (8 * E * E + 4 * S * E)),
     "mlp_block_fwd lean": (lambda: ops.mlp_block_fwd(n_in.view(M, E), gi, bi, W1, b1, W2, b2, gi, bi), 2 * U, M * 4 * E * FH),
     "mlp_block_fwd +legacy outputs": (lambda: ops.mlp_block_fwd(n_in.view(M, E), gi, bi, W1, b1, W2, b2, gi, bi, extras=True),
                                       8 * U, M * 4 * E * FH),
