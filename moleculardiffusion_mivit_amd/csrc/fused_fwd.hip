@@ -126,6 +126,22 @@ __device__ __forceinline__ void load_raw(uint4 (&raw)[4], const bf16 *nin, int64
     }
 }
 __device__ __forceinline__ bf16x8 as_frag(const uint4 &u) { return __builtin_bit_cast(bf16x8, u); }
+// The same four loads WRITTEN OUT (inline asm, immediate offsets): invisible to the compiler's waitcnt pass, which therefore
+// cannot put `vmcnt(0)` -- a wait for every row store issued since -- in front of their first use.  The caller orders them with
+// an explicit counted wait (attn_block_fwd: prefetch at the top of an iteration, wait at the top of the next).  The row is
+// clamped by the caller (always a valid address); rows that do not exist are zeroed after the wait (frag_if).
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void load_raw_asm(u32x4_t (&raw)[4], const bf16 *rowptr) {
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(raw[0]) : "v"(rowptr) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, off offset:64" : "=v"(raw[1]) : "v"(rowptr) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, off offset:128" : "=v"(raw[2]) : "v"(rowptr) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, off offset:192" : "=v"(raw[3]) : "v"(rowptr) : "memory");
+}
+__device__ __forceinline__ bf16x8 frag_if(const u32x4_t &u, bool valid) {
+    const unsigned m = valid ? 0xffffffffu : 0u;
+    const u32x4_t v = {u[0] & m, u[1] & m, u[2] & m, u[3] & m};
+    return __builtin_bit_cast(bf16x8, v);
+}
 // The producing LayerNorm's affine is FOLDED into the consuming weights while they are staged (once per workgroup):
 //   (gamma * n + beta) W^T + b  =  n (W * gamma)^T + (b + W beta)
 // so the projections run on the raw normalised rows exactly as loaded -- no per-element affine, no copy.
@@ -387,18 +403,58 @@ __global__ __launch_bounds__(NW * 64) void attn_block_fwd_kernel(const AttnFwdAr
     const bf16x8 id0 = idfrag(0, cq, g), id1 = idfrag(1, cq, g);
     const int bstride = gridDim.x * NW;
     int b = blockIdx.x * NW + wave;
-    uint4 nx[NT][4];
-    if (b < a.B) {
+    // Next sequence's rows.  One or two row tiles (ASM_PF): requested at the TOP of an iteration -- before any of the iteration's
+    // row stores -- into registers the compiler never sees a load for, and waited for at the top of the next one.
+    // VM program order of a wave:   L(b) | stores of sequence b-stride ... wait | L(b+stride) | stores of sequence b | wait | ...
+    // i.e. younger than L(b) at its wait are exactly the row stores of the iteration before: at least NSTORE instructions (the
+    // launcher picks NT = ceil(S / 16): every row tile has a valid row, so every (tile, head, output) store is issued; optional
+    // outputs only add more).  vmcnt counts to 63: with NSTORE >= 63 the wait is vmcnt(63) -- the 63 youngest stores stay in
+    // flight, L(b) is older than all of them.
+    // (Requested after the attention phase with ordinary loads -- round 2, and still the form for three and four row tiles --
+    // the compiler puts vmcnt(0) in front of their first use: the row stores sit under per-row validity branches it cannot
+    // count.  Every iteration then drains ~50 (inference) to ~125 (training: + q|k|v) store acknowledgements: 237 -> 301 us per
+    // layer for the q|k|v store alone.  With three or four tiles in flight the allocator parks written-out destinations in
+    // accumulation registers right behind the asm statement -- a copy of registers the memory system has not written yet;
+    // scripts/isa_check.py::check_asm_load_window is the guard that found it -- and accumulation-register destinations
+    // ("=a") crash this compiler's AGPR rewrite pass.)
+    constexpr bool ASM_PF = NT <= 2;
+    constexpr int NBASE = H * NT * 2 + 8 * NT + NT;                    // ctx (two halves per head and tile) | n | rstd
+    constexpr int NSTORE = NBASE + (EXTRAS ? H * NT * 6 : 0);          // + q, k (two halves each), v (two feature tiles)
+    constexpr int WAITB = NBASE < 63 ? NBASE : 63, WAITN = NSTORE < 63 ? NSTORE : 63;
+    const bool qkv_stored = EXTRAS && a.qkvout != nullptr;             // (the launcher picks EXTRAS exactly then)
+    u32x4_t nx[NT][4];
+    uint4 nxc[NT][4];
+    auto request = [&](int seq) {
 #pragma unroll
-        for (int rt = 0; rt < NT; ++rt) load_raw(nx[rt], a.nin, (int64_t)b * S + rt * 16 + cq, rt * 16 + cq < S, g);
-    }
+        for (int rt = 0; rt < NT; ++rt) {
+            if constexpr (ASM_PF) load_raw_asm(nx[rt], a.nin + ((int64_t)seq * S + min(rt * 16 + cq, S - 1)) * E + 8 * g);
+            else load_raw(nxc[rt], a.nin, (int64_t)seq * S + rt * 16 + cq, rt * 16 + cq < S, g);
+        }
+    };
+    if (b < a.B) request(b);
+    bool first = true;
     for (; b < a.B; b += bstride) {
         const int64_t base = (int64_t)b * S;
         bf16x8 xf[NT][4];
+        if constexpr (ASM_PF) {
+            if (first) wait_vm<0>();
+            else if (EXTRAS && !qkv_stored) wait_vm<WAITB>();
+            else wait_vm<WAITN>();
+            first = false;
 #pragma unroll
-        for (int rt = 0; rt < NT; ++rt)
+            for (int rt = 0; rt < NT; ++rt) {
+                asm volatile("" : "+v"(nx[rt][0]), "+v"(nx[rt][1]), "+v"(nx[rt][2]), "+v"(nx[rt][3]));      // (ordered after the wait)
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) xf[rt][ks] = as_frag(nx[rt][ks]);
+                for (int ks = 0; ks < 4; ++ks) xf[rt][ks] = frag_if(nx[rt][ks], rt * 16 + cq < S);
+            }
+            asm volatile("" ::: "memory");
+            request(min(b + bstride, a.B - 1));      // (a clamped re-read on the last round: never consumed, drained before the kernel ends)
+        } else {
+#pragma unroll
+            for (int rt = 0; rt < NT; ++rt)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) xf[rt][ks] = as_frag(nxc[rt][ks]);
+        }
         bf16x8 cf[H][NT];                            // context, as the column operand of the out-projection
 #pragma unroll
         for (int h = 0; h < H; ++h) {
@@ -516,6 +572,7 @@ __global__ __launch_bounds__(NW * 64) void attn_block_fwd_kernel(const AttnFwdAr
                 }
             }
         }
+        if constexpr (!ASM_PF) request(min(b + bstride, a.B - 1));      // in flight under the out-projection and the epilogue
         __builtin_amdgcn_sched_barrier(0);
         // ---- out-projection (+ bias) + residual (identity product on the input fragments), LayerNorm ----
         f32x4 oa[8][NT];
@@ -526,11 +583,6 @@ __global__ __launch_bounds__(NW * 64) void attn_block_fwd_kernel(const AttnFwdAr
             for (int rt = 0; rt < NT; ++rt) oa[nt][rt] = bv + gv * mma((nt & 1) ? id1 : id0, xf[rt][nt >> 1], zero);
         }
         __builtin_amdgcn_sched_barrier(0);
-        {                                        // next sequence's rows: in flight under the out-projection and the epilogue
-            const int nb = min(b + bstride, a.B - 1);                 // (unconditional, after the last use of this sequence's
-#pragma unroll                                                       //  fragments: the same registers)
-            for (int rt = 0; rt < NT; ++rt) load_raw(nx[rt], a.nin, (int64_t)nb * S + rt * 16 + cq, rt * 16 + cq < S, g);
-        }
 #pragma unroll
         for (int h = 0; h < H; ++h) {
 #pragma unroll
@@ -549,6 +601,7 @@ __global__ __launch_bounds__(NW * 64) void attn_block_fwd_kernel(const AttnFwdAr
             ln_store(z, base + rt * 16 + cq, rt * 16 + cq < S, gout, bout, a.o, g);
         }
     }
+    if constexpr (ASM_PF) wait_vm<0>();            // the clamped request of the last round
 }
 
 bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
