@@ -120,6 +120,7 @@ int mivit_wgrad_bf16(const void *dy, int64_t lddy, const void *x, int64_t ldx, i
 
 /* Fused forward of the two halves of the post-norm encoder layer (helpers/models.py:97-108), bf16 mode, model width
  * E = 128, feed-forward width F = 256, 4 heads of 32 (the PSFNoise 32x64x64 configuration); csrc/fused_fwd.hip.
+ * (The reference's shipped width E = 64 / F = 128 / 4 heads of 16: the ..._w64 entries further down.)
  * LayerNorm outputs travel NORMALISED: n = (z - mean) * rstd (bf16) with rstd per row (fp32); a consumer applies the
  * producing LayerNorm's affine while loading, x = gamma_in * n_in + beta_in (gamma_in = beta_in = NULL: n_in is x).
  *   attn_block_fwd: z = x + out_proj(softmax(q k^T / sqrt(32)) v), q|k|v = x Wqkv^T + bqkv   (models.py:33-59,100-102)
@@ -177,6 +178,28 @@ size_t mivit_attn_out_bwd_workspace_bytes(int M);
 int mivit_attn_out_bwd(const void *dy, const void *n1, const float *rstd1, const float *gamma1, const void *ctx,
                        const void *Wo_bf16, int M, void *dz1, void *dctx, float *dWo, float *dbo, float *dgamma1,
                        float *dbeta1, void *workspace, size_t workspace_bytes, void *stream);
+
+/* The same five operators for the reference's shipped layer width: E = 64, F = 128, 4 heads of 16
+ * (Experiments/Framerate/trainSettingsFramerate.py:42-47, Experiments/ImagesFeatures/...:112-188): csrc/fused_fwd.hip and
+ * csrc/fused_bwd.hip compiled a second time with -DMIVIT_WIDTH64.  Same arguments, layouts and optional outputs. */
+int mivit_fused_layer_supported_w64(int dtype, int embed_dim, int hidden_dim, int num_heads, int tokens);
+int mivit_attn_block_fwd_w64(const void *n_in, const float *gamma_in, const float *beta_in, const void *Wqkv_bf16,
+                             const float *bqkv, const void *Wo_bf16, const float *bo, const float *gamma_out,
+                             const float *beta_out, int B, int S, void *ctx, void *n_out, float *rstd, void *x_out,
+                             void *z_out, float *mean, void *qkv_out, void *stream);
+int mivit_mlp_block_fwd_w64(const void *n_in, const float *gamma_in, const float *beta_in, const void *W1_bf16,
+                            const float *b1, const void *W2_bf16, const float *b2, const float *gamma_out,
+                            const float *beta_out, int M, int act, void *n_out, float *rstd, void *x_out, void *z_out,
+                            float *mean, void *h_out, void *u_out, void *stream);
+size_t mivit_mlp_block_bwd_workspace_bytes_w64(int M);
+int mivit_mlp_block_bwd_w64(const void *dy, const void *n2, const float *rstd2, const float *gamma2, const void *n1,
+                            const float *gamma1, const float *beta1, const void *W1_bf16, const float *b1, const void *W2_bf16,
+                            int M, int act, void *dx1, float *dW1, float *db1, float *dW2, float *db2, float *dgamma2,
+                            float *dbeta2, void *workspace, size_t workspace_bytes, void *stream);
+size_t mivit_attn_out_bwd_workspace_bytes_w64(int M);
+int mivit_attn_out_bwd_w64(const void *dy, const void *n1, const float *rstd1, const float *gamma1, const void *ctx,
+                           const void *Wo_bf16, int M, void *dz1, void *dctx, float *dWo, float *dbo, float *dgamma1,
+                           float *dbeta1, void *workspace, size_t workspace_bytes, void *stream);
 
 /* DeepResNetEmbedding in inference mode (helpers/models.py:230-257; ResidualBlock :202-228): conv3x3(1->32)+BN+ReLU,
  * ResidualBlock(32->64), ResidualBlock(64->128), global average pool, Linear(128->E), fused in one kernel that keeps F

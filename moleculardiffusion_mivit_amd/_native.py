@@ -124,6 +124,13 @@ SYMBOLS = {
     "mivit_render_frames": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "mivit_attn_out_bwd_workspace_bytes": (c_size_t, [c_int]),
     "mivit_attn_out_bwd": (c_int, [c_void_p] * 6 + [c_int] + [c_void_p] * 7 + [c_size_t, c_void_p]),
+    "mivit_fused_layer_supported_w64": (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    "mivit_attn_block_fwd_w64": (c_int, [c_void_p] * 9 + [c_int, c_int] + [c_void_p] * 8),
+    "mivit_mlp_block_fwd_w64": (c_int, [c_void_p] * 9 + [c_int, c_int] + [c_void_p] * 8),
+    "mivit_mlp_block_bwd_workspace_bytes_w64": (c_size_t, [c_int]),
+    "mivit_mlp_block_bwd_w64": (c_int, [c_void_p] * 10 + [c_int, c_int] + [c_void_p] * 8 + [c_size_t, c_void_p]),
+    "mivit_attn_out_bwd_workspace_bytes_w64": (c_size_t, [c_int]),
+    "mivit_attn_out_bwd_w64": (c_int, [c_void_p] * 6 + [c_int] + [c_void_p] * 7 + [c_size_t, c_void_p]),
     "mivit_profile_enable": (c_int, [ctypes.c_uint64]),
     "mivit_profile_collect": (c_int, [c_int, POINTER(ctypes.c_double), POINTER(c_int)]),
     "mivit_profile_tag_name": (c_char_p, [c_int]),

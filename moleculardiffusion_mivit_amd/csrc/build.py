@@ -17,6 +17,9 @@ HEADERS = [os.path.join(HERE, "common.h"), os.path.join(HERE, "stream_prims.h"),
 # -DMIVIT_ELEM_F16 (IEEE half instead of bf16, every external suffixed _f16) and both objects go into the library
 ELEM_SOURCES = ["rowstream.hip", "wavestream.hip", "wgrad_dma.hip", "wgrad_small.hip", "attention_fast.hip", "embed.hip",
                 "fused_fwd.hip", "fused_bwd.hip"]
+# the fused encoder-layer blocks are in addition compiled per layer width (elem.h): -DMIVIT_WIDTH64 = the reference's shipped
+# E = 64 / F = 128 / head dim 16, externals suffixed _w64 (and _w64_f16)
+WIDTH_SOURCES = ["fused_fwd.hip", "fused_bwd.hip"]
 LIB = os.path.join(PKG, "libmivit_hip.so")
 # the same library with every counted s_waitcnt vmcnt(N) of stream_prims.h::wait_vm turned into vmcnt(0) (-DMIVIT_STRICT_WAITS).
 # TEST INFRASTRUCTURE ONLY: tests/test_strict_waits_gpu.py runs the bench-scale shapes through both and requires bitwise-equal
@@ -61,6 +64,9 @@ def build(force=False, verbose=True, strict=True):
             variants.append((".f16.o", ["-DMIVIT_ELEM_F16"]))
             if strict and src in WAIT_SOURCES:
                 variants.append((".f16.strict.o", ["-DMIVIT_ELEM_F16", "-DMIVIT_STRICT_WAITS"]))
+        if src in WIDTH_SOURCES:
+            for ext, extra in list(variants) + [(".o", [])]:
+                variants.append((".w64" + ext, ["-DMIVIT_WIDTH64"] + extra))
         for ext, extra in variants:
             o = os.path.join(OBJDIR, src.replace(".hip", ext))
             if force or _stale(o, [s, os.path.abspath(__file__)] + HEADERS):
@@ -81,8 +87,11 @@ def build(force=False, verbose=True, strict=True):
         list(ex.map(compile_one, jobs))
     objs = [os.path.join(OBJDIR, s.replace(".hip", ".o")) for s in SOURCES]
     objs += [os.path.join(OBJDIR, s.replace(".hip", ".f16.o")) for s in ELEM_SOURCES]
+    objs += [os.path.join(OBJDIR, s.replace(".hip", ext)) for s in WIDTH_SOURCES for ext in (".w64.o", ".w64.f16.o")]
     sobjs = [os.path.join(OBJDIR, s.replace(".hip", ".strict.o" if s in WAIT_SOURCES else ".o")) for s in SOURCES]
     sobjs += [os.path.join(OBJDIR, s.replace(".hip", ".f16.strict.o" if s in WAIT_SOURCES else ".f16.o")) for s in ELEM_SOURCES]
+    sobjs += [os.path.join(OBJDIR, s.replace(".hip", ext)) for s in WIDTH_SOURCES
+              for ext in ((".w64.strict.o", ".w64.f16.strict.o") if strict and s in WAIT_SOURCES else (".w64.o", ".w64.f16.o"))]
     for lib, ob in ((LIB, objs), (LIB_STRICT, sobjs)) if strict else ((LIB, objs),):
         if force or jobs or _stale(lib, ob):
             cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + ob

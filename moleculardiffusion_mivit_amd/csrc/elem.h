@@ -35,13 +35,6 @@
 #define launch_embed_fwd_dma launch_embed_fwd_dma_f16
 #define embed_wgrad_dma_ws_bytes embed_wgrad_dma_ws_bytes_f16
 #define launch_embed_wgrad_dma launch_embed_wgrad_dma_f16
-#define fused_layer_supported fused_layer_supported_f16
-#define launch_attn_block_fwd launch_attn_block_fwd_f16
-#define launch_mlp_block_fwd launch_mlp_block_fwd_f16
-#define mlp_block_bwd_ws_bytes mlp_block_bwd_ws_bytes_f16
-#define launch_mlp_block_bwd launch_mlp_block_bwd_f16
-#define attn_out_bwd_ws_bytes attn_out_bwd_ws_bytes_f16
-#define launch_attn_out_bwd launch_attn_out_bwd_f16
 // the 16-deep MFMA of attention_fast.hip's backward (operands travel as 4 x 16-bit lanes)
 #define ELEM_MFMA_16x16x16(a, b, c)                                                                                       \
     __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(__attribute__((ext_vector_type(4))) _Float16, a),            \
@@ -54,4 +47,34 @@ __device__ __forceinline__ float elem_hi(uint32_t w) { return (float)__builtin_b
 #define ELEM_MFMA_16x16x16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0)
 __device__ __forceinline__ float elem_lo(uint32_t w) { return __uint_as_float(w << 16); }            // bf16 = the high half of an fp32
 __device__ __forceinline__ float elem_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+#endif
+
+// The fused encoder-layer blocks (fused_fwd.hip / fused_bwd.hip) are in addition compiled per LAYER WIDTH: as is for
+// E = 128 / F = 256 / head dim 32, and with -DMIVIT_WIDTH64 for the reference's shipped E = 64 / F = 128 / head dim 16
+// (Experiments/Framerate/trainSettingsFramerate.py:42-47).  Their externals carry _w64 and / or _f16; the bf16 builds also
+// export the operator-level C entry points (mivit_attn_block_fwd ..., include/mivit_hip.h), the width-64 one as ..._w64.
+#if defined(MIVIT_WIDTH64) && defined(MIVIT_ELEM_F16)
+#define MIVIT_FUSED_NAME(x) x##_w64_f16
+#elif defined(MIVIT_WIDTH64)
+#define MIVIT_FUSED_NAME(x) x##_w64
+#elif defined(MIVIT_ELEM_F16)
+#define MIVIT_FUSED_NAME(x) x##_f16
+#endif
+#ifdef MIVIT_FUSED_NAME
+#define fused_layer_supported MIVIT_FUSED_NAME(fused_layer_supported)
+#define launch_attn_block_fwd MIVIT_FUSED_NAME(launch_attn_block_fwd)
+#define launch_mlp_block_fwd MIVIT_FUSED_NAME(launch_mlp_block_fwd)
+#define mlp_block_bwd_ws_bytes MIVIT_FUSED_NAME(mlp_block_bwd_ws_bytes)
+#define launch_mlp_block_bwd MIVIT_FUSED_NAME(launch_mlp_block_bwd)
+#define attn_out_bwd_ws_bytes MIVIT_FUSED_NAME(attn_out_bwd_ws_bytes)
+#define launch_attn_out_bwd MIVIT_FUSED_NAME(launch_attn_out_bwd)
+#endif
+#if defined(MIVIT_WIDTH64) && !defined(MIVIT_ELEM_F16)
+#define mivit_fused_layer_supported mivit_fused_layer_supported_w64
+#define mivit_mlp_block_fwd mivit_mlp_block_fwd_w64
+#define mivit_attn_block_fwd mivit_attn_block_fwd_w64
+#define mivit_mlp_block_bwd_workspace_bytes mivit_mlp_block_bwd_workspace_bytes_w64
+#define mivit_mlp_block_bwd mivit_mlp_block_bwd_w64
+#define mivit_attn_out_bwd_workspace_bytes mivit_attn_out_bwd_workspace_bytes_w64
+#define mivit_attn_out_bwd mivit_attn_out_bwd_w64
 #endif

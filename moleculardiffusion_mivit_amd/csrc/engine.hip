@@ -10,43 +10,31 @@
 #include <string>
 #include <vector>
 
-// fused encoder-layer blocks (fused_fwd.hip)
-bool fused_layer_supported(int dtype, int E, int F, int H, int S);
-int launch_attn_block_fwd(const void *nin, const float *gin, const float *bin, const void *Wqkv, const float *bqkv,
-                          const void *Wo, const float *bo, const float *gout, const float *bout, int B, int S, void *ctx,
-                          void *nout, float *rstd, void *xout, void *zout, float *mean, void *qkvout, hipStream_t s);
-int launch_mlp_block_fwd(const void *nin, const float *gin, const float *bin, const void *W1, const float *b1, const void *W2,
-                         const float *b2, const float *gout, const float *bout, int M, int act, void *nout, float *rstd,
-                         void *xout, void *zout, float *mean, void *hout, void *uout, hipStream_t s);
-
-size_t mlp_block_bwd_ws_bytes(int M);
-size_t attn_out_bwd_ws_bytes(int M);
-int launch_attn_out_bwd(const void *dy, const void *n1, const float *rstd1, const float *gamma1, const void *ctx, const void *Wo, int M,
-                        void *dz1, void *dctx, float *dWo, float *dbo, float *dgamma1, float *dbeta1, void *ws, size_t ws_bytes,
-                        hipStream_t s);
-int launch_mlp_block_bwd(const void *dy, const void *n2, const float *rstd2, const float *gamma2, const void *n1,
-                         const float *gamma1, const float *beta1, const void *W1, const float *b1, const void *W2, int M, int act,
-                         void *dx1, float *dW1, float *db1, float *dW2, float *db2, float *dgamma2, float *dbeta2, void *ws,
-                         size_t ws_bytes, hipStream_t s);
-
-// ... and the same two units compiled with -DMIVIT_ELEM_F16 (elem.h)
-bool fused_layer_supported_f16(int dtype, int E, int F, int H, int S);
-int launch_attn_block_fwd_f16(const void *nin, const float *gin, const float *bin, const void *Wqkv, const float *bqkv,
-                          const void *Wo, const float *bo, const float *gout, const float *bout, int B, int S, void *ctx,
-                          void *nout, float *rstd, void *xout, void *zout, float *mean, void *qkvout, hipStream_t s);
-int launch_mlp_block_fwd_f16(const void *nin, const float *gin, const float *bin, const void *W1, const float *b1, const void *W2,
-                         const float *b2, const float *gout, const float *bout, int M, int act, void *nout, float *rstd,
-                         void *xout, void *zout, float *mean, void *hout, void *uout, hipStream_t s);
-
-size_t mlp_block_bwd_ws_bytes_f16(int M);
-size_t attn_out_bwd_ws_bytes_f16(int M);
-int launch_attn_out_bwd_f16(const void *dy, const void *n1, const float *rstd1, const float *gamma1, const void *ctx, const void *Wo, int M,
-                        void *dz1, void *dctx, float *dWo, float *dbo, float *dgamma1, float *dbeta1, void *ws, size_t ws_bytes,
-                        hipStream_t s);
-int launch_mlp_block_bwd_f16(const void *dy, const void *n2, const float *rstd2, const float *gamma2, const void *n1,
-                         const float *gamma1, const float *beta1, const void *W1, const float *b1, const void *W2, int M, int act,
-                         void *dx1, float *dW1, float *db1, float *dW2, float *db2, float *dgamma2, float *dbeta2, void *ws,
-                         size_t ws_bytes, hipStream_t s);
+// fused encoder-layer blocks (fused_fwd.hip / fused_bwd.hip): one set of externals per element type and layer width (elem.h:
+// the two units are compiled as is, with -DMIVIT_ELEM_F16, with -DMIVIT_WIDTH64 and with both)
+#define MIVIT_FUSED_DECLS(SFX)                                                                                                     \
+    bool fused_layer_supported##SFX(int dtype, int E, int F, int H, int S);                                                        \
+    int launch_attn_block_fwd##SFX(const void *nin, const float *gin, const float *bin, const void *Wqkv, const float *bqkv,       \
+                                   const void *Wo, const float *bo, const float *gout, const float *bout, int B, int S, void *ctx, \
+                                   void *nout, float *rstd, void *xout, void *zout, float *mean, void *qkvout, hipStream_t s);     \
+    int launch_mlp_block_fwd##SFX(const void *nin, const float *gin, const float *bin, const void *W1, const float *b1,            \
+                                  const void *W2, const float *b2, const float *gout, const float *bout, int M, int act,           \
+                                  void *nout, float *rstd, void *xout, void *zout, float *mean, void *hout, void *uout,            \
+                                  hipStream_t s);                                                                                  \
+    size_t mlp_block_bwd_ws_bytes##SFX(int M);                                                                                     \
+    size_t attn_out_bwd_ws_bytes##SFX(int M);                                                                                      \
+    int launch_attn_out_bwd##SFX(const void *dy, const void *n1, const float *rstd1, const float *gamma1, const void *ctx,         \
+                                 const void *Wo, int M, void *dz1, void *dctx, float *dWo, float *dbo, float *dgamma1,             \
+                                 float *dbeta1, void *ws, size_t ws_bytes, hipStream_t s);                                         \
+    int launch_mlp_block_bwd##SFX(const void *dy, const void *n2, const float *rstd2, const float *gamma2, const void *n1,         \
+                                  const float *gamma1, const float *beta1, const void *W1, const float *b1, const void *W2, int M, \
+                                  int act, void *dx1, float *dW1, float *db1, float *dW2, float *db2, float *dgamma2,              \
+                                  float *dbeta2, void *ws, size_t ws_bytes, hipStream_t s);
+MIVIT_FUSED_DECLS()
+MIVIT_FUSED_DECLS(_f16)
+MIVIT_FUSED_DECLS(_w64)
+MIVIT_FUSED_DECLS(_w64_f16)
+#undef MIVIT_FUSED_DECLS
 
 struct FusedOps {
     decltype(&fused_layer_supported) ok;
@@ -54,16 +42,25 @@ struct FusedOps {
     decltype(&launch_mlp_block_fwd) mlp_fwd;
     decltype(&launch_mlp_block_bwd) mlp_bwd;
     decltype(&launch_attn_out_bwd) attn_out_bwd;
+    decltype(&mlp_block_bwd_ws_bytes) mlp_bwd_ws;
+    decltype(&attn_out_bwd_ws_bytes) attn_out_bwd_ws;
 };
-static const FusedOps kFusedBf16 = {fused_layer_supported, launch_attn_block_fwd, launch_mlp_block_fwd, launch_mlp_block_bwd, launch_attn_out_bwd};
-static const FusedOps kFusedF16 = {fused_layer_supported_f16, launch_attn_block_fwd_f16, launch_mlp_block_fwd_f16, launch_mlp_block_bwd_f16,
-                                   launch_attn_out_bwd_f16};
-static const FusedOps *fused_ops(int dtype) {
-    static const bool f16_off = getenv("MIVIT_NO_F16_STREAM") != nullptr;
-    return dtype == MIVIT_BF16 ? &kFusedBf16 : (dtype == MIVIT_F16 && !f16_off ? &kFusedF16 : nullptr);
+#define MIVIT_FUSED_TABLE(SFX)                                                                                                \
+    {fused_layer_supported##SFX, launch_attn_block_fwd##SFX, launch_mlp_block_fwd##SFX, launch_mlp_block_bwd##SFX,            \
+     launch_attn_out_bwd##SFX, mlp_block_bwd_ws_bytes##SFX, attn_out_bwd_ws_bytes##SFX}
+static const FusedOps kFusedBf16 = MIVIT_FUSED_TABLE(), kFusedF16 = MIVIT_FUSED_TABLE(_f16), kFusedBf16W64 = MIVIT_FUSED_TABLE(_w64),
+                      kFusedF16W64 = MIVIT_FUSED_TABLE(_w64_f16);
+#undef MIVIT_FUSED_TABLE
+// (MIVIT_NO_FUSED_W64: the reference's shipped width back on the per-operator streaming path -- A/B measurements)
+static const FusedOps *fused_ops(int dtype, int E) {
+    static const bool f16_off = getenv("MIVIT_NO_F16_STREAM") != nullptr, w64_off = getenv("MIVIT_NO_FUSED_W64") != nullptr;
+    if (E == 64 && w64_off) return nullptr;
+    if (dtype == MIVIT_BF16) return E == 64 ? &kFusedBf16W64 : &kFusedBf16;
+    if (dtype == MIVIT_F16 && !f16_off) return E == 64 ? &kFusedF16W64 : &kFusedF16;
+    return nullptr;
 }
 static bool fused_ok(int dtype, int E, int F, int H, int S) {
-    const FusedOps *f = fused_ops(dtype);
+    const FusedOps *f = fused_ops(dtype, E);
     return f && f->ok(dtype, E, F, H, S);
 }
 
@@ -179,7 +176,7 @@ Ws make_ws(const mivit_plan *p, int B, int T, bool bwd) {
             if (b > wg) wg = b;
         };
         mx((int)M, 3 * E, E); mx((int)M, E, E); mx((int)M, F, E); mx((int)M, E, F);
-        if (fused) wg = std::max(std::max(wg, mlp_block_bwd_ws_bytes((int)M)), attn_out_bwd_ws_bytes((int)M));
+        if (fused) wg = std::max(std::max(wg, fused_ops(c.dtype, E)->mlp_bwd_ws((int)M)), fused_ops(c.dtype, E)->attn_out_bwd_ws((int)M));
         if (c.embedding != MIVIT_EMBED_EXTERNAL) {
             mx((int)Mt, E, c.patch_size * c.patch_size);
             if ((c.dtype == MIVIT_F16 ? embed_dma_supported_f16 : embed_dma_supported)(c.dtype, (int)Mt, c.patch_size * c.patch_size, E)) {
@@ -539,11 +536,11 @@ static int forward_impl(const mivit_plan *plan, const float *params, const float
             const Ws::L &b = w.layer[l];
             const bool last = l + 1 == c.num_layers;
             prof_set_tag(MIVIT_PROF_ATTN_BLOCK_FWD);
-            RC(fused_ops(dt)->attn_fwd(nin, gin, bin, WT(lp.qkv_w), P + lp.qkv_b, WT(lp.out_w), P + lp.out_b, P + lp.n1_w,
+            RC(fused_ops(dt, E)->attn_fwd(nin, gin, bin, WT(lp.qkv_w), P + lp.qkv_b, WT(lp.out_w), P + lp.out_b, P + lp.n1_w,
                                      P + lp.n1_b, B, S, at(ws, b.ctx), at(ws, b.z1), static_cast<float *>(at(ws, b.rstd1)),
                                      nullptr, nullptr, nullptr, need_backward ? at(ws, b.qkv) : nullptr, s));
             prof_set_tag(MIVIT_PROF_MLP_BLOCK_FWD);
-            RC(fused_ops(dt)->mlp_fwd(at(ws, b.z1), P + lp.n1_w, P + lp.n1_b, WT(lp.fc1_w), P + lp.fc1_b, WT(lp.fc2_w), P + lp.fc2_b,
+            RC(fused_ops(dt, E)->mlp_fwd(at(ws, b.z1), P + lp.n1_w, P + lp.n1_b, WT(lp.fc1_w), P + lp.fc1_b, WT(lp.fc2_w), P + lp.fc2_b,
                                     P + lp.n2_w, P + lp.n2_b, M, c.activation, at(ws, b.z2), static_cast<float *>(at(ws, b.rstd2)),
                                     last ? at(ws, w.xL) : nullptr, nullptr, nullptr, nullptr, nullptr, s));      // (h is recomputed by the fused backward)
             nin = at(ws, b.z2); gin = P + lp.n2_w; bin = P + lp.n2_b;
@@ -704,7 +701,7 @@ static int backward_impl(const mivit_plan *plan, const float *params, const floa
                 // feed-forward block in one launch (fused_bwd.hip): d(x2) -> d(x1), all six parameter gradients
                 dx1 = at(ws, w.dxb); dz1 = at(ws, w.dF);
                 prof_set_tag(MIVIT_PROF_MLP_BLOCK_BWD);
-                RC(fused_ops(dt)->mlp_bwd(at(ws, w.dxa), at(ws, b.z2), static_cast<const float *>(at(ws, b.rstd2)), P + lp.n2_w,
+                RC(fused_ops(dt, E)->mlp_bwd(at(ws, w.dxa), at(ws, b.z2), static_cast<const float *>(at(ws, b.rstd2)), P + lp.n2_w,
                                         at(ws, b.z1), P + lp.n1_w, P + lp.n1_b, WT(lp.fc1_w), P + lp.fc1_b, WT(lp.fc2_w), M,
                                         c.activation, dx1, G + lp.fc1_w, G + lp.fc1_b, G + lp.fc2_w, G + lp.fc2_b, G + lp.n2_w,
                                         G + lp.n2_b, wg, wgb, s));
@@ -720,7 +717,7 @@ static int backward_impl(const mivit_plan *plan, const float *params, const floa
             if (fz) {
                 // LayerNorm-1 backward + out-projection weight / data gradient in one launch (fused_bwd.hip)
                 prof_set_tag(MIVIT_PROF_ATTN_OUT_BWD);
-                RC(fused_ops(dt)->attn_out_bwd(dx1, at(ws, b.z1), static_cast<const float *>(at(ws, b.rstd1)), P + lp.n1_w, at(ws, b.ctx),
+                RC(fused_ops(dt, E)->attn_out_bwd(dx1, at(ws, b.z1), static_cast<const float *>(at(ws, b.rstd1)), P + lp.n1_w, at(ws, b.ctx),
                                        WT(lp.out_w), M, dz1, at(ws, w.dctx), G + lp.out_w, G + lp.out_b, G + lp.n1_w, G + lp.n1_b,
                                        wg, wgb, s));
             } else {

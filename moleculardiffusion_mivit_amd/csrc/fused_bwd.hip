@@ -1,4 +1,6 @@
-// Fused backward of the feed-forward half of the post-norm encoder layer, bf16 mode, E = 128 / F = 256
+// Fused backward of the feed-forward half of the post-norm encoder layer, 16-bit modes, E = 128 / F = 256 -- and, compiled
+// a second time with -DMIVIT_WIDTH64 (elem.h), the reference's shipped E = 64 / F = 128: the four-wave kernel and attn_out_bwd
+// are written against the derived constants below (the numbers in the comments are those of width 128)
 // (reference helpers/models.py:72-77 FeedForward, :104-106 x = LN2(x1 + ff(x1)); autograd of that block):
 //
 //   in : dy = dL/dx2 (x2 = gamma2 * n2 + beta2), n2 = xhat of LN2, rstd2, n1 = xhat of LN1 (x1 = gamma1 * n1 + beta1)
@@ -30,9 +32,21 @@
 
 namespace {
 
+#ifdef MIVIT_WIDTH64
+constexpr int E = 64, F = 128;
+constexpr int LDE = E + 8, LDF = F + 16;             // 144-byte rows (9 x 16 B, odd: the 16 rows of a b128 read hit 16 bank groups)
+#else
 constexpr int E = 128, F = 256;
-constexpr int NW = 4, NT = NW * 64, R = 32;          // waves per workgroup, threads, rows per tile
 constexpr int LDE = E + 16, LDF = F + 16;            // LDS row pitches (elements): conflict-free b128 and transposing reads
+#endif
+constexpr int NW = 4, NT = NW * 64, R = 32;          // waves per workgroup, threads, rows per tile
+constexpr int KS = E / 32, ET = E / 16;              // contraction steps over / 16-feature tiles of an embedding row
+constexpr int CPR = E / 8;                           // 16-byte chunks per row = threads per row of the element-wise phase (16 | 8)
+constexpr int RPP = NT / CPR, RPT = R / RPP;         // rows per pass of all threads (16 | 32), rows per thread (2 | 1)
+constexpr int FW = F / NW, NTW = FW / 16;            // hidden units per wave (64 | 32) and their 16-unit tiles (4 | 2)
+constexpr int EW = E / NW, KT2 = EW / 16;            // features per wave of the data-gradient phases (32 | 16), their tiles (2 | 1)
+constexpr int FS = F / 32;                           // contraction steps over the hidden units
+constexpr int NROWST = 2 * KT2;                      // 8-byte row stores per wave and full tile: what the tile wait counts on
 
 constexpr int OFF_W1 = 0;                            // [F][LDE]  W1 as stored ([hidden unit][input feature]): serves u (plain reads) and dx1 (transposing reads)
 constexpr int OFF_X = OFF_W1 + F * LDE * 2;          // [R][LDE]  x1 = gamma1 * n1 + beta1 rows
@@ -73,7 +87,12 @@ __device__ __forceinline__ bf16x8 pack8(const f32x4 a, const f32x4 b) {
     return f;
 }
 __device__ __forceinline__ float x4_sum(float v) { return rows4_sum(v); }   // common.h: permlane-swap / DPP forms
-__device__ __forceinline__ float g16_sum(float v) { return row16_sum(v); }
+// sum over the CPR threads that share a row in the element-wise phase (a 16-lane row, or one half of it: xor 1, xor 2 by
+// quad permutation, then the mirrored half-row)
+__device__ __forceinline__ float g16_sum(float v) {
+    if constexpr (CPR == 16) return row16_sum(v);
+    v += dpp_mov<0xB1>(v); v += dpp_mov<0x4E>(v); return v + dpp_mov<0x141>(v);
+}
 __device__ __forceinline__ bf16x8 lds_frag(const bf16 *p) { return *reinterpret_cast<const bf16x8 *>(p); }
 __device__ __forceinline__ void unpack8(const uint4 &u, float (&v)[8]) {
     const uint32_t w[4] = {u.x, u.y, u.z, u.w};
@@ -129,20 +148,20 @@ __global__ __launch_bounds__(NT) void mlp_block_bwd_kernel(const MlpBwdArgs a) {
     for (int i = tid; i < E; i += NT) { b1f[F + i] = a.gamma2[i]; b1f[F + E + i] = a.gamma1[i]; b1f[F + 2 * E + i] = a.beta1[i]; }
     // register-resident operand of this wave's hidden units n = 64 wave + 16 nt + cq:
     //   w2f[nt][ks]: W2[32ks + 8g .. +7][n]           (column operand of dh = dz2 W2)
-    bf16x8 w2f[4][4];
+    bf16x8 w2f[NTW][KS];
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-        const int n = 64 * wave + 16 * nt + cq;
+    for (int nt = 0; nt < NTW; ++nt) {
+        const int n = FW * wave + 16 * nt + cq;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
+        for (int ks = 0; ks < KS; ++ks) {
             bf16x8 t;
 #pragma unroll
             for (int e = 0; e < 8; ++e) t[e] = __builtin_bit_cast(__bf16, a.W2[(int64_t)(ks * 32 + 8 * g + e) * F + n].v);
             w2f[nt][ks] = t;
         }
     }
-    // this thread's slice of the element-wise phase: columns 8c .. 8c+7 of rows r0 and r0 + 16 of the tile
-    const int c = tid & 15, r0 = tid >> 4;
+    // this thread's slice of the element-wise phase: columns 8c .. 8c+7 of rows r0 (and r0 + 16) of the tile
+    const int c = tid % CPR, r0 = tid / CPR;
     // LDS-typed pointers: as plain `const float *` they were kept across the tile loop as generic addresses and every read became
     // a flat_load (vmcnt AND lgkmcnt, out of order -> s_waitcnt vmcnt(0) in the element-wise phase, i.e. a wait for the previous
     // tile's store acks)
@@ -150,12 +169,14 @@ __global__ __launch_bounds__(NT) void mlp_block_bwd_kernel(const MlpBwdArgs a) {
     lds_cf *gam2 = (lds_cf *)(b1f + F + 8 * c), *gam1 = (lds_cf *)(b1f + F + E + 8 * c), *bet1 = (lds_cf *)(b1f + F + 2 * E + 8 * c);
 #pragma unroll
     for (int i = 0; i < 6; ++i) cacc[i * NT + tid] = f32x4{0.f, 0.f, 0.f, 0.f};       // (thread-private slots: no barrier needed)
-    f32x4 dW1[4][8], dW2[8][4];
+    f32x4 dW1[NTW][ET], dW2[ET][NTW];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NTW; ++i)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { dW1[i][j] = zero; dW2[j][i] = zero; }
-    float db1[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < ET; ++j) { dW1[i][j] = zero; dW2[j][i] = zero; }
+    float db1[NTW];
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) db1[i] = 0.f;
     __syncthreads();
 
     const int ntiles = (a.M + R - 1) / R;
@@ -164,8 +185,8 @@ __global__ __launch_bounds__(NT) void mlp_block_bwd_kernel(const MlpBwdArgs a) {
     // compute phases, no barrier -- the issuing wave's vmcnt wait is the only ordering needed
     auto prefetch = [&](int t) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int row = min(t * R + r0 + 16 * i, a.M - 1);        // (64-bit only in the address)
+        for (int i = 0; i < RPT; ++i) {
+            const int row = min(t * R + r0 + RPP * i, a.M - 1);        // (64-bit only in the address)
             const int64_t o = (int64_t)row * E + 8 * c;
             dma16_opaque(a.dy + o, stg + (3 * i + 0) * NT + wave * 64);
             dma16_opaque(a.n2 + o, stg + (3 * i + 1) * NT + wave * 64);
@@ -197,13 +218,14 @@ __global__ __launch_bounds__(NT) void mlp_block_bwd_kernel(const MlpBwdArgs a) {
             // VM program order of a wave: P(t) [8 DMA pieces: the staged rows of tile t] | 4 row stores of tile t-1's phase 2 | this
             // wait.  P(t) was requested one tile ago; younger than it are only those four stores (every full tile issues them,
             // scripts/isa_check.py counts them in the ISA; the one partial tile is the last of the launch): vmcnt(4) = P(t) landed.
-            if (first) wait_vm<0>(); else wait_vm<4>();
+            // (width 64: 4 pieces, NROWST = 2 stores)
+            if (first) wait_vm<0>(); else wait_vm<NROWST>();
             first = false;
             PT_MARK(0);                                            // 0: wait for the staged rows
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < RPT; ++i) {
                 float d[8], nh[8], gdy[8];
-                const bool ok = row0 + r0 + 16 * i < a.M;          // rows past the end were clamped to a real row: cancel them
+                const bool ok = row0 + r0 + RPP * i < a.M;          // rows past the end were clamped to a real row: cancel them
                 const uint4 pdy = keep_if(stg[(3 * i + 0) * NT + tid], ok), pn2 = stg[(3 * i + 1) * NT + tid];
                 const uint4 pn1 = keep_if(stg[(3 * i + 2) * NT + tid], ok);
                 unpack8(pdy, d); unpack8(pn2, nh);
@@ -219,12 +241,12 @@ __global__ __launch_bounds__(NT) void mlp_block_bwd_kernel(const MlpBwdArgs a) {
                 const float prs = __uint_as_float(__float_as_uint(rst[i * NT + tid]) & (ok ? 0xffffffffu : 0u));
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { dz[e] = prs * (gdy[e] - s1 - nh[e] * s2); sz[e] += dz[e]; }
-                store16(DZ + (r0 + 16 * i) * LDE + 8 * c, dz);
+                store16(DZ + (r0 + RPP * i) * LDE + 8 * c, dz);
                 float x1v[8];
                 unpack8(pn1, x1v);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) x1v[e] = ok ? x1v[e] * g1v[e] + b1v[e] : 0.f;
-                store16(X + (r0 + 16 * i) * LDE + 8 * c, x1v);
+                store16(X + (r0 + RPP * i) * LDE + 8 * c, x1v);
             }
             f32x4 ca[6];
 #pragma unroll
@@ -240,7 +262,7 @@ __global__ __launch_bounds__(NT) void mlp_block_bwd_kernel(const MlpBwdArgs a) {
         barrier();          // raw s_barrier (LDS drained): __syncthreads() also waits vmcnt(0), i.e. for the row prefetch just issued and for store acks
         PT_MARK(2);                                             // 2: prefetch issue + barrier
         // ---------------- phase 1: u, dh for this wave's 64 hidden units; dW1, dW2 ----------------
-        bf16x8 hB[4], dhB[4];
+        bf16x8 hB[NTW], dhB[NTW];
         {
             // u and dh for 32 of the wave's 64 hidden units at a time (register budget): un-transposed products, so the
             // accumulators (lane = hidden unit, registers = rows) are the row-contraction operands of the weight gradients.
@@ -249,18 +271,18 @@ __global__ __launch_bounds__(NT) void mlp_block_bwd_kernel(const MlpBwdArgs a) {
             // compiler spill 11-39 registers of the fc2^T slice at the 512 a wave has; their scratch reloads sit in vmcnt behind the
             // row prefetch and the row stores.  The loop stays un-prefetched: one exposed LDS round trip per 8 MFMAs.)
             typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-            const int dst_lane = (64 * wave + cq) * R + 4 * g, dst_sw0 = (q & 1) << 4, dst_sw1 = ((q & 1) ^ 1) << 4;
+            const int dst_lane = (FW * wave + cq) * R + 4 * g, dst_sw0 = (q & 1) << 4, dst_sw1 = ((q & 1) ^ 1) << 4;
 #pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {
+            for (int hf = 0; hf < NTW / 2; ++hf) {
                 f32x4 u[2][2], dh[2][2];
 #pragma unroll
                 for (int n2 = 0; n2 < 2; ++n2) {
-                    const float bv = b1f[64 * wave + 32 * hf + 16 * n2 + cq];
+                    const float bv = b1f[FW * wave + 32 * hf + 16 * n2 + cq];
 #pragma unroll
                     for (int rt = 0; rt < 2; ++rt) { u[rt][n2] = f32x4{bv, bv, bv, bv}; dh[rt][n2] = zero; }
                 }
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks)
+                for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
                     for (int rt = 0; rt < 2; ++rt) {
                         const bf16x8 xa = lds_frag(X + (16 * rt + cq) * LDE + ks * 32 + 8 * g);
@@ -268,7 +290,7 @@ __global__ __launch_bounds__(NT) void mlp_block_bwd_kernel(const MlpBwdArgs a) {
 #pragma unroll
                         for (int n2 = 0; n2 < 2; ++n2) {
                             const int nt = 2 * hf + n2;
-                            u[rt][n2] = mma(xa, lds_frag(W1i + (64 * wave + 16 * nt + cq) * LDE + ks * 32 + 8 * g), u[rt][n2]);
+                            u[rt][n2] = mma(xa, lds_frag(W1i + (FW * wave + 16 * nt + cq) * LDE + ks * 32 + 8 * g), u[rt][n2]);
                             dh[rt][n2] = mma(za, w2f[nt][ks], dh[rt][n2]);
                         }
                     }
@@ -302,14 +324,14 @@ __global__ __launch_bounds__(NT) void mlp_block_bwd_kernel(const MlpBwdArgs a) {
             bf16x8 xb = tr_pair(X + (4 * g + q) * LDE + 4 * pp, X + (16 + 4 * g + q) * LDE + 4 * pp);
             bf16x8 zb = tr_pair(DZ + (4 * g + q) * LDE + 4 * pp, DZ + (16 + 4 * g + q) * LDE + 4 * pp);
 #pragma unroll
-            for (int t = 0; t < 8; ++t) {
+            for (int t = 0; t < ET; ++t) {
                 bf16x8 xn = xb, zn = zb;
-                if (t < 7) {
+                if (t < ET - 1) {
                     xn = tr_pair(X + (4 * g + q) * LDE + 16 * (t + 1) + 4 * pp, X + (16 + 4 * g + q) * LDE + 16 * (t + 1) + 4 * pp);
                     zn = tr_pair(DZ + (4 * g + q) * LDE + 16 * (t + 1) + 4 * pp, DZ + (16 + 4 * g + q) * LDE + 16 * (t + 1) + 4 * pp);
                 }
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
+                for (int nt = 0; nt < NTW; ++nt) {
                     dW1[nt][t] = mma(dhB[nt], xb, dW1[nt][t]);       // [n][k] += dh^T x1
                     dW2[t][nt] = mma(zb, hB[nt], dW2[t][nt]);        // [e][n] += dz2^T h
                 }
@@ -320,42 +342,49 @@ __global__ __launch_bounds__(NT) void mlp_block_bwd_kernel(const MlpBwdArgs a) {
         barrier();          // raw s_barrier (LDS drained): __syncthreads() also waits vmcnt(0), i.e. for the row prefetch just issued and for store acks
         PT_MARK(5);                                             // 5: barrier
         // ---------------- phase 2: dx1^T for this wave's 32 input features ----------------
-        f32x4 dx[2][2];
+        f32x4 dx[KT2][2];
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
+        for (int kt = 0; kt < KT2; ++kt)
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) dx[kt][rt] = zero;
         // A = W1^T read transposed out of the W1 image: k-slots 0-3 = hidden units 32ks + 4g + {0..3}, slots 4-7 = 32ks + 16 + 4g + {0..3};
         // B = dh^T by the same transposing read out of the [hidden][row] image: identical k-slot order on both operands
         {
             auto wfrag = [&](int ks, int kt) {
-                return tr_pair(W1i + (32 * ks + 4 * g + q) * LDE + 32 * wave + 16 * kt + 4 * pp,
-                               W1i + (32 * ks + 16 + 4 * g + q) * LDE + 32 * wave + 16 * kt + 4 * pp);
+                return tr_pair(W1i + (32 * ks + 4 * g + q) * LDE + EW * wave + 16 * kt + 4 * pp,
+                               W1i + (32 * ks + 16 + 4 * g + q) * LDE + EW * wave + 16 * kt + 4 * pp);
             };
             // = tr_pair(DH + dht_off(32 ks + 4 g + q, 16 rt + 4 pp), DH + dht_off(32 ks + 16 + 4 g + q, 16 rt + 4 pp)): the swizzle bit of
             // hidden units 32 ks (+ 16) + 4 g + q is g & 1 -- two lane-dependent bases, everything else immediate offsets
             const bf16 *dbase[2] = {DH + (4 * g + q) * R + ((g & 1) << 4) + 4 * pp, DH + (4 * g + q) * R + (((g & 1) ^ 1) << 4) + 4 * pp};
             auto dfrag = [&](int ks, int rt) { return tr_pair(dbase[rt] + 32 * ks * R, dbase[rt] + (32 * ks + 16) * R); };
             bf16x8 d0 = dfrag(0, 0), d1 = dfrag(0, 1);
-            bf16x8 w0 = wfrag(0, 0), w1 = wfrag(0, 1);
+            bf16x8 wf[KT2];
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
-                bf16x8 e0 = d0, e1 = d1, v0 = w0, v1 = w1;
-                if (ks < 7) {
+            for (int kt = 0; kt < KT2; ++kt) wf[kt] = wfrag(0, kt);
+#pragma unroll
+            for (int ks = 0; ks < FS; ++ks) {
+                bf16x8 e0 = d0, e1 = d1, vf[KT2];
+#pragma unroll
+                for (int kt = 0; kt < KT2; ++kt) vf[kt] = wf[kt];
+                if (ks < FS - 1) {
                     e0 = dfrag(ks + 1, 0); e1 = dfrag(ks + 1, 1);
-                    v0 = wfrag(ks + 1, 0); v1 = wfrag(ks + 1, 1);
+#pragma unroll
+                    for (int kt = 0; kt < KT2; ++kt) vf[kt] = wfrag(ks + 1, kt);
                 }
-                dx[0][0] = mma(w0, d0, dx[0][0]); dx[0][1] = mma(w0, d1, dx[0][1]);
-                dx[1][0] = mma(w1, d0, dx[1][0]); dx[1][1] = mma(w1, d1, dx[1][1]);
-                d0 = e0; d1 = e1; w0 = v0; w1 = v1;
+#pragma unroll
+                for (int kt = 0; kt < KT2; ++kt) { dx[kt][0] = mma(wf[kt], d0, dx[kt][0]); dx[kt][1] = mma(wf[kt], d1, dx[kt][1]); }
+                d0 = e0; d1 = e1;
+#pragma unroll
+                for (int kt = 0; kt < KT2; ++kt) wf[kt] = vf[kt];
             }
         }
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
             const int row = row0 + 16 * rt + cq;
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt) {
-                const int col = 32 * wave + 16 * kt + 4 * g;
+            for (int kt = 0; kt < KT2; ++kt) {
+                const int col = EW * wave + 16 * kt + 4 * g;
                 const uint2 zr = *reinterpret_cast<const uint2 *>(DZ + (16 * rt + cq) * LDE + col);
                 f32x4 o = dx[kt][rt];
                 o[0] += elem_lo(zr.x); o[1] += elem_hi(zr.x);
@@ -379,23 +408,23 @@ __global__ __launch_bounds__(NT) void mlp_block_bwd_kernel(const MlpBwdArgs a) {
     // ---------------- partial gradients -> this workgroup's slab ----------------
     float *sl = a.slabs + (int64_t)blockIdx.x * SL_TOTAL;
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
+    for (int nt = 0; nt < NTW; ++nt) {
 #pragma unroll
-        for (int t = 0; t < 8; ++t)
+        for (int t = 0; t < ET; ++t)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                sl[SL_W1 + (64 * wave + 16 * nt + 4 * g + j) * E + 16 * t + cq] = dW1[nt][t][j];
-                sl[SL_W2 + (16 * t + 4 * g + j) * F + 64 * wave + 16 * nt + cq] = dW2[t][nt][j];
+                sl[SL_W1 + (FW * wave + 16 * nt + 4 * g + j) * E + 16 * t + cq] = dW1[nt][t][j];
+                sl[SL_W2 + (16 * t + 4 * g + j) * F + FW * wave + 16 * nt + cq] = dW2[t][nt][j];
             }
         const float s = x4_sum(db1[nt]);
-        if (g == 0) sl[SL_B1 + 64 * wave + 16 * nt + cq] = s;
+        if (g == 0) sl[SL_B1 + FW * wave + 16 * nt + cq] = s;
     }
-    // column sums of the element-wise phase: thread (c, r0) holds columns 8c .. 8c+7; fold the 16 row-threads of a column
+    // column sums of the element-wise phase: thread (c, r0) holds columns 8c .. 8c+7; fold the RPP row-threads of a column
     __syncthreads();
     for (int i = tid; i < 3 * E; i += NT) {
         const int which = i / E, col = i - which * E, cc = col >> 3, e = col & 7;
         float s = 0.f;
-        for (int rr = 0; rr < 16; ++rr) s += cacc[(2 * which + (e >> 2)) * NT + cc + 16 * rr][e & 3];
+        for (int rr = 0; rr < RPP; ++rr) s += cacc[(2 * which + (e >> 2)) * NT + cc + CPR * rr][e & 3];
         sl[(which == 0 ? SL_G2 : which == 1 ? SL_BE2 : SL_B2) + col] = s;
     }
 }
@@ -410,6 +439,7 @@ __global__ __launch_bounds__(NT) void mlp_block_bwd_kernel(const MlpBwdArgs a) {
 // input features 16 w .. 16 w + 15 (one 8-byte row store per row tile: the count behind wait_vm<2>).  Same LDS layout, same
 // slab layout, same arithmetic per element (dW / db accumulate the same products in the same row order per hidden unit).
 // ================================================================================================================
+#ifndef MIVIT_WIDTH64          // (width 128 only: at width 64 the four-wave kernel above already runs at 2 workgroups' worth of registers per SIMD)
 constexpr int NW8 = 8, NT8 = NW8 * 64, NH = NT8 / 2;         // NH = 256 threads per role
 
 template <int ACT>
@@ -707,6 +737,8 @@ __global__ __launch_bounds__(NT8) void mlp_block_bwd8_kernel(const MlpBwdArgs a)
     }
 }
 
+#endif          // !MIVIT_WIDTH64
+
 // ================================================================================================================
 // LayerNorm-1 backward + out-projection backward (autograd of x1 = LN1(x + out_proj(ctx)), models.py:57,100-102, up to the
 // attention core):   in : dy = dL/dx1, n1 / rstd1 (LN1's normalised output, 1/std), ctx (the out-projection's input)
@@ -740,35 +772,35 @@ __global__ __launch_bounds__(NT, 2) void attn_out_bwd_kernel(const AttnOutBwdArg
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, cq = lane & 15, q = cq >> 2, pp = cq & 3;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     // row operand of dctx^T = Wo^T dz1^T for this wave's context features c = 32 wave + 16 ct + cq: A[c][e] = Wo[e][c]
-    bf16x8 wof[2][4];
+    bf16x8 wof[KT2][KS];
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
+    for (int ct = 0; ct < KT2; ++ct)
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
+        for (int ks = 0; ks < KS; ++ks) {
             bf16x8 t;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) t[e] = __builtin_bit_cast(__bf16, a.Wo[(int64_t)(ks * 32 + 8 * g + e) * E + 32 * wave + 16 * ct + cq].v);
+            for (int e = 0; e < 8; ++e) t[e] = __builtin_bit_cast(__bf16, a.Wo[(int64_t)(ks * 32 + 8 * g + e) * E + EW * wave + 16 * ct + cq].v);
             wof[ct][ks] = t;
         }
-    const int c = tid & 15, r0 = tid >> 4;
+    const int c = tid % CPR, r0 = tid / CPR;
     float gam[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) gam[e] = a.gamma1[8 * c + e];
     float sg[8], sb[8], sz[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) sg[e] = sb[e] = sz[e] = 0.f;
-    f32x4 dWo[2][8];
+    f32x4 dWo[KT2][ET];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < KT2; ++i)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) dWo[i][j] = zero;
+        for (int j = 0; j < ET; ++j) dWo[i][j] = zero;
 
     const int ntiles = (a.M + R - 1) / R;
     int tile = blockIdx.x;
     auto prefetch = [&](int t) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int64_t row = min((int64_t)t * R + r0 + 16 * i, (int64_t)a.M - 1);
+        for (int i = 0; i < RPT; ++i) {
+            const int64_t row = min((int64_t)t * R + r0 + RPP * i, (int64_t)a.M - 1);
             const int64_t o = row * E + 8 * c;
             dma16_opaque(a.dy + o, stg + (3 * i + 0) * NT + wave * 64);
             dma16_opaque(a.n1 + o, stg + (3 * i + 1) * NT + wave * 64);
@@ -783,12 +815,13 @@ __global__ __launch_bounds__(NT, 2) void attn_out_bwd_kernel(const AttnOutBwdArg
         // ---- phase 0: LayerNorm backward, dz1 -> HBM + LDS image, ctx -> LDS image ----
         // the staged rows were requested one tile ago; younger than them are only the four dctx row stores of the last
         // phase 1 (every full tile issues them; the one partial tile is the last of the launch): do not wait for their acks
-        if (first) wait_vm<0>(); else wait_vm<4>();
+        // (width 64: NROWST = 2 of them)
+        if (first) wait_vm<0>(); else wait_vm<NROWST>();
         first = false;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < RPT; ++i) {
             float d[8], nh[8], gdy[8];
-            const bool ok = row0 + r0 + 16 * i < a.M;
+            const bool ok = row0 + r0 + RPP * i < a.M;
             const uint4 pdy = keep_if(stg[(3 * i + 0) * NT + tid], ok), pn = stg[(3 * i + 1) * NT + tid];
             const uint4 pct = keep_if(stg[(3 * i + 2) * NT + tid], ok);
             unpack8(pdy, d); unpack8(pn, nh);
@@ -804,39 +837,41 @@ __global__ __launch_bounds__(NT, 2) void attn_out_bwd_kernel(const AttnOutBwdArg
             const float prs = __uint_as_float(__float_as_uint(rst[i * NT + tid]) & (ok ? 0xffffffffu : 0u));
 #pragma unroll
             for (int e = 0; e < 8; ++e) { dz[e] = prs * (gdy[e] - s1 - nh[e] * s2); sz[e] += dz[e]; }
-            store16(DZ + (r0 + 16 * i) * LDE + 8 * c, dz);
-            if (ok) store16(a.dz1 + (row0 + r0 + 16 * i) * E + 8 * c, dz);
-            *reinterpret_cast<uint4 *>(CT + (r0 + 16 * i) * LDE + 8 * c) = pct;
+            store16(DZ + (r0 + RPP * i) * LDE + 8 * c, dz);
+            if (ok) store16(a.dz1 + (row0 + r0 + RPP * i) * E + 8 * c, dz);
+            *reinterpret_cast<uint4 *>(CT + (r0 + RPP * i) * LDE + 8 * c) = pct;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         prefetch(min(tile + (int)gridDim.x, ntiles - 1));
         barrier();          // raw s_barrier (LDS drained): __syncthreads() also waits vmcnt(0), i.e. for the row prefetch just issued and for store acks
         // ---- phase 1: dctx^T for this wave's 32 context features; dWo rows 32 wave .. +31 ----
-        f32x4 dc[2][2] = {{zero, zero}, {zero, zero}};
+        f32x4 dc[KT2][2];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
+        for (int ct = 0; ct < KT2; ++ct) { dc[ct][0] = zero; dc[ct][1] = zero; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
             const bf16x8 z0 = lds_frag(DZ + cq * LDE + ks * 32 + 8 * g), z1 = lds_frag(DZ + (16 + cq) * LDE + ks * 32 + 8 * g);
 #pragma unroll
-            for (int ct = 0; ct < 2; ++ct) { dc[ct][0] = mma(wof[ct][ks], z0, dc[ct][0]); dc[ct][1] = mma(wof[ct][ks], z1, dc[ct][1]); }
+            for (int ct = 0; ct < KT2; ++ct) { dc[ct][0] = mma(wof[ct][ks], z0, dc[ct][0]); dc[ct][1] = mma(wof[ct][ks], z1, dc[ct][1]); }
         }
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
             const int64_t row = row0 + 16 * rt + cq;
             if (row < a.M) {
 #pragma unroll
-                for (int ct = 0; ct < 2; ++ct) {
+                for (int ct = 0; ct < KT2; ++ct) {
                     typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
                     const f32x4 o = dc[ct][rt];
                     const bf16x4 ob = {(__bf16)o[0], (__bf16)o[1], (__bf16)o[2], (__bf16)o[3]};
-                    *reinterpret_cast<bf16x4 *>(a.dctx + row * E + 32 * wave + 16 * ct + 4 * g) = ob;
+                    *reinterpret_cast<bf16x4 *>(a.dctx + row * E + EW * wave + 16 * ct + 4 * g) = ob;
                 }
             }
         }
 #pragma unroll
-        for (int et = 0; et < 2; ++et) {
-            const bf16x8 za = tr_pair(DZ + (4 * g + q) * LDE + 32 * wave + 16 * et + 4 * pp, DZ + (16 + 4 * g + q) * LDE + 32 * wave + 16 * et + 4 * pp);
+        for (int et = 0; et < KT2; ++et) {
+            const bf16x8 za = tr_pair(DZ + (4 * g + q) * LDE + EW * wave + 16 * et + 4 * pp, DZ + (16 + 4 * g + q) * LDE + EW * wave + 16 * et + 4 * pp);
 #pragma unroll
-            for (int ct = 0; ct < 8; ++ct) {
+            for (int ct = 0; ct < ET; ++ct) {
                 const bf16x8 cb = tr_pair(CT + (4 * g + q) * LDE + 16 * ct + 4 * pp, CT + (16 + 4 * g + q) * LDE + 16 * ct + 4 * pp);
                 dWo[et][ct] = mma(za, cb, dWo[et][ct]);                 // [e][c] += dz1^T ctx
             }
@@ -846,15 +881,18 @@ __global__ __launch_bounds__(NT, 2) void attn_out_bwd_kernel(const AttnOutBwdArg
     // ---- partial gradients -> this workgroup's slab ----
     float *sl = a.slabs + (int64_t)blockIdx.x * AO_SL_TOTAL;
 #pragma unroll
-    for (int et = 0; et < 2; ++et)
+    for (int et = 0; et < KT2; ++et)
 #pragma unroll
-        for (int ct = 0; ct < 8; ++ct)
+        for (int ct = 0; ct < ET; ++ct)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) sl[AO_SL_W + (32 * wave + 16 * et + 4 * g + j) * E + 16 * ct + cq] = dWo[et][ct][j];
+            for (int j = 0; j < 4; ++j) sl[AO_SL_W + (EW * wave + 16 * et + 4 * g + j) * E + 16 * ct + cq] = dWo[et][ct][j];
+    // column sums: the wave's row-threads of chunk c are the lanes with the same lane % CPR -- the four 16-lane rows, and at
+    // width 64 both halves of each (row_ror:8)
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        const float vg = x4_sum(sg[e]), vb = x4_sum(sb[e]), vz = x4_sum(sz[e]);
-        if (g == 0) { red[(wave * 3 + 0) * E + 8 * c + e] = vg; red[(wave * 3 + 1) * E + 8 * c + e] = vb; red[(wave * 3 + 2) * E + 8 * c + e] = vz; }
+        float vg = x4_sum(sg[e]), vb = x4_sum(sb[e]), vz = x4_sum(sz[e]);
+        if constexpr (CPR == 8) { vg += dpp_mov<0x128>(vg); vb += dpp_mov<0x128>(vb); vz += dpp_mov<0x128>(vz); }
+        if (g == 0 && cq < CPR) { red[(wave * 3 + 0) * E + 8 * c + e] = vg; red[(wave * 3 + 1) * E + 8 * c + e] = vb; red[(wave * 3 + 2) * E + 8 * c + e] = vz; }
     }
     __syncthreads();
     for (int i = tid; i < 3 * E; i += NT) {
@@ -871,8 +909,13 @@ int grid_for(int M) { return std::min(256, ceil_div(M, R)); }
 
 }  // namespace
 
+#ifdef MIVIT_WIDTH64
+static const int g_mlp_bwd_waves = 4;
+constexpr int NW8 = 8;
+#else
 static int g_mlp_bwd_waves = [] { const char *e = getenv("MIVIT_MLP_BWD_WAVES"); return e && atoi(e) == 4 ? 4 : 8; }();
-#ifndef MIVIT_ELEM_F16
+#endif
+#if !defined(MIVIT_ELEM_F16) && !defined(MIVIT_WIDTH64)
 extern "C" int mivit_mlp_block_bwd_set_waves(int waves) {
     const int old = g_mlp_bwd_waves;
     if (waves == 4 || waves == 8) g_mlp_bwd_waves = waves;
@@ -906,12 +949,20 @@ int launch_mlp_block_bwd(const void *dy, const void *n2, const float *rstd2, con
 #endif
     {
         ProfScope prof(s);
+#ifdef MIVIT_WIDTH64
+#define BWD_LAUNCH8(ACT_) do { } while (0)
+#else
+#define BWD_LAUNCH8(ACT_)                                                                                        \
+    do {                                                                                                         \
+        auto kern = mlp_block_bwd8_kernel<ACT_>;                                                                 \
+        MIVIT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES)); \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(NT8), LDS_BYTES, s, a);                                        \
+    } while (0)
+#endif
 #define BWD_LAUNCH(ACT_)                                                                                         \
     do {                                                                                                         \
         if (waves == 8) {                                                                                        \
-            auto kern = mlp_block_bwd8_kernel<ACT_>;                                                             \
-            MIVIT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES)); \
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(NT8), LDS_BYTES, s, a);                                    \
+            BWD_LAUNCH8(ACT_);                                                                                   \
         } else {                                                                                                 \
             auto kern = mlp_block_bwd_kernel<ACT_>;                                                              \
             MIVIT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES)); \
@@ -925,6 +976,7 @@ int launch_mlp_block_bwd(const void *dy, const void *n2, const float *rstd2, con
             default: BWD_LAUNCH(MIVIT_ACT_NONE); break;
         }
 #undef BWD_LAUNCH
+#undef BWD_LAUNCH8
         MIVIT_LAUNCH_CHECK();
     }
 #ifdef MIVIT_PHASE_TIMING
@@ -960,7 +1012,7 @@ int launch_mlp_block_bwd(const void *dy, const void *n2, const float *rstd2, con
     return 0;
 }
 
-#ifndef MIVIT_ELEM_F16      // operator-level C-ABI: declared for bf16 (include/mivit_hip.h)
+#ifndef MIVIT_ELEM_F16      // operator-level C-ABI: declared for bf16 (include/mivit_hip.h; the width-64 build exports ..._w64)
 extern "C" size_t mivit_mlp_block_bwd_workspace_bytes(int M) { return mlp_block_bwd_ws_bytes(M); }
 extern "C" int mivit_mlp_block_bwd(const void *dy, const void *n2, const float *rstd2, const float *gamma2, const void *n1,
                                    const float *gamma1, const float *beta1, const void *W1_bf16, const float *b1,

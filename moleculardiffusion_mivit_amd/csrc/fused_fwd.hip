@@ -1,6 +1,7 @@
-// Fused forward kernels of the post-norm encoder layer, bf16 mode, E = 128 / F = 256 / head dim 32 (the PSFNoise
-// 32x64x64 configuration: reference helpers/models.py:97-108 TransformerEncoderLayerWithSkip, :33-59 attention,
-// :72-77 feed-forward):
+// Fused forward kernels of the post-norm encoder layer, 16-bit modes, for two layer widths chosen PER TRANSLATION UNIT
+// (elem.h): E = 128 / F = 256 / head dim 32 (the PSFNoise 32x64x64 configuration) and, under -DMIVIT_WIDTH64, the
+// reference's shipped E = 64 / F = 128 / head dim 16 (Experiments/Framerate/trainSettingsFramerate.py:42-47); 4 heads both.
+// Reference helpers/models.py:97-108 TransformerEncoderLayerWithSkip, :33-59 attention, :72-77 feed-forward:
 //
 //   attn_block_fwd :  n1 = LNhat( x + out_proj(attention(q_proj x, k_proj x, v_proj x)) )      one wave per SEQUENCE
 //   mlp_block_fwd  :  n2 = LNhat( x1 + fc2(act(fc1 x1)) )                                      one wave per 32 ROWS
@@ -30,11 +31,22 @@
 
 namespace {
 
+#ifdef MIVIT_WIDTH64
+constexpr int E = 64, F = 128, H = 4, DH = 16;
+constexpr int LDE = E + 8;           // LDS row pitch (elements) of a [*, 64] operand image: 144 B = 9 x 16 B (odd: 16 rows, 16 bank groups)
+constexpr int LDF = F + 16;          // ... of a [*, 128] image: 288 B = 18 x 16 B
+constexpr float QSCALE = 0.25f * 1.4426950408889634f;                     // 1/sqrt(16) * log2(e), folded into the q projection
+#else
 constexpr int E = 128, F = 256, H = 4, DH = 32;
 constexpr int LDE = E + 16;          // LDS row pitch (elements) of a [*, 128] operand image: 288 B = 18 x 16 B
 constexpr int LDF = F + 16;          // ... of a [*, 256] image: 544 B = 34 x 16 B   (pitch = 2 mod 16 units: conflict-free b128)
-constexpr int NWAVES = 8, NTHREADS = NWAVES * 64;
 constexpr float QSCALE = 0.17677669529663687f * 1.4426950408889634f;      // 1/sqrt(32) * log2(e), folded into the q projection
+#endif
+constexpr int KS = E / 32;           // contraction steps of a projection over the embedding (32 per MFMA)
+constexpr int ET = E / 16;           // 16-feature tiles of an embedding row
+constexpr int DT = DH / 16;          // 16-feature tiles of a head
+constexpr int HB = 32 / DH;          // heads per 32-wide contraction block of the out-projection
+constexpr int NWAVES = 8, NTHREADS = NWAVES * 64;
 
 __device__ __forceinline__ bf16x8 pack8(const f32x4 a, const f32x4 b) {
     bf16x8 f;
@@ -57,6 +69,10 @@ __device__ __forceinline__ void store_halves(bf16 *p_lo, bf16 *p_hi, const bf16x
     const H h = __builtin_bit_cast(H, f);
     *reinterpret_cast<uint2 *>(p_lo) = h.lo;
     *reinterpret_cast<uint2 *>(p_hi) = h.hi;
+}
+__device__ __forceinline__ void store_lo(bf16 *p_lo, const bf16x8 f) {
+    struct H { uint2 lo, hi; };
+    *reinterpret_cast<uint2 *>(p_lo) = __builtin_bit_cast(H, f).lo;
 }
 __device__ __forceinline__ bf16x8 lds_frag(const bf16 *p) { return *reinterpret_cast<const bf16x8 *>(p); }
 
@@ -117,10 +133,10 @@ __device__ __forceinline__ void stage_vec(float *dst, const float *src, int n, f
 }
 
 // column-operand fragments of 16 activation rows: lane (row = lane & 15, g) holds k = 32 ks + 8 g + 0..7.
-// load_raw issues the four 16-byte loads (zeros for rows that do not exist); the registers ARE the MFMA operands.
-__device__ __forceinline__ void load_raw(uint4 (&raw)[4], const bf16 *nin, int64_t row, bool valid, int g) {
+// load_raw issues the KS 16-byte loads (zeros for rows that do not exist); the registers ARE the MFMA operands.
+__device__ __forceinline__ void load_raw(uint4 (&raw)[KS], const bf16 *nin, int64_t row, bool valid, int g) {
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
+    for (int ks = 0; ks < KS; ++ks) {
         raw[ks] = make_uint4(0u, 0u, 0u, 0u);
         if (valid) raw[ks] = *reinterpret_cast<const uint4 *>(nin + row * E + ks * 32 + 8 * g);
     }
@@ -131,11 +147,13 @@ __device__ __forceinline__ bf16x8 as_frag(const uint4 &u) { return __builtin_bit
 // an explicit counted wait (attn_block_fwd: prefetch at the top of an iteration, wait at the top of the next).  The row is
 // clamped by the caller (always a valid address); rows that do not exist are zeroed after the wait (frag_if).
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void load_raw_asm(u32x4_t (&raw)[4], const bf16 *rowptr) {
+__device__ __forceinline__ void load_raw_asm(u32x4_t (&raw)[KS], const bf16 *rowptr) {
     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(raw[0]) : "v"(rowptr) : "memory");
     asm volatile("global_load_dwordx4 %0, %1, off offset:64" : "=v"(raw[1]) : "v"(rowptr) : "memory");
-    asm volatile("global_load_dwordx4 %0, %1, off offset:128" : "=v"(raw[2]) : "v"(rowptr) : "memory");
-    asm volatile("global_load_dwordx4 %0, %1, off offset:192" : "=v"(raw[3]) : "v"(rowptr) : "memory");
+    if constexpr (KS > 2) {
+        asm volatile("global_load_dwordx4 %0, %1, off offset:128" : "=v"(raw[KS > 2 ? 2 : 0]) : "v"(rowptr) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off offset:192" : "=v"(raw[KS > 2 ? 3 : 0]) : "v"(rowptr) : "memory");
+    }
 }
 __device__ __forceinline__ bf16x8 frag_if(const u32x4_t &u, bool valid) {
     const unsigned m = valid ? 0xffffffffu : 0u;
@@ -207,21 +225,21 @@ struct LnOut {
     bf16 *xout;                       // optional: gamma * nhat + beta
     bf16 *zout; float *mean;          // optional: pre-norm sum and mean (unfused backward)
 };
-__device__ __forceinline__ void ln_store(f32x4 (&z)[8], int64_t row, bool valid, const float *gout, const float *bout,
+__device__ __forceinline__ void ln_store(f32x4 (&z)[ET], int64_t row, bool valid, const float *gout, const float *bout,
                                          const LnOut &o, int g) {
     float s = 0.f;
 #pragma unroll
-    for (int et = 0; et < 8; ++et) s += z[et][0] + z[et][1] + z[et][2] + z[et][3];
+    for (int et = 0; et < ET; ++et) s += z[et][0] + z[et][1] + z[et][2] + z[et][3];
     const float mu = x4_sum(s) * (1.f / E);
     float q = 0.f;
 #pragma unroll
-    for (int et = 0; et < 8; ++et)
+    for (int et = 0; et < ET; ++et)
 #pragma unroll
         for (int j = 0; j < 4; ++j) { const float d = z[et][j] - mu; q += d * d; }
     const float rs = rsqrtf(x4_sum(q) * (1.f / E) + 1e-5f);
     if (!valid) return;
 #pragma unroll
-    for (int et = 0; et < 8; ++et) {
+    for (int et = 0; et < ET; ++et) {
         const int c = 16 * et + 4 * g;
         if (o.zout) store4_bf16(o.zout + row * E + c, z[et]);
         f32x4 nh;
@@ -277,7 +295,7 @@ __global__ __launch_bounds__(NWV * 64) void mlp_block_fwd_kernel(const MlpFwdArg
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     int tile = blockIdx.x * NWV + wave;
     const int tstride = gridDim.x * NWV;
-    uint4 nx[NR][4];
+    uint4 nx[NR][KS];
     if (tile < ntiles) {
 #pragma unroll
         for (int rb = 0; rb < NR; ++rb) {
@@ -287,11 +305,11 @@ __global__ __launch_bounds__(NWV * 64) void mlp_block_fwd_kernel(const MlpFwdArg
     }
     for (; tile < ntiles; tile += tstride) {
         const int64_t row0 = (int64_t)tile * 16 * NR;
-        bf16x8 xf[NR][4];
+        bf16x8 xf[NR][KS];
 #pragma unroll
         for (int rb = 0; rb < NR; ++rb)
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) xf[rb][ks] = as_frag(nx[rb][ks]);
+            for (int ks = 0; ks < KS; ++ks) xf[rb][ks] = as_frag(nx[rb][ks]);
         {                                        // next tile's rows: in flight while this one computes (unconditional --
             const int nxt = min(tile + tstride, ntiles - 1);          // a clamped re-read on the last round -- so the
 #pragma unroll                                                       // registers are dead until here)
@@ -300,9 +318,9 @@ __global__ __launch_bounds__(NWV * 64) void mlp_block_fwd_kernel(const MlpFwdArg
                 load_raw(nx[rb], a.nin, row, row < a.M, g);
             }
         }
-        f32x4 fa[8][NR];
+        f32x4 fa[ET][NR];
 #pragma unroll
-        for (int et = 0; et < 8; ++et) {
+        for (int et = 0; et < ET; ++et) {
             const f32x4 bv = ld4(b2 + 16 * et + 4 * g), gv = ld4(gin + 16 * et + 4 * g);
 #pragma unroll
             for (int rb = 0; rb < NR; ++rb) fa[et][rb] = bv + gv * mma((et & 1) ? id1 : id0, xf[rb][et >> 1], zero);   // bias + residual
@@ -318,7 +336,7 @@ __global__ __launch_bounds__(NWV * 64) void mlp_block_fwd_kernel(const MlpFwdArg
                 for (int rb = 0; rb < NR; ++rb) ha[t][rb] = bv;
             }
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
+            for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     const bf16x8 w = lds_frag(W1i + (32 * p + 16 * t + cq) * LDE + ks * 32 + 8 * g);
@@ -340,7 +358,7 @@ __global__ __launch_bounds__(NWV * 64) void mlp_block_fwd_kernel(const MlpFwdArg
             }
             // f^T += W2[:, block p (permuted)] h^T
 #pragma unroll
-            for (int et = 0; et < 8; ++et) {
+            for (int et = 0; et < ET; ++et) {
                 const bf16x8 w = lds_frag(W2i + (16 * et + cq) * LDF + p * 32 + 8 * g);
 #pragma unroll
                 for (int rb = 0; rb < NR; ++rb) fa[et][rb] = mma(w, hf[rb], fa[et][rb]);
@@ -349,9 +367,9 @@ __global__ __launch_bounds__(NWV * 64) void mlp_block_fwd_kernel(const MlpFwdArg
 #pragma unroll
         for (int rb = 0; rb < NR; ++rb) {
             const int64_t row = row0 + rb * 16 + cq;
-            f32x4 z[8];
+            f32x4 z[ET];
 #pragma unroll
-            for (int et = 0; et < 8; ++et) z[et] = fa[et][rb];
+            for (int et = 0; et < ET; ++et) z[et] = fa[et][rb];
             ln_store(z, row, row < a.M, gout, bout, a.o, g);
         }
     }
@@ -417,13 +435,13 @@ __global__ __launch_bounds__(NW * 64) void attn_block_fwd_kernel(const AttnFwdAr
     // accumulation registers right behind the asm statement -- a copy of registers the memory system has not written yet;
     // scripts/isa_check.py::check_asm_load_window is the guard that found it -- and accumulation-register destinations
     // ("=a") crash this compiler's AGPR rewrite pass.)
-    constexpr bool ASM_PF = NT <= 2;
-    constexpr int NBASE = H * NT * 2 + 8 * NT + NT;                    // ctx (two halves per head and tile) | n | rstd
-    constexpr int NSTORE = NBASE + (EXTRAS ? H * NT * 6 : 0);          // + q, k (two halves each), v (two feature tiles)
+    constexpr bool ASM_PF = NT <= 2 || E == 64;          // (width 64: 110-200 registers at any tile count, nothing gets parked)
+    constexpr int NBASE = KS * NT * 2 + ET * NT + NT;                  // ctx (two halves per 32 features and tile) | n | rstd
+    constexpr int NSTORE = NBASE + (EXTRAS ? H * NT * 3 * DT : 0);     // + q, k, v (one 8-byte store per 16 head features each)
     constexpr int WAITB = NBASE < 63 ? NBASE : 63, WAITN = NSTORE < 63 ? NSTORE : 63;
     const bool qkv_stored = EXTRAS && a.qkvout != nullptr;             // (the launcher picks EXTRAS exactly then)
-    u32x4_t nx[NT][4];
-    uint4 nxc[NT][4];
+    u32x4_t nx[NT][KS];
+    uint4 nxc[NT][KS];
     auto request = [&](int seq) {
 #pragma unroll
         for (int rt = 0; rt < NT; ++rt) {
@@ -435,7 +453,7 @@ __global__ __launch_bounds__(NW * 64) void attn_block_fwd_kernel(const AttnFwdAr
     bool first = true;
     for (; b < a.B; b += bstride) {
         const int64_t base = (int64_t)b * S;
-        bf16x8 xf[NT][4];
+        bf16x8 xf[NT][KS];
         if constexpr (ASM_PF) {
             if (first) wait_vm<0>();
             else if (EXTRAS && !qkv_stored) wait_vm<WAITB>();
@@ -443,9 +461,10 @@ __global__ __launch_bounds__(NW * 64) void attn_block_fwd_kernel(const AttnFwdAr
             first = false;
 #pragma unroll
             for (int rt = 0; rt < NT; ++rt) {
-                asm volatile("" : "+v"(nx[rt][0]), "+v"(nx[rt][1]), "+v"(nx[rt][2]), "+v"(nx[rt][3]));      // (ordered after the wait)
+                if constexpr (KS > 2) asm volatile("" : "+v"(nx[rt][0]), "+v"(nx[rt][1]), "+v"(nx[rt][KS > 2 ? 2 : 0]), "+v"(nx[rt][KS > 2 ? 3 : 0]));
+                else asm volatile("" : "+v"(nx[rt][0]), "+v"(nx[rt][1]));      // (ordered after the wait)
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) xf[rt][ks] = frag_if(nx[rt][ks], rt * 16 + cq < S);
+                for (int ks = 0; ks < KS; ++ks) xf[rt][ks] = frag_if(nx[rt][ks], rt * 16 + cq < S);
             }
             asm volatile("" ::: "memory");
             request(min(b + bstride, a.B - 1));      // (a clamped re-read on the last round: never consumed, drained before the kernel ends)
@@ -453,57 +472,62 @@ __global__ __launch_bounds__(NW * 64) void attn_block_fwd_kernel(const AttnFwdAr
 #pragma unroll
             for (int rt = 0; rt < NT; ++rt)
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) xf[rt][ks] = as_frag(nxc[rt][ks]);
+                for (int ks = 0; ks < KS; ++ks) xf[rt][ks] = as_frag(nxc[rt][ks]);
         }
-        bf16x8 cf[H][NT];                            // context, as the column operand of the out-projection
+        bf16x8 cf[KS][NT];                           // context, as the column operand of the out-projection: one fragment per
+        f32x4 ot_even[NT];                           // 32 features = one head (head dim 32) or two (head dim 16: the even head waits here)
 #pragma unroll
         for (int h = 0; h < H; ++h) {
             __builtin_amdgcn_sched_barrier(0);
             // ---- q^T, k^T (lane = token, registers = 4 head features), one after the other (register budget) ----
+            // (head dim 16: the upper half of the 32-deep contraction is zero on both operands)
             bf16x8 qf[NT], kf[NT];
 #pragma unroll
             for (int which = 0; which < 2; ++which) {
-                f32x4 pa[2][NT];
+                f32x4 pa[DT][NT];
 #pragma unroll
-                for (int dt = 0; dt < 2; ++dt) {
+                for (int dt = 0; dt < DT; ++dt) {
                     const f32x4 bb = ld4(bqkv + which * E + h * DH + 16 * dt + 4 * g);
 #pragma unroll
                     for (int rt = 0; rt < NT; ++rt) pa[dt][rt] = bb;
                 }
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks)
+                for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-                    for (int dt = 0; dt < 2; ++dt) {
+                    for (int dt = 0; dt < DT; ++dt) {
                         const bf16x8 w = lds_frag(Wq + (which * E + h * DH + 16 * dt + cq) * LDE + ks * 32 + 8 * g);
 #pragma unroll
                         for (int rt = 0; rt < NT; ++rt) pa[dt][rt] = mma(w, xf[rt][ks], pa[dt][rt]);
                     }
 #pragma unroll
                 for (int rt = 0; rt < NT; ++rt) {
-                    if (which == 0) qf[rt] = pack8(pa[0][rt], pa[1][rt]);
-                    else kf[rt] = pack8(pa[0][rt], pa[1][rt]);
+                    if (which == 0) qf[rt] = pack8(pa[0][rt], DT == 2 ? pa[DT - 1][rt] : zero);
+                    else kf[rt] = pack8(pa[0][rt], DT == 2 ? pa[DT - 1][rt] : zero);
                     if (EXTRAS && a.qkvout && rt * 16 + cq < S) {          // (q leaves unscaled, as the reference's q_proj output)
                         bf16 *dst = a.qkvout + (base + rt * 16 + cq) * (3 * E) + which * E + h * DH + 4 * g;
-                        if (which == 0) { store4_bf16(dst, pa[0][rt] * (1.f / QSCALE)); store4_bf16(dst + 16, pa[1][rt] * (1.f / QSCALE)); }
-                        else store_halves(dst, dst + 16, kf[rt]);          // k: exactly the packed operand
+                        if (which == 0) {
+                            store4_bf16(dst, pa[0][rt] * (1.f / QSCALE));
+                            if (DT == 2) store4_bf16(dst + 16, pa[DT - 1][rt] * (1.f / QSCALE));
+                        } else if (DT == 2) store_halves(dst, dst + 16, kf[rt]);          // k: exactly the packed operand
+                        else store_lo(dst, kf[rt]);
                     }
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
             // ---- v (lane = head feature, registers = 4 tokens): the operand of P V with keys as contraction index ----
-            bf16x8 vr[NP][2];
+            bf16x8 vr[NP][DT];
             {
-                f32x4 va[NT][2];
+                f32x4 va[NT][DT];
 #pragma unroll
-                for (int dt = 0; dt < 2; ++dt) {
+                for (int dt = 0; dt < DT; ++dt) {
                     const float bv = bqkv[2 * E + h * DH + 16 * dt + cq];
 #pragma unroll
                     for (int rt = 0; rt < NT; ++rt) va[rt][dt] = f32x4{bv, bv, bv, bv};
                 }
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks)
+                for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-                    for (int dt = 0; dt < 2; ++dt) {
+                    for (int dt = 0; dt < DT; ++dt) {
                         const bf16x8 wv = lds_frag(Wq + (2 * E + h * DH + 16 * dt + cq) * LDE + ks * 32 + 8 * g);
 #pragma unroll
                         for (int rt = 0; rt < NT; ++rt) va[rt][dt] = mma(xf[rt][ks], wv, va[rt][dt]);
@@ -511,16 +535,16 @@ __global__ __launch_bounds__(NW * 64) void attn_block_fwd_kernel(const AttnFwdAr
 #pragma unroll
                 for (int p = 0; p < NP; ++p)
 #pragma unroll
-                    for (int dt = 0; dt < 2; ++dt) vr[p][dt] = pack8(va[2 * p][dt], (2 * p + 1 < NT) ? va[2 * p + 1][dt] : zero);
+                    for (int dt = 0; dt < DT; ++dt) vr[p][dt] = pack8(va[2 * p][dt], (2 * p + 1 < NT) ? va[2 * p + 1][dt] : zero);
                 if (EXTRAS && a.qkvout) {         // v^T once more (lane = token): 8-byte row stores instead of 2-byte scatters
 #pragma unroll
-                    for (int dt = 0; dt < 2; ++dt) {
+                    for (int dt = 0; dt < DT; ++dt) {
                         f32x4 vt[NT];
                         const f32x4 bb = ld4(bqkv + 2 * E + h * DH + 16 * dt + 4 * g);
 #pragma unroll
                         for (int rt = 0; rt < NT; ++rt) vt[rt] = bb;
 #pragma unroll
-                        for (int ks = 0; ks < 4; ++ks) {
+                        for (int ks = 0; ks < KS; ++ks) {
                             const bf16x8 wv = lds_frag(Wq + (2 * E + h * DH + 16 * dt + cq) * LDE + ks * 32 + 8 * g);
 #pragma unroll
                             for (int rt = 0; rt < NT; ++rt) vt[rt] = mma(wv, xf[rt][ks], vt[rt]);
@@ -558,46 +582,50 @@ __global__ __launch_bounds__(NW * 64) void attn_block_fwd_kernel(const AttnFwdAr
                 const float inv = __builtin_amdgcn_rcpf(x4_sum(sum));
 #pragma unroll
                 for (int j = 0; j < NT; ++j) st[j] *= inv;
-                f32x4 ot[2] = {zero, zero};          // O^T: lane = query, registers = head features 16 dt + 4 g + r
+                f32x4 ot[DT];                        // O^T: lane = query, registers = head features 16 dt + 4 g + r
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) ot[dt] = zero;
 #pragma unroll
                 for (int p = 0; p < NP; ++p) {
                     const bf16x8 pf = pack8(st[2 * p], (2 * p + 1 < NT) ? st[2 * p + 1] : zero);
 #pragma unroll
-                    for (int dt = 0; dt < 2; ++dt) ot[dt] = mma(vr[p][dt], pf, ot[dt]);
+                    for (int dt = 0; dt < DT; ++dt) ot[dt] = mma(vr[p][dt], pf, ot[dt]);
                 }
-                cf[h][it] = pack8(ot[0], ot[1]);
+                if (DT == 1 && (h & 1) == 0) { ot_even[it] = ot[0]; continue; }        // (stored with its odd neighbour)
+                const int kb = h / HB;                                               // the 32-feature block this head completes
+                cf[kb][it] = DT == 2 ? pack8(ot[0], ot[DT - 1]) : pack8(ot_even[it], ot[0]);
                 if (it * 16 + cq < S) {
-                    bf16 *dst = a.ctx + (base + it * 16 + cq) * E + h * DH + 4 * g;
-                    store_halves(dst, dst + 16, cf[h][it]);
+                    bf16 *dst = a.ctx + (base + it * 16 + cq) * E + kb * 32 + 4 * g;
+                    store_halves(dst, dst + 16, cf[kb][it]);
                 }
             }
         }
         if constexpr (!ASM_PF) request(min(b + bstride, a.B - 1));      // in flight under the out-projection and the epilogue
         __builtin_amdgcn_sched_barrier(0);
         // ---- out-projection (+ bias) + residual (identity product on the input fragments), LayerNorm ----
-        f32x4 oa[8][NT];
+        f32x4 oa[ET][NT];
 #pragma unroll
-        for (int nt = 0; nt < 8; ++nt) {
+        for (int nt = 0; nt < ET; ++nt) {
             const f32x4 bv = ld4(bo + 16 * nt + 4 * g), gv = ld4(gin + 16 * nt + 4 * g);
 #pragma unroll
             for (int rt = 0; rt < NT; ++rt) oa[nt][rt] = bv + gv * mma((nt & 1) ? id1 : id0, xf[rt][nt >> 1], zero);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int h = 0; h < H; ++h) {
+        for (int kb = 0; kb < KS; ++kb) {
 #pragma unroll
-            for (int nt = 0; nt < 8; ++nt) {
-                const bf16x8 w = lds_frag(Wo + (16 * nt + cq) * LDE + h * 32 + 8 * g);
+            for (int nt = 0; nt < ET; ++nt) {
+                const bf16x8 w = lds_frag(Wo + (16 * nt + cq) * LDE + kb * 32 + 8 * g);
 #pragma unroll
-                for (int rt = 0; rt < NT; ++rt) oa[nt][rt] = mma(w, cf[h][rt], oa[nt][rt]);
+                for (int rt = 0; rt < NT; ++rt) oa[nt][rt] = mma(w, cf[kb][rt], oa[nt][rt]);
             }
             __builtin_amdgcn_sched_barrier(0);      // keeps the weight-fragment reads of later heads from piling up
         }
 #pragma unroll
         for (int rt = 0; rt < NT; ++rt) {
-            f32x4 z[8];
+            f32x4 z[ET];
 #pragma unroll
-            for (int nt = 0; nt < 8; ++nt) z[nt] = oa[nt][rt];
+            for (int nt = 0; nt < ET; ++nt) z[nt] = oa[nt][rt];
             ln_store(z, base + rt * 16 + cq, rt * 16 + cq < S, gout, bout, a.o, g);
         }
     }
@@ -677,7 +705,7 @@ int launch_attn_block_fwd(const void *nin, const float *gin, const float *bin, c
     a.qkvout = static_cast<bf16 *>(qkvout);
     const int nt = ceil_div(S, 16);
     static const int nw_env = [] { const char *e = getenv("MIVIT_ATTN_BLOCK_WAVES"); return e ? atoi(e) : 0; }();
-    const int nw = nw_env == 8 || nw_env == 4 ? nw_env : (nt >= 3 ? 4 : 8);
+    const int nw = nw_env == 8 || nw_env == 4 ? nw_env : (nt >= 3 && E == 128 ? 4 : 8);
     const int grid = std::min(256, ceil_div(B, nw));
     ProfScope prof(s);
 #define ATT_LAUNCH3(NT_, EX_, NW_)                                                               \

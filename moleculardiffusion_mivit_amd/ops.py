@@ -341,10 +341,21 @@ def deepresnet_infer(x, dtype, eps, running, params, chunk_frames: int = 8192):
 
 
 # ---------------------------------------------------------------------------------------------------------------
-# fused encoder-layer blocks (csrc/fused_fwd.hip), bf16 mode, E = 128 / F = 256 / 4 heads
+# fused encoder-layer blocks (csrc/fused_fwd.hip / fused_bwd.hip), bf16 mode, 4 heads, E = 128 / F = 256 or E = 64 / F = 128
 # ---------------------------------------------------------------------------------------------------------------
+def _fused_entry(name: str, embed_dim: int, hidden_dim=None):
+    """the C entry point of a fused block for this layer width (the kernels are compiled per width: anything else is refused
+    here, before a launch that would index past the tensors)"""
+    if embed_dim not in (64, 128) or (hidden_dim is not None and hidden_dim != 2 * embed_dim):
+        raise ValueError(f"{name}: fused blocks exist for E=128/F=256 and E=64/F=128, got E={embed_dim}"
+                         + (f" F={hidden_dim}" if hidden_dim is not None else ""))
+    return getattr(N.lib, name + ("_w64" if embed_dim == 64 else ""))
+
+
 def fused_layer_supported(embed_dim: int, hidden_dim: int, num_heads: int, tokens: int) -> bool:
-    return bool(N.lib.mivit_fused_layer_supported(N.BF16, embed_dim, hidden_dim, num_heads, tokens))
+    if embed_dim not in (64, 128):
+        return False
+    return bool(_fused_entry("mivit_fused_layer_supported", embed_dim)(N.BF16, embed_dim, hidden_dim, num_heads, tokens))
 
 
 def _f32(t):
@@ -366,7 +377,9 @@ def attn_block_fwd(n_in, gamma_in, beta_in, Wqkv, bqkv, Wo, bo, gamma_out, beta_
                    qkv=torch.empty(B, S, 3 * E, dtype=torch.bfloat16, device=dev))
     gi, bi, go, bo_ = _f32(gamma_in), _f32(beta_in), _f32(gamma_out), _f32(beta_out)
     bq, bo2 = _f32(bqkv), _f32(bo)
-    N.check(N.lib.mivit_attn_block_fwd(_p(n_in), _p(gi), _p(bi), _p(Wqkv.contiguous()), _p(bq), _p(Wo.contiguous()), _p(bo2),
+    if tuple(Wqkv.shape) != (3 * E, E) or tuple(Wo.shape) != (E, E):
+        raise ValueError(f"attn_block_fwd: weights {tuple(Wqkv.shape)}, {tuple(Wo.shape)} do not match E={E}")
+    N.check(_fused_entry("mivit_attn_block_fwd", E)(_p(n_in), _p(gi), _p(bi), _p(Wqkv.contiguous()), _p(bq), _p(Wo.contiguous()), _p(bo2),
                                        _p(go), _p(bo_), B, S, _p(out["ctx"]), _p(out["n"]), _p(out["rstd"]), _p(out.get("x")),
                                        _p(out.get("z")), _p(out.get("mean")), _p(out.get("qkv")), _s(n_in)),
             "mivit_attn_block_fwd")
@@ -387,7 +400,9 @@ def mlp_block_fwd(n_in, gamma_in, beta_in, W1, b1, W2, b2, gamma_out, beta_out, 
                    h=torch.empty(M, Fh, dtype=torch.bfloat16, device=dev), u=torch.empty(M, Fh, dtype=torch.bfloat16, device=dev))
     gi, bi, go, bo_ = _f32(gamma_in), _f32(beta_in), _f32(gamma_out), _f32(beta_out)
     b1f, b2f = _f32(b1), _f32(b2)
-    N.check(N.lib.mivit_mlp_block_fwd(_p(n_in), _p(gi), _p(bi), _p(W1.contiguous()), _p(b1f), _p(W2.contiguous()), _p(b2f),
+    if tuple(W1.shape) != (Fh, E) or tuple(W2.shape) != (E, Fh):
+        raise ValueError(f"mlp_block_fwd: weights {tuple(W1.shape)}, {tuple(W2.shape)} do not match E={E}")
+    N.check(_fused_entry("mivit_mlp_block_fwd", E, Fh)(_p(n_in), _p(gi), _p(bi), _p(W1.contiguous()), _p(b1f), _p(W2.contiguous()), _p(b2f),
                                       _p(go), _p(bo_), M, act, _p(out["n"]), _p(out["rstd"]), _p(out.get("x")), _p(out.get("z")),
                                       _p(out.get("mean")), _p(out.get("h")), _p(out.get("u")), _s(n_in)), "mivit_mlp_block_fwd")
     return out
@@ -403,11 +418,13 @@ def mlp_block_bwd(dy, n2, rstd2, gamma2, n1, gamma1, beta1, W1, b1, W2, act=N.AC
     out = {"dx1": torch.empty(M, E, dtype=torch.bfloat16, device=dev), "dW1": torch.empty(Fh, E, device=dev),
            "db1": torch.empty(Fh, device=dev), "dW2": torch.empty(E, Fh, device=dev), "db2": torch.empty(E, device=dev),
            "dgamma2": torch.empty(E, device=dev), "dbeta2": torch.empty(E, device=dev)}
-    nbytes = N.lib.mivit_mlp_block_bwd_workspace_bytes(M)
+    if tuple(W1.shape) != (Fh, E) or tuple(W2.shape) != (E, Fh):
+        raise ValueError(f"mlp_block_bwd: weights {tuple(W1.shape)}, {tuple(W2.shape)} do not match E={E}")
+    nbytes = _fused_entry("mivit_mlp_block_bwd_workspace_bytes", E, Fh)(M)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     args = [dy.contiguous(), n2.contiguous(), _f32(rstd2), _f32(gamma2), n1.contiguous(), _f32(gamma1), _f32(beta1), W1.contiguous(),
             _f32(b1), W2.contiguous()]
-    N.check(N.lib.mivit_mlp_block_bwd(*[_p(t) for t in args], M, act, _p(out["dx1"]), _p(out["dW1"]), _p(out["db1"]), _p(out["dW2"]),
+    N.check(_fused_entry("mivit_mlp_block_bwd", E, Fh)(*[_p(t) for t in args], M, act, _p(out["dx1"]), _p(out["dW1"]), _p(out["db1"]), _p(out["dW2"]),
                                       _p(out["db2"]), _p(out["dgamma2"]), _p(out["dbeta2"]), _p(ws), nbytes, _s(dy)),
             "mivit_mlp_block_bwd")
     return out
@@ -422,9 +439,11 @@ def attn_out_bwd(dy, n1, rstd1, gamma1, ctx, Wo):
     out = {"dz1": torch.empty(M, E, dtype=torch.bfloat16, device=dev), "dctx": torch.empty(M, E, dtype=torch.bfloat16, device=dev),
            "dWo": torch.empty(E, E, device=dev), "dbo": torch.empty(E, device=dev), "dgamma1": torch.empty(E, device=dev),
            "dbeta1": torch.empty(E, device=dev)}
-    nbytes = N.lib.mivit_attn_out_bwd_workspace_bytes(M)
+    if tuple(Wo.shape) != (E, E):
+        raise ValueError(f"attn_out_bwd: weight {tuple(Wo.shape)} does not match E={E}")
+    nbytes = _fused_entry("mivit_attn_out_bwd_workspace_bytes", E)(M)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     args = [dy.contiguous(), n1.contiguous(), _f32(rstd1), _f32(gamma1), ctx.contiguous(), Wo.contiguous()]
-    N.check(N.lib.mivit_attn_out_bwd(*[_p(t) for t in args], M, _p(out["dz1"]), _p(out["dctx"]), _p(out["dWo"]), _p(out["dbo"]),
+    N.check(_fused_entry("mivit_attn_out_bwd", E)(*[_p(t) for t in args], M, _p(out["dz1"]), _p(out["dctx"]), _p(out["dWo"]), _p(out["dbo"]),
                                      _p(out["dgamma1"]), _p(out["dbeta1"]), _p(ws), nbytes, _s(dy)), "mivit_attn_out_bwd")
     return out

@@ -306,14 +306,18 @@ def main():
         errs += check_m0_nop("embed.hip", ke)
     # ---- the other users of the written-out DMA ----
     for src in ("fused_fwd.hip", "attention_fast.hip"):
-        for extra in ((), ("-DMIVIT_ELEM_F16",)):
+        for extra in ((), ("-DMIVIT_ELEM_F16",), ("-DMIVIT_WIDTH64",), ("-DMIVIT_WIDTH64", "-DMIVIT_ELEM_F16")):
+            if src == "attention_fast.hip" and "-DMIVIT_WIDTH64" in extra:
+                continue
             kd = kernels(device_asm(src, extra))
             errs += check_asm_reads_mfma(src, kd)
             for n, (lines, meta) in kd.items():
-                if re.search(r"attn_block_fwd_kernelILi[12]E", n):          # (one or two row tiles: the written-out form)
+                # (width 128: one or two row tiles use the written-out form; width 64: every tile count)
+                if re.search(r"attn_block_fwd_kernelILi[12]E" if "-DMIVIT_WIDTH64" not in extra else r"attn_block_fwd_kernel", n):
                     errs += check_asm_load_window(n, lines)
-    for src in ("rowstream.hip", "gemm_dma.hip", "wgrad_dma.hip", "fused_bwd.hip"):
-        kd = kernels(device_asm(src))
+    for src, extra in (("rowstream.hip", ()), ("gemm_dma.hip", ()), ("wgrad_dma.hip", ()), ("fused_bwd.hip", ()),
+                       ("fused_bwd.hip", ("-DMIVIT_WIDTH64",))):
+        kd = kernels(device_asm(src, extra))
         errs += check_m0_nop(src, kd)
         errs += check_asm_reads_mfma(src, kd)
         for n, (lines, meta) in kd.items():
@@ -322,7 +326,8 @@ def main():
             #  stricter, never looser)
             if "mlp_block_bwd" in n or "attn_out_bwd" in n:
                 c = count_in_loop(lines, r"^global_store_dwordx2\b")
-                need = 2 if "mlp_block_bwd8" in n else 4          # (the eight-wave kernel: one row store per row tile and wave)
+                # (the eight-wave kernel, and both kernels at width 64: one row store per row tile and wave -- NROWST in the source)
+                need = 2 if "mlp_block_bwd8" in n or extra else 4
                 if c < need:
                     errs.append(f"{n}: {c} global_store_dwordx2 in the tile loop; wait_vm<{need}> counts on >= {need} row stores per tile")
             if "rowstream_kernel" in n:

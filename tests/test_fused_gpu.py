@@ -13,6 +13,17 @@ pytestmark = pytest.mark.gpu
 E, FH, H = 128, 256, 4
 
 
+@pytest.fixture(autouse=True, params=[128, 64], ids=["w128", "w64"])
+def _layer_width(request):
+    """every test of this file runs at both widths the fused blocks are compiled for (elem.h: E = 128 / F = 256 / head dim 32
+    and the reference's shipped E = 64 / F = 128 / head dim 16, Experiments/Framerate/trainSettingsFramerate.py:42-47)"""
+    global E, FH
+    old = (E, FH)
+    E, FH = request.param, 2 * request.param
+    yield request.param
+    E, FH = old
+
+
 def _rel(a, b):
     a, b = a.double().cpu(), b.double().cpu()
     return float((a - b).abs().max() / (b.abs().max() + 1e-30))
@@ -94,8 +105,8 @@ def test_mlp_block_fwd_exact_integers():
 def _attn_ref(x, xb, Wqkv, bqkv, Wo, bo, S):
     B = x.shape[0]
     qkv = F.linear(xb, Wqkv.float(), bqkv)
-    q, k, v = [_bf(t).float().view(B, S, H, 32).transpose(1, 2) for t in qkv.split(E, dim=-1)]
-    p = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(32.0), dim=-1)
+    q, k, v = [_bf(t).float().view(B, S, H, E // H).transpose(1, 2) for t in qkv.split(E, dim=-1)]
+    p = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(float(E // H)), dim=-1)
     ctx = (_bf(p).float() @ v).transpose(1, 2).reshape(B, S, E)
     z = xb + F.linear(_bf(ctx).float(), Wo.float(), bo)
     return qkv, ctx, z
