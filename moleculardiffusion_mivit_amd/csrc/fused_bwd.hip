@@ -54,9 +54,11 @@ constexpr int OFF_DZ = OFF_X + R * LDE * 2;          // [R][LDE]  dz2 rows
 constexpr int OFF_DH = OFF_DZ + R * LDE * 2;         // [F][R]    dh TRANSPOSED: one 64-byte row of the tile's 32 rows per hidden unit (see dht_off)
 constexpr int OFF_VEC = OFF_DH + F * R * 2;          // b1 [F], gamma2 [E], gamma1 [E], beta1 [E] fp32
 constexpr int OFF_ACC = OFF_VEC + (F + 3 * E) * 4;               // [6][NT] float4: running column sums of the element-wise phase (dgamma2, dbeta2, db2)
-constexpr int OFF_STG = OFF_ACC + 6 * NT * 16;        // [6][NW][64] x 16 B: next tile's dy / n2 / n1 chunks, landed by LDS-DMA (thread-private slots)
-constexpr int OFF_RST = OFF_STG + 6 * NT * 16;       // [2][NT] floats: rstd2 of the next tile's two rows per thread (LDS-DMA, thread-private slots)
-constexpr int LDS_BYTES = OFF_RST + 2 * NT * 4;
+constexpr int OFF_STG = OFF_ACC + 6 * NT * 16;        // [3 RPT][NW][64] x 16 B: next tile's dy / n2 / n1 chunks, landed by LDS-DMA (thread-private slots)
+constexpr int OFF_RST = OFF_STG + 3 * RPT * NT * 16; // [RPT][NT] floats: rstd2 of the next tile's rows per thread (LDS-DMA, thread-private slots)
+constexpr int LDS_BYTES = OFF_RST + RPT * NT * 4;
+// (Width 64 fits two workgroups per CU -- 75 KB of LDS, 190 registers x 4 waves.  Measured at the Framerate shape, 127 k rows:
+//  grids of 512 give 67.2 against 65.2 us per launch, and twice the slab traffic: not used.)
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 
 // slab layout per workgroup (floats)
@@ -750,9 +752,9 @@ __global__ __launch_bounds__(NT8) void mlp_block_bwd8_kernel(const MlpBwdArgs a)
 // register footprint -> two workgroups per CU cover each other's barriers.
 // ================================================================================================================
 constexpr int AO_OFF_DZ = 0, AO_OFF_CT = AO_OFF_DZ + R * LDE * 2, AO_OFF_STG = AO_OFF_CT + R * LDE * 2;
-constexpr int AO_OFF_RED = AO_OFF_STG + 6 * NT * 16;            // [NW][3][E] floats: end-of-launch fold of the column sums
-constexpr int AO_OFF_RST = AO_OFF_RED + NW * 3 * E * 4;        // [2][NT] floats: rstd1 of the next tile's rows
-constexpr int AO_LDS = AO_OFF_RST + 2 * NT * 4;
+constexpr int AO_OFF_RED = AO_OFF_STG + 3 * RPT * NT * 16;      // [NW][3][E] floats: end-of-launch fold of the column sums
+constexpr int AO_OFF_RST = AO_OFF_RED + NW * 3 * E * 4;        // [RPT][NT] floats: rstd1 of the next tile's rows
+constexpr int AO_LDS = AO_OFF_RST + RPT * NT * 4;
 constexpr int AO_SL_W = 0, AO_SL_B = E * E, AO_SL_G = AO_SL_B + E, AO_SL_BE = AO_SL_G + E, AO_SL_TOTAL = AO_SL_BE + E;   // arena order:
                                                                 // out_proj.weight, out_proj.bias, norm1.weight, norm1.bias
 struct AttnOutBwdArgs {

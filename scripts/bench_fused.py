@@ -1,5 +1,6 @@
-"""Micro-benchmark of the fused encoder-layer block kernels at the headline shape (B sequences of 33 tokens, E=128).
-    python scripts/bench_fused.py [B]
+"""Micro-benchmark of the fused encoder-layer block kernels at the headline shape (B sequences of 33 tokens, E=128) or, with
+E = 64, the reference's shipped width (Framerate shape: 31 tokens).
+    python scripts/bench_fused.py [B] [E] [S]
 Prints microseconds per launch, achieved HBM GB/s on the algorithmic bytes and MFMA TFLOP/s on the algorithmic FLOPs."""
 import math
 import os
@@ -11,7 +12,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from moleculardiffusion_mivit_amd import ops  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
-S, E, FH = 33, 128, 256
+E = int(sys.argv[2]) if len(sys.argv) > 2 else 128
+S = int(sys.argv[3]) if len(sys.argv) > 3 else (33 if E == 128 else 31)
+FH = 2 * E
 dev = "cuda"
 g = torch.Generator(device=dev).manual_seed(0)
 rn = lambda *s, sc=1.0: torch.randn(*s, device=dev, generator=g) * sc
@@ -47,7 +50,7 @@ _bq, _bo = bqkv.float(), bo.float()
 
 
 def attn_train():       # what the engine launches in training: ctx, n, rstd + the q|k|v store, nothing else
-    N.check(N.lib.mivit_attn_block_fwd(_p(n_in), _p(gi), _p(bi), _p(Wqkv), _p(_bq), _p(Wo), _p(_bo), _p(gi), _p(bi), B, S, _p(_ab["ctx"]),
+    N.check(ops._fused_entry("mivit_attn_block_fwd", E)(_p(n_in), _p(gi), _p(bi), _p(Wqkv), _p(_bq), _p(Wo), _p(_bo), _p(gi), _p(bi), B, S, _p(_ab["ctx"]),
                                        _p(_ab["n"]), _p(_ab["rstd"]), None, None, None, _p(_ab["qkv"]),
                                        ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "attn_block_fwd")
 

@@ -51,6 +51,17 @@ def _rel(a, b):
     return float((a.double() - b.double()).abs().max() / (b.double().abs().max() + 1e-30))
 
 
+@pytest.fixture(params=[128, 64], ids=["w128", "w64"])
+def layer_width(request):
+    """the fused encoder-layer blocks exist for two layer widths (csrc/elem.h): E = 128 / F = 256 / head dim 32 and the
+    reference's shipped E = 64 / F = 128 / head dim 16"""
+    global E, FH
+    old = (E, FH)
+    E, FH = request.param, 2 * request.param
+    yield request.param
+    E, FH = old
+
+
 @pytest.fixture
 def embed_variant(request):
     from moleculardiffusion_mivit_amd import _native as N
@@ -191,7 +202,7 @@ def _ln_hat(z):
 
 
 @pytest.mark.parametrize("B,S", [(2600, 33), (1100, 61)])
-def test_attn_block_fwd_bench_scale(B, S):
+def test_attn_block_fwd_bench_scale(B, S, layer_width):
     """One persistent workgroup per CU, one wave per sequence: 256 x 4 sequences per pass -> B = 2600 is 2.5 passes (reference
     models.py:33-59,100-102; plain torch fp32 on the bf16-rounded operands, all rows)."""
     from moleculardiffusion_mivit_amd import ops
@@ -202,8 +213,8 @@ def test_attn_block_fwd_bench_scale(B, S):
     go, bo2 = 1.0 + 0.3 * _randn((E,), 18), 0.2 * _randn((E,), 19)
     xb = _bf(n_in.float() * gi + bi).float()
     qkv = F.linear(xb, Wqkv.float(), bqkv)
-    q, k, v = [_bf(t).float().view(B, S, H, 32).transpose(1, 2) for t in qkv.split(E, dim=-1)]
-    p = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(32.0), dim=-1)
+    q, k, v = [_bf(t).float().view(B, S, H, E // H).transpose(1, 2) for t in qkv.split(E, dim=-1)]
+    p = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(float(E // H)), dim=-1)
     ctx = (_bf(p).float() @ v).transpose(1, 2).reshape(B, S, E)
     z = xb + F.linear(_bf(ctx).float(), Wo.float(), bo)
     nh, mu, rstd = _ln_hat(z)
@@ -220,7 +231,7 @@ def test_attn_block_fwd_bench_scale(B, S):
     assert torch.equal(sub["n"], lean["n"][B - 70:]) and torch.equal(sub["ctx"], lean["ctx"][B - 70:])
 
 
-def test_attn_block_fwd_uniform_softmax_exact_bench_scale():
+def test_attn_block_fwd_uniform_softmax_exact_bench_scale(layer_width):
     """Zero q/k weights -> uniform probabilities; S = 32 and small-integer v make ctx exact up to one bf16 rounding."""
     from moleculardiffusion_mivit_amd import ops
     B, S = 2500, 32
@@ -240,7 +251,7 @@ def test_attn_block_fwd_uniform_softmax_exact_bench_scale():
 
 
 @pytest.mark.parametrize("act", [1, 3])
-def test_mlp_block_fwd_bench_scale(act):
+def test_mlp_block_fwd_bench_scale(act, layer_width):
     """256 persistent workgroups x 8 waves x 32 rows = 65 536 rows per pass: 140 017 rows = 2.1 passes, ragged last tile."""
     from moleculardiffusion_mivit_amd import ops
     M = 140000 + 17
@@ -267,7 +278,7 @@ def test_mlp_block_fwd_bench_scale(act):
     assert torch.equal(sub["n"], lean["n"][M - 1000:])          # rows are independent
 
 
-def test_mlp_block_fwd_exact_integers_bench_scale():
+def test_mlp_block_fwd_exact_integers_bench_scale(layer_width):
     from moleculardiffusion_mivit_amd import ops
     M = 140000 + 17
     n_in = _ints((M, E), -2, 2, 31)
@@ -303,7 +314,7 @@ def mlp_bwd_waves(request):
 
 
 @pytest.mark.parametrize("act", [1, 3])
-def test_mlp_block_bwd_bench_scale(act, mlp_bwd_waves):
+def test_mlp_block_bwd_bench_scale(act, mlp_bwd_waves, layer_width):
     """256 persistent workgroups x 32-row tiles: 140 017 rows = 17+ tiles per workgroup, ragged last tile (reference autograd of
     models.py:72-77,104-106 written out in fp32, all rows)."""
     from moleculardiffusion_mivit_amd import ops
@@ -333,7 +344,7 @@ def test_mlp_block_bwd_bench_scale(act, mlp_bwd_waves):
         assert torch.equal(out[k], again[k]), k
 
 
-def test_attn_out_bwd_bench_scale():
+def test_attn_out_bwd_bench_scale(layer_width):
     """512 workgroups x 32-row tiles: 140 017 rows = 8+ tiles per workgroup (reference models.py:57,100-102)."""
     from moleculardiffusion_mivit_amd import ops
     M = 140000 + 17
@@ -356,7 +367,7 @@ def test_attn_out_bwd_bench_scale():
         assert torch.equal(out[k], again[k]), k
 
 
-def test_attn_out_bwd_exact_integers_bench_scale():
+def test_attn_out_bwd_exact_integers_bench_scale(layer_width):
     """gamma = 1, rstd = 1 and dy rows with zero mean and zero projection on n make dz1 = dy exactly; small integers make
     dctx / dWo exact: a tile that arrived late or a stale staging slot is an exact mismatch."""
     from moleculardiffusion_mivit_amd import ops

@@ -101,16 +101,25 @@ def _run_everything():
         N.lib.mivit_gemm_dma_set_variant(old)
         out[f"gemm_dma_fwd_v{v}"], out[f"gemm_dma_dgrad_v{v}"] = y, dxw
     # --- fused backward blocks ---
-    args = (_bf(_randn((M, E), 21)), _bf(_randn((M, E), 22)), 1 + 0.1 * _randn((M,), 23).abs(), 1 + 0.1 * _randn((E,), 24),
-            _bf(_randn((M, E), 25)), 1 + 0.1 * _randn((E,), 26), 0.1 * _randn((E,), 27), _bf(_randn((FH, E), 28, 0.1)),
-            0.1 * _randn((FH,), 29), _bf(_randn((E, FH), 30, 0.1)))
-    for waves in (8, 4):           # both kernels behind the entry (hidden units split over 8 / 4 waves)
-        old = N.lib.mivit_mlp_block_bwd_set_waves(waves)
-        for k, v in ops.mlp_block_bwd(*args).items():
-            out[f"mlp_bwd{waves}_" + k] = v
-        N.lib.mivit_mlp_block_bwd_set_waves(old)
-    for k, v in ops.attn_out_bwd(args[0], args[1], args[2], args[3], args[4], _bf(_randn((E, E), 31, 0.1))).items():
-        out["attn_out_bwd_" + k] = v
+    for Ew, FHw in ((E, FH), (64, 128)):          # both layer widths the blocks are compiled for (csrc/elem.h)
+        args = (_bf(_randn((M, Ew), 21)), _bf(_randn((M, Ew), 22)), 1 + 0.1 * _randn((M,), 23).abs(), 1 + 0.1 * _randn((Ew,), 24),
+                _bf(_randn((M, Ew), 25)), 1 + 0.1 * _randn((Ew,), 26), 0.1 * _randn((Ew,), 27), _bf(_randn((FHw, Ew), 28, 0.1)),
+                0.1 * _randn((FHw,), 29), _bf(_randn((Ew, FHw), 30, 0.1)))
+        for waves in (8, 4) if Ew == 128 else (4,):          # both kernels behind the entry (hidden units split over 8 / 4 waves)
+            old = N.lib.mivit_mlp_block_bwd_set_waves(waves)
+            for k, v in ops.mlp_block_bwd(*args).items():
+                out[f"mlp_bwd{waves}_w{Ew}_" + k] = v
+            N.lib.mivit_mlp_block_bwd_set_waves(old)
+        for k, v in ops.attn_out_bwd(args[0], args[1], args[2], args[3], args[4], _bf(_randn((Ew, Ew), 31, 0.1))).items():
+            out[f"attn_out_bwd_w{Ew}_" + k] = v
+        # the attention block's forward: one / two row tiles order their row prefetch with a counted wait (width 64: every tile count)
+        for S_ in (31, 61):
+            Bq = 2600
+            o = ops.attn_block_fwd(_bf(_randn((Bq, S_, Ew), 32)), None, None, _bf(_randn((3 * Ew, Ew), 33, 0.1)), 0.1 * _randn((3 * Ew,), 34),
+                                   _bf(_randn((Ew, Ew), 35, 0.1)), 0.1 * _randn((Ew,), 36), 1 + 0.1 * _randn((Ew,), 37), 0.1 * _randn((Ew,), 38),
+                                   extras=(S_ == 31))
+            for k, v in o.items():
+                out[f"attn_fwd_w{Ew}_S{S_}_" + k] = v
     # --- the whole model at the bench shape, B = 4096: forward, loss, backward ---
     # (bf16, and fp16: the same kernels compiled for IEEE half -- elem.h -- with their own counted waits in the object code)
     cfg = orc.MiViTConfig(embedding="linear", patch_size=64, embed_dim=128, num_heads=4, hidden_dim=256, num_layers=4)
@@ -125,7 +134,7 @@ def _run_everything():
             out[f"model_{prec}_grad_" + k] = p.grad.detach().clone()
         torch.cuda.synchronize()
         del m
-    # the 64-wide model (wave-stream K = 64 / 192, wgrad_small) at the Framerate shape
+    # the 64-wide model (fused blocks of width 64; wave-stream K = 192 data gradient, wgrad_small) at the Framerate shape
     cfg3 = orc.MiViTConfig(embedding="linear", patch_size=13, embed_dim=64, num_heads=4, hidden_dim=128, num_layers=2)
     m = build_product_model(cfg3, "bf16", orc.closed_form_params(cfg3))
     x3 = 0.2 + 0.06 * _randn((4096, 30, 13, 13), 43)
