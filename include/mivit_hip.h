@@ -179,6 +179,18 @@ int mivit_attn_out_bwd(const void *dy, const void *n1, const float *rstd1, const
                        const void *Wo_bf16, int M, void *dz1, void *dctx, float *dWo, float *dbo, float *dgamma1,
                        float *dbeta1, void *workspace, size_t workspace_bytes, void *stream);
 
+/* q|k|v projection backward in one pass over dqkv (autograd of qkv = x Wqkv^T + bqkv, helpers/models.py:42-44, joined by the
+ * residual branch's gradient, :100-102), csrc/fused_bwd.hip:
+ * in : dqkv [M,3E] bf16 (from mivit_attention_bwd), x [M,E] bf16 (the projection's input rows), Wqkv bf16 [3E,E], res [M,E] bf16;
+ * out: dx = dqkv Wqkv + res [M,E] bf16;  dW = dqkv^T x [3E,E], db = column sums of dqkv [3E], fp32 (overwritten).  Deterministic.
+ * E = 128 (and E = 64 as ..._w64). */
+size_t mivit_qkv_bwd_workspace_bytes(int M);
+int mivit_qkv_bwd(const void *dqkv, const void *x, const void *Wqkv_bf16, const void *res, int M, void *dx, float *dW, float *db,
+                  void *workspace, size_t workspace_bytes, void *stream);
+size_t mivit_qkv_bwd_workspace_bytes_w64(int M);
+int mivit_qkv_bwd_w64(const void *dqkv, const void *x, const void *Wqkv_bf16, const void *res, int M, void *dx, float *dW, float *db,
+                      void *workspace, size_t workspace_bytes, void *stream);
+
 /* The same five operators for the reference's shipped layer width: E = 64, F = 128, 4 heads of 16
  * (Experiments/Framerate/trainSettingsFramerate.py:42-47, Experiments/ImagesFeatures/...:112-188): csrc/fused_fwd.hip and
  * csrc/fused_bwd.hip compiled a second time with -DMIVIT_WIDTH64.  Same arguments, layouts and optional outputs. */
@@ -385,7 +397,8 @@ enum {
     MIVIT_PROF_ATTN_CORE_BWD = 14,  /* attention core backward (attention_fast.hip)                                       */
     MIVIT_PROF_QKV_WGRAD = 15,      /* q|k|v weight gradient (wgrad_dma.hip) + affine fix-up                              */
     MIVIT_PROF_QKV_DGRAD = 16,      /* q|k|v data gradient + residual gradient (rowstream.hip)                            */
-    MIVIT_PROF_NUM_TAGS = 17
+    MIVIT_PROF_QKV_BWD = 17,        /* both of them in one pass over dqkv (fused_bwd.hip::qkv_bwd_kernel) + affine fix-up  */
+    MIVIT_PROF_NUM_TAGS = 18
 };
 int mivit_profile_enable(uint64_t tag_mask);   /* 0 disables */
 int mivit_profile_collect(int tag, double *total_ms, int *count);

@@ -124,6 +124,10 @@ SYMBOLS = {
     "mivit_render_frames": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "mivit_attn_out_bwd_workspace_bytes": (c_size_t, [c_int]),
     "mivit_attn_out_bwd": (c_int, [c_void_p] * 6 + [c_int] + [c_void_p] * 7 + [c_size_t, c_void_p]),
+    "mivit_qkv_bwd_workspace_bytes": (c_size_t, [c_int]),
+    "mivit_qkv_bwd": (c_int, [c_void_p] * 4 + [c_int] + [c_void_p] * 4 + [c_size_t, c_void_p]),
+    "mivit_qkv_bwd_workspace_bytes_w64": (c_size_t, [c_int]),
+    "mivit_qkv_bwd_w64": (c_int, [c_void_p] * 4 + [c_int] + [c_void_p] * 4 + [c_size_t, c_void_p]),
     "mivit_fused_layer_supported_w64": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "mivit_attn_block_fwd_w64": (c_int, [c_void_p] * 9 + [c_int, c_int] + [c_void_p] * 8),
     "mivit_mlp_block_fwd_w64": (c_int, [c_void_p] * 9 + [c_int, c_int] + [c_void_p] * 8),
@@ -137,7 +141,7 @@ SYMBOLS = {
 }
 PROF_TAGS = ["embed_fwd", "embed_wgrad", "linear_fwd", "linear_dgrad", "linear_wgrad", "attn_fwd", "attn_bwd",
              "ln_fwd", "ln_bwd", "op", "attn_block_fwd", "mlp_block_fwd", "mlp_block_bwd", "attn_out_bwd", "attn_core_bwd",
-             "qkv_wgrad", "qkv_dgrad"]
+             "qkv_wgrad", "qkv_dgrad", "qkv_bwd"]
 
 
 class MivitError(RuntimeError):

@@ -68,6 +68,8 @@ __device__ __forceinline__ float elem_hi(uint32_t w) { return __uint_as_float(w 
 #define launch_mlp_block_bwd MIVIT_FUSED_NAME(launch_mlp_block_bwd)
 #define attn_out_bwd_ws_bytes MIVIT_FUSED_NAME(attn_out_bwd_ws_bytes)
 #define launch_attn_out_bwd MIVIT_FUSED_NAME(launch_attn_out_bwd)
+#define qkv_bwd_ws_bytes MIVIT_FUSED_NAME(qkv_bwd_ws_bytes)
+#define launch_qkv_bwd MIVIT_FUSED_NAME(launch_qkv_bwd)
 #endif
 #if defined(MIVIT_WIDTH64) && !defined(MIVIT_ELEM_F16)
 #define mivit_fused_layer_supported mivit_fused_layer_supported_w64
@@ -77,4 +79,6 @@ __device__ __forceinline__ float elem_hi(uint32_t w) { return __uint_as_float(w 
 #define mivit_mlp_block_bwd mivit_mlp_block_bwd_w64
 #define mivit_attn_out_bwd_workspace_bytes mivit_attn_out_bwd_workspace_bytes_w64
 #define mivit_attn_out_bwd mivit_attn_out_bwd_w64
+#define mivit_qkv_bwd_workspace_bytes mivit_qkv_bwd_workspace_bytes_w64
+#define mivit_qkv_bwd mivit_qkv_bwd_w64
 #endif

@@ -29,7 +29,10 @@
     int launch_mlp_block_bwd##SFX(const void *dy, const void *n2, const float *rstd2, const float *gamma2, const void *n1,         \
                                   const float *gamma1, const float *beta1, const void *W1, const float *b1, const void *W2, int M, \
                                   int act, void *dx1, float *dW1, float *db1, float *dW2, float *db2, float *dgamma2,              \
-                                  float *dbeta2, void *ws, size_t ws_bytes, hipStream_t s);
+                                  float *dbeta2, void *ws, size_t ws_bytes, hipStream_t s);                                        \
+    size_t qkv_bwd_ws_bytes##SFX(int M);                                                                                           \
+    int launch_qkv_bwd##SFX(const void *dqkv, const void *x, const void *Wqkv, const void *res, int M, void *dx, float *dW,        \
+                            float *db, void *ws, size_t ws_bytes, hipStream_t s);
 MIVIT_FUSED_DECLS()
 MIVIT_FUSED_DECLS(_f16)
 MIVIT_FUSED_DECLS(_w64)
@@ -44,10 +47,12 @@ struct FusedOps {
     decltype(&launch_attn_out_bwd) attn_out_bwd;
     decltype(&mlp_block_bwd_ws_bytes) mlp_bwd_ws;
     decltype(&attn_out_bwd_ws_bytes) attn_out_bwd_ws;
+    decltype(&launch_qkv_bwd) qkv_bwd;
+    decltype(&qkv_bwd_ws_bytes) qkv_bwd_ws;
 };
 #define MIVIT_FUSED_TABLE(SFX)                                                                                                \
     {fused_layer_supported##SFX, launch_attn_block_fwd##SFX, launch_mlp_block_fwd##SFX, launch_mlp_block_bwd##SFX,            \
-     launch_attn_out_bwd##SFX, mlp_block_bwd_ws_bytes##SFX, attn_out_bwd_ws_bytes##SFX}
+     launch_attn_out_bwd##SFX, mlp_block_bwd_ws_bytes##SFX, attn_out_bwd_ws_bytes##SFX, launch_qkv_bwd##SFX, qkv_bwd_ws_bytes##SFX}
 static const FusedOps kFusedBf16 = MIVIT_FUSED_TABLE(), kFusedF16 = MIVIT_FUSED_TABLE(_f16), kFusedBf16W64 = MIVIT_FUSED_TABLE(_w64),
                       kFusedF16W64 = MIVIT_FUSED_TABLE(_w64_f16);
 #undef MIVIT_FUSED_TABLE
@@ -176,7 +181,10 @@ Ws make_ws(const mivit_plan *p, int B, int T, bool bwd) {
             if (b > wg) wg = b;
         };
         mx((int)M, 3 * E, E); mx((int)M, E, E); mx((int)M, F, E); mx((int)M, E, F);
-        if (fused) wg = std::max(std::max(wg, fused_ops(c.dtype, E)->mlp_bwd_ws((int)M)), fused_ops(c.dtype, E)->attn_out_bwd_ws((int)M));
+        if (fused) {
+            const FusedOps *fo = fused_ops(c.dtype, E);
+            wg = std::max(std::max(wg, fo->mlp_bwd_ws((int)M)), std::max(fo->attn_out_bwd_ws((int)M), fo->qkv_bwd_ws((int)M)));
+        }
         if (c.embedding != MIVIT_EMBED_EXTERNAL) {
             mx((int)Mt, E, c.patch_size * c.patch_size);
             if ((c.dtype == MIVIT_F16 ? embed_dma_supported_f16 : embed_dma_supported)(c.dtype, (int)Mt, c.patch_size * c.patch_size, E)) {
@@ -732,14 +740,25 @@ static int backward_impl(const mivit_plan *plan, const float *params, const floa
             }
             prof_set_tag(fz ? MIVIT_PROF_ATTN_CORE_BWD : MIVIT_PROF_ATTN_BWD);
             RC(launch_attention_bwd(dt, at(ws, b.qkv), at(ws, w.dctx), B, S, H, Dh, at(ws, w.dqkv), s));
-            if (fz) prof_pin_tag(MIVIT_PROF_QKV_WGRAD);
-            int rc_q = lin_wgrad(dt, at(ws, w.dqkv), 3 * E, xin, 0, E, M, 3 * E, E, G + lp.qkv_w, G + lp.qkv_b, wg, wgb, s);
-            if (!rc_q && fz && l > 0)
-                rc_q = launch_affine_fixup(G + lp.qkv_w, G + lp.qkv_b, P + plan->layers[l - 1].n2_w, P + plan->layers[l - 1].n2_b, 3 * E, E, s);
-            if (fz) prof_pin_tag(MIVIT_PROF_QKV_DGRAD);
-            if (!rc_q)
-                rc_q = lin_dgrad(dt, at(ws, w.dqkv), 3 * E, WT(lp.qkv_w), M, 3 * E, E, MIVIT_ACT_NONE, nullptr, 0, dz1,
-                                 E, at(ws, w.dxa), E, 0, s);                                      // dxa = d(x_in)
+            // q|k|v projection backward.  Fused path: weight, bias and data gradient (+ the residual branch's d(z1)) in ONE pass
+            // over dqkv (fused_bwd.hip::qkv_bwd_kernel); MIVIT_NO_QKV_BWD=1 keeps the two launches it replaces (A/B runs)
+            static const bool qkv_split = getenv("MIVIT_NO_QKV_BWD") != nullptr;
+            int rc_q = 0;
+            if (fz && !qkv_split) {
+                prof_pin_tag(MIVIT_PROF_QKV_BWD);
+                rc_q = fused_ops(dt, E)->qkv_bwd(at(ws, w.dqkv), xin, WT(lp.qkv_w), dz1, M, at(ws, w.dxa), G + lp.qkv_w, G + lp.qkv_b, wg, wgb, s);
+                if (!rc_q && l > 0)
+                    rc_q = launch_affine_fixup(G + lp.qkv_w, G + lp.qkv_b, P + plan->layers[l - 1].n2_w, P + plan->layers[l - 1].n2_b, 3 * E, E, s);
+            } else {
+                if (fz) prof_pin_tag(MIVIT_PROF_QKV_WGRAD);
+                rc_q = lin_wgrad(dt, at(ws, w.dqkv), 3 * E, xin, 0, E, M, 3 * E, E, G + lp.qkv_w, G + lp.qkv_b, wg, wgb, s);
+                if (!rc_q && fz && l > 0)
+                    rc_q = launch_affine_fixup(G + lp.qkv_w, G + lp.qkv_b, P + plan->layers[l - 1].n2_w, P + plan->layers[l - 1].n2_b, 3 * E, E, s);
+                if (fz) prof_pin_tag(MIVIT_PROF_QKV_DGRAD);
+                if (!rc_q)
+                    rc_q = lin_dgrad(dt, at(ws, w.dqkv), 3 * E, WT(lp.qkv_w), M, 3 * E, E, MIVIT_ACT_NONE, nullptr, 0, dz1,
+                                     E, at(ws, w.dxa), E, 0, s);                                  // dxa = d(x_in)
+            }
             prof_pin_tag(-1);
             RC(rc_q);
         } else {

@@ -34,7 +34,8 @@ namespace {
 
 #ifdef MIVIT_WIDTH64
 constexpr int E = 64, F = 128;
-constexpr int LDE = E + 8, LDF = F + 16;             // 144-byte rows (9 x 16 B, odd: the 16 rows of a b128 read hit 16 bank groups)
+constexpr int LDE = E + 16, LDF = F + 16;            // 160-byte rows: 10 x 16 B (b128 reads: a group of 16 lanes = 8 rows x 2 chunks, conflict-free
+                                                     // for pitches of 2, 6, 10, 14 mod 16 units) and 40 banks (transposing reads: 8 rows, 8 banks apart)
 #else
 constexpr int E = 128, F = 256;
 constexpr int LDE = E + 16, LDF = F + 16;            // LDS row pitches (elements): conflict-free b128 and transposing reads
@@ -906,10 +907,176 @@ __global__ __launch_bounds__(NT, 2) void attn_out_bwd_kernel(const AttnOutBwdArg
     }
 }
 
+// ================================================================================================================
+// q|k|v projection backward: weight gradient AND data gradient in one pass over dqkv (autograd of qkv = x Wqkv^T + bqkv,
+// reference helpers/models.py:42-44, plus the residual branch's gradient that joins d(x) there, :100-102):
+//   in : dqkv [M, 3E] (the attention core's backward), x [M, E] (the projection's input rows as the engine holds them: the
+//        producing LayerNorm's normalised output, or the token rows for layer 0), Wqkv [3E, E], res [M, E] = d(x) of the residual
+//   out: dx = dqkv Wqkv + res [M, E];  dW = dqkv^T x [3E, E], db = column sums of dqkv [3E]  (fp32, overwritten)
+// dqkv is read ONCE (the two launches this replaces -- wgrad_dma and the 384-deep row-stream data gradient -- read it twice:
+// 9 U -> 6 U of traffic per layer).  Same skeleton as attn_out_bwd: 32-row tiles requested one tile ahead by LDS-DMA into
+// thread-private slots, copied into padded operand images, then wave w (E / 16 of them: 8 | 4) takes
+//   * features 16 w .. 16 w + 15 of dx^T = Wqkv^T dqkv^T (its slice of Wqkv^T lives in registers; + res; 8-byte row stores), and
+//   * rows 48 w .. 48 w + 47 of dW (row contraction over the tile: both operands by transposing LDS reads) and of db (the same
+//     dqkv^T fragments against a vector of ones: one more MFMA per fragment, no element-wise pass, no fold).
+// Per-workgroup partial gradients go to slabs, reduced in a fixed order (deterministic).
+// ================================================================================================================
+constexpr int QN = 3 * E, QCH = QN / 8;                  // q|k|v width; its 16-byte chunks per row (48 | 24)
+constexpr int NWQ = E / 16, NTQ = NWQ * 64;              // waves, threads per workgroup
+constexpr int KQ = QN / 32;                              // contraction steps of the data gradient (12 | 6)
+constexpr int LDQ = QN + 16;                             // image pitch: 800 | 416 B = 2 | 10 mod 16 units, 8 | 40 banks per row
+constexpr int QB_OFF_DQ = 0, QB_OFF_X = QB_OFF_DQ + R * LDQ * 2, QB_OFF_RES = QB_OFF_X + R * LDE * 2, QB_OFF_STG = QB_OFF_RES + R * LDE * 2;
+constexpr int QB_LDS = QB_OFF_STG + 5 * NTQ * 16;        // staging: 3 dqkv chunks + 1 x chunk + 1 res chunk per thread and tile
+constexpr int QB_SL_W = 0, QB_SL_B = QN * E, QB_SL_TOTAL = QB_SL_B + QN;          // arena order: in_proj weight, bias
+constexpr int QB_WGPC = E == 64 ? 2 : 1;                 // resident workgroups per CU the grid is sized for
+static_assert(R * QCH == 3 * NTQ && R * CPR == NTQ && QN == 48 * NWQ, "q|k|v backward: thread / wave slices");
+static_assert(QB_LDS * QB_WGPC <= 160 * 1024, "LDS budget");
+
+struct QkvBwdArgs {
+    const bf16 *dqkv, *x, *W, *res;
+    int M;
+    bf16 *dx;
+    float *slabs;          // [gridDim.x][QB_SL_TOTAL]
+};
+
+__global__ __launch_bounds__(NTQ) void qkv_bwd_kernel(const QkvBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16 *DQ = reinterpret_cast<bf16 *>(smem + QB_OFF_DQ), *X = reinterpret_cast<bf16 *>(smem + QB_OFF_X), *RS = reinterpret_cast<bf16 *>(smem + QB_OFF_RES);
+    uint4 *stg = reinterpret_cast<uint4 *>(smem + QB_OFF_STG);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, cq = lane & 15, q = cq >> 2, pp = cq & 3;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    // row operand of dx^T = Wqkv^T dqkv^T for this wave's features c = 16 wave + cq: A[c][n] = Wqkv[n][c]
+    bf16x8 wof[KQ];
+#pragma unroll
+    for (int ks = 0; ks < KQ; ++ks) {
+        bf16x8 t;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t[e] = __builtin_bit_cast(__bf16, a.W[(int64_t)(ks * 32 + 8 * g + e) * E + 16 * wave + cq].v);
+        wof[ks] = t;
+    }
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+    f32x4 dW[3][ET], dbv[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        dbv[i] = zero;
+#pragma unroll
+        for (int j = 0; j < ET; ++j) dW[i][j] = zero;
+    }
+    // this thread's slices of a tile: dqkv chunks i = tid + NTQ j (row i / QCH, chunk i % QCH), one chunk (row r0, chunk c) of x and res
+    const int c = tid % CPR, r0 = tid / CPR;
+    const int ntiles = (a.M + R - 1) / R;
+    int tile = blockIdx.x;
+    auto prefetch = [&](int t) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int i = tid + NTQ * j, rr = i / QCH, cc = i - rr * QCH;
+            const int64_t row = min((int64_t)t * R + rr, (int64_t)a.M - 1);
+            dma16_opaque(a.dqkv + row * QN + 8 * cc, stg + j * NTQ + wave * 64);
+        }
+        const int64_t row = min((int64_t)t * R + r0, (int64_t)a.M - 1);
+        dma16_opaque(a.x + row * E + 8 * c, stg + 3 * NTQ + wave * 64);
+        dma16_opaque(a.res + row * E + 8 * c, stg + 4 * NTQ + wave * 64);
+    };
+    if (tile < ntiles) prefetch(tile);
+    bool first = true;
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int64_t row0 = (int64_t)tile * R;
+        // ---- phase 0: staged chunks -> operand images (rows past the end were clamped to a real row: zeroed here) ----
+        // VM program order of a wave: P(t) [5 DMA pieces] | the 2 dx row stores of tile t-1 (one per row tile: every full tile
+        // issues them; the one partial tile is the last of the launch) | this wait: vmcnt(2) = P(t) landed.
+        if (first) wait_vm<0>(); else wait_vm<2>();
+        first = false;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int i = tid + NTQ * j, rr = i / QCH, cc = i - rr * QCH;
+            *reinterpret_cast<uint4 *>(DQ + rr * LDQ + 8 * cc) = keep_if(stg[j * NTQ + tid], row0 + rr < a.M);
+        }
+        *reinterpret_cast<uint4 *>(X + r0 * LDE + 8 * c) = keep_if(stg[3 * NTQ + tid], row0 + r0 < a.M);
+        *reinterpret_cast<uint4 *>(RS + r0 * LDE + 8 * c) = stg[4 * NTQ + tid];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the staging slots have been read: they may be refilled
+        prefetch(min(tile + (int)gridDim.x, ntiles - 1));
+        barrier();          // raw s_barrier (LDS drained): __syncthreads() would also wait for the prefetch just issued and for store acks
+        // ---- phase 1: dx^T for this wave's 16 features ----
+        f32x4 dc[2] = {zero, zero};
+#pragma unroll
+        for (int ks = 0; ks < KQ; ++ks) {
+            const bf16x8 z0 = lds_frag(DQ + cq * LDQ + ks * 32 + 8 * g), z1 = lds_frag(DQ + (16 + cq) * LDQ + ks * 32 + 8 * g);
+            dc[0] = mma(wof[ks], z0, dc[0]);
+            dc[1] = mma(wof[ks], z1, dc[1]);
+        }
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            const int64_t row = row0 + 16 * rt + cq;
+            const uint2 rr = *reinterpret_cast<const uint2 *>(RS + (16 * rt + cq) * LDE + 16 * wave + 4 * g);
+            f32x4 o = dc[rt];
+            o[0] += elem_lo(rr.x); o[1] += elem_hi(rr.x);
+            o[2] += elem_lo(rr.y); o[3] += elem_hi(rr.y);
+            if (row < a.M) {
+                typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+                const bf16x4 ob = {(__bf16)o[0], (__bf16)o[1], (__bf16)o[2], (__bf16)o[3]};
+                *reinterpret_cast<bf16x4 *>(a.dx + row * E + 16 * wave + 4 * g) = ob;
+            }
+        }
+        // ---- phase 2: dW rows 48 wave .. + 47 (and db): the contraction runs over the 32 rows of the tile ----
+        bf16x8 za[3];
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt) {
+            za[nt] = tr_pair(DQ + (4 * g + q) * LDQ + 48 * wave + 16 * nt + 4 * pp, DQ + (16 + 4 * g + q) * LDQ + 48 * wave + 16 * nt + 4 * pp);
+            dbv[nt] = mma(za[nt], ones, dbv[nt]);                  // [n][*] += sum over rows of dqkv[row][n]
+        }
+#pragma unroll
+        for (int ct = 0; ct < ET; ++ct) {
+            const bf16x8 cb = tr_pair(X + (4 * g + q) * LDE + 16 * ct + 4 * pp, X + (16 + 4 * g + q) * LDE + 16 * ct + 4 * pp);
+#pragma unroll
+            for (int nt = 0; nt < 3; ++nt) dW[nt][ct] = mma(za[nt], cb, dW[nt][ct]);       // [n][k] += dqkv^T x
+        }
+        barrier();
+    }
+    // ---- partial gradients -> this workgroup's slab ----
+    float *sl = a.slabs + (int64_t)blockIdx.x * QB_SL_TOTAL;
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt) {
+#pragma unroll
+        for (int ct = 0; ct < ET; ++ct)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sl[QB_SL_W + (48 * wave + 16 * nt + 4 * g + j) * E + 16 * ct + cq] = dW[nt][ct][j];
+        if (cq == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sl[QB_SL_B + 48 * wave + 16 * nt + 4 * g + j] = dbv[nt][j];
+        }
+    }
+}
+
 bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 int grid_for(int M) { return std::min(256, ceil_div(M, R)); }
+int qkv_grid_for(int M) { return std::min(256 * QB_WGPC, ceil_div(M, R)); }
 
 }  // namespace
+
+size_t qkv_bwd_ws_bytes(int M) { return align_up((size_t)qkv_grid_for(std::max(M, 1)) * QB_SL_TOTAL * sizeof(float), 256); }
+
+// dx [M,E]; dW [3E,E], db [3E] fp32 (overwritten)
+int launch_qkv_bwd(const void *dqkv, const void *x, const void *Wqkv, const void *res, int M, void *dx, float *dW, float *db, void *ws,
+                   size_t ws_bytes, hipStream_t s) {
+    MIVIT_CHECK(dqkv && x && Wqkv && res && dx && dW && db && ws && M > 0, "qkv_bwd: null pointer / empty problem");
+    MIVIT_CHECK(aligned16(dqkv) && aligned16(x) && aligned16(res) && aligned16(dx), "qkv_bwd: pointers must be 16-byte aligned");
+    MIVIT_CHECK(ws_bytes >= qkv_bwd_ws_bytes(M), "qkv_bwd: workspace too small");
+    QkvBwdArgs a{static_cast<const bf16 *>(dqkv), static_cast<const bf16 *>(x), static_cast<const bf16 *>(Wqkv), static_cast<const bf16 *>(res),
+                 M, static_cast<bf16 *>(dx), static_cast<float *>(ws)};
+    const int grid = qkv_grid_for(M);
+    {
+        ProfScope prof(s);
+        MIVIT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(qkv_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, QB_LDS));
+        hipLaunchKernelGGL(qkv_bwd_kernel, dim3(grid), dim3(NTQ), QB_LDS, s, a);
+        MIVIT_LAUNCH_CHECK();
+    }
+    const float *sl = static_cast<const float *>(ws);
+    if (db == dW + QB_SL_B) return launch_slab_reduce_strided(sl, grid, QB_SL_TOTAL, QB_SL_TOTAL, dW, s);
+    RC(launch_slab_reduce_strided(sl + QB_SL_W, grid, QB_SL_TOTAL, QN * E, dW, s));
+    return launch_slab_reduce_strided(sl + QB_SL_B, grid, QB_SL_TOTAL, QN, db, s);
+}
 
 #ifdef MIVIT_WIDTH64
 static const int g_mlp_bwd_waves = 4;
@@ -1056,6 +1223,12 @@ int launch_attn_out_bwd(const void *dy, const void *n1, const float *rstd1, cons
 }
 
 #ifndef MIVIT_ELEM_F16
+extern "C" size_t mivit_qkv_bwd_workspace_bytes(int M) { return qkv_bwd_ws_bytes(M); }
+extern "C" int mivit_qkv_bwd(const void *dqkv, const void *x, const void *Wqkv_bf16, const void *res, int M, void *dx, float *dW, float *db,
+                             void *workspace, size_t workspace_bytes, void *stream) {
+    prof_set_tag(MIVIT_PROF_OP);
+    return launch_qkv_bwd(dqkv, x, Wqkv_bf16, res, M, dx, dW, db, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+}
 extern "C" size_t mivit_attn_out_bwd_workspace_bytes(int M) { return attn_out_bwd_ws_bytes(M); }
 extern "C" int mivit_attn_out_bwd(const void *dy, const void *n1, const float *rstd1, const float *gamma1, const void *ctx,
                                   const void *Wo_bf16, int M, void *dz1, void *dctx, float *dWo, float *dbo, float *dgamma1,

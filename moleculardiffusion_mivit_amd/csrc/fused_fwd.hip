@@ -33,8 +33,8 @@ namespace {
 
 #ifdef MIVIT_WIDTH64
 constexpr int E = 64, F = 128, H = 4, DH = 16;
-constexpr int LDE = E + 8;           // LDS row pitch (elements) of a [*, 64] operand image: 144 B = 9 x 16 B (odd: 16 rows, 16 bank groups)
-constexpr int LDF = F + 16;          // ... of a [*, 128] image: 288 B = 18 x 16 B
+constexpr int LDE = E + 16;          // LDS row pitch (elements) of a [*, 64] operand image: 160 B = 10 x 16 B
+constexpr int LDF = F + 16;          // ... of a [*, 128] image: 288 B = 18 x 16 B   (pitches of 2, 6, 10, 14 mod 16 units: conflict-free b128)
 constexpr float QSCALE = 0.25f * 1.4426950408889634f;                     // 1/sqrt(16) * log2(e), folded into the q projection
 #else
 constexpr int E = 128, F = 256, H = 4, DH = 32;

@@ -44,7 +44,7 @@ thread_local int t_override = -1;             // >= 0: the engine pins the tag a
 thread_local hipEvent_t t_start = nullptr;
 const char *kTagNames[MIVIT_PROF_NUM_TAGS] = {"embed_fwd", "embed_wgrad", "linear_fwd", "linear_dgrad", "linear_wgrad",
                                               "attn_fwd", "attn_bwd", "ln_fwd", "ln_bwd", "op", "attn_block_fwd", "mlp_block_fwd",
-                                              "mlp_block_bwd", "attn_out_bwd", "attn_core_bwd", "qkv_wgrad", "qkv_dgrad"};
+                                              "mlp_block_bwd", "attn_out_bwd", "attn_core_bwd", "qkv_wgrad", "qkv_dgrad", "qkv_bwd"};
 }  // namespace
 
 void prof_set_tag(int tag) {

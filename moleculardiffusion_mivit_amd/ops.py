@@ -447,3 +447,21 @@ def attn_out_bwd(dy, n1, rstd1, gamma1, ctx, Wo):
     N.check(_fused_entry("mivit_attn_out_bwd", E)(*[_p(t) for t in args], M, _p(out["dz1"]), _p(out["dctx"]), _p(out["dWo"]), _p(out["dbo"]),
                                      _p(out["dgamma1"]), _p(out["dbeta1"]), _p(ws), nbytes, _s(dy)), "mivit_attn_out_bwd")
     return out
+
+
+@torch.no_grad()
+def qkv_bwd(dqkv, x, Wqkv, res):
+    """q|k|v projection backward in one pass over dqkv (include/mivit_hip.h): dict(dx, dW, db); dx = dqkv Wqkv + res."""
+    _gpu(dqkv, x, Wqkv, res)
+    M, E = x.shape
+    if tuple(dqkv.shape) != (M, 3 * E) or tuple(Wqkv.shape) != (3 * E, E) or tuple(res.shape) != (M, E):
+        raise ValueError(f"qkv_bwd: shapes {tuple(dqkv.shape)}, {tuple(Wqkv.shape)}, {tuple(res.shape)} do not match x {tuple(x.shape)}")
+    dev = x.device
+    out = {"dx": torch.empty(M, E, dtype=torch.bfloat16, device=dev), "dW": torch.empty(3 * E, E, device=dev),
+           "db": torch.empty(3 * E, device=dev)}
+    nbytes = _fused_entry("mivit_qkv_bwd_workspace_bytes", E)(M)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    args = [dqkv.contiguous(), x.contiguous(), Wqkv.contiguous(), res.contiguous()]
+    N.check(_fused_entry("mivit_qkv_bwd", E)(*[_p(t) for t in args], M, _p(out["dx"]), _p(out["dW"]), _p(out["db"]), _p(ws), nbytes,
+                                             _s(x)), "mivit_qkv_bwd")
+    return out

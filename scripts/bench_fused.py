@@ -72,6 +72,9 @@ if hasattr(ops, "mlp_block_bwd"):
                               M * 10 * E * FH)
 if hasattr(ops, "attn_out_bwd"):
     cases["attn_out_bwd"] = (lambda: ops.attn_out_bwd(dy, n_in.view(M, E), rstd, gi, n_in.view(M, E), Wo), 5 * U, M * 4 * E * E)
+if hasattr(ops, "qkv_bwd"):
+    dqkv = rn(M, 3 * E).bfloat16()
+    cases["qkv_bwd"] = (lambda: ops.qkv_bwd(dqkv, n_in.view(M, E), Wqkv, dy), 6 * U, M * 12 * E * E)
 for name, (fn, byt, fl) in cases.items():
     us = timeit(fn)
     print(f"{name:34s} {us:9.1f} us   {byt / us / 1e3:8.1f} GB/s   {fl / us / 1e6:8.1f} TFLOP/s", flush=True)

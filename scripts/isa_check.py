@@ -330,6 +330,10 @@ def main():
                 need = 2 if "mlp_block_bwd8" in n or extra else 4
                 if c < need:
                     errs.append(f"{n}: {c} global_store_dwordx2 in the tile loop; wait_vm<{need}> counts on >= {need} row stores per tile")
+            if "qkv_bwd_kernel" in n:
+                c = count_in_loop(lines, r"^global_store_dwordx2\b")
+                if c < 2:
+                    errs.append(f"{n}: {c} global_store_dwordx2 in the tile loop; wait_vm<2> counts on 2 row stores per tile")
             if "rowstream_kernel" in n:
                 c = count_in_loop(lines, r"^global_store_dwordx4\b")
                 m = re.search(r"rowstream_kernelILi(\d+)", n)

@@ -385,6 +385,24 @@ def test_attn_out_bwd_exact_integers_bench_scale(layer_width):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+def test_qkv_bwd_exact_integers_bench_scale(layer_width):
+    """256 (512 at width 64) persistent workgroups x 32-row tiles: 140 017 rows = 17 (9) tiles per workgroup, ragged last tile; small
+    integers: dx exact, dW / db exact in fp32 (|partial sums| < 2^24)."""
+    from moleculardiffusion_mivit_amd import ops
+    M = 140000 + 17
+    dqkv = _ints((M, 3 * E), -2, 2, 61)
+    x = _ints((M, E), -1, 1, 62)
+    aw = torch.arange(3 * E * E, device="cuda").reshape(3 * E, E)
+    W = (((aw * 13 + 5) % 31) == 0).float() * ((aw % 3) - 1.0)
+    res = _ints((M, E), -3, 3, 63)
+    out = ops.qkv_bwd(_bf(dqkv), _bf(x), _bf(W), _bf(res))
+    assert torch.equal(out["dx"].float(), dqkv @ W + res)
+    assert torch.equal(out["dW"].double(), dqkv.double().t() @ x.double())
+    assert torch.equal(out["db"].double(), dqkv.double().sum(0))
+    sub = ops.qkv_bwd(_bf(dqkv[M - 1000:]).contiguous(), _bf(x[M - 1000:]).contiguous(), _bf(W), _bf(res[M - 1000:]).contiguous())
+    assert torch.equal(sub["dx"], out["dx"][M - 1000:])
+
+
 # model level, BASELINE configs[1] shape (T32 P64 E128 H4 F256 L4), B = 4096: the path bench.py times
 # ---------------------------------------------------------------------------------------------------------------------
 def _c1_model(precision):

@@ -242,3 +242,41 @@ def test_attn_out_bwd(M):
     again = ops.attn_out_bwd(_bf(dy).cuda(), _bf(nh).cuda(), rstd.cuda(), g1.cuda(), _bf(ctx).cuda(), _bf(Wo).cuda())
     for k in out:
         assert torch.equal(out[k], again[k]), k
+
+
+@pytest.mark.parametrize("M", [1, 31, 264, 1000, 16500])
+def test_qkv_bwd(M):
+    """q|k|v projection backward (weight, bias and data gradient + residual in one pass, csrc/fused_bwd.hip::qkv_bwd_kernel)
+    vs the chain rule of qkv = x Wqkv^T + bqkv in fp32 (reference models.py:42-44,100-102)."""
+    from moleculardiffusion_mivit_amd import ops
+    dqkv = _bf(_mk((M, 3 * E), 51)).float()
+    x = _bf(_mk((M, E), 52)).float()
+    W = _bf(_mk((3 * E, E), 53, 1 / math.sqrt(E))).float()
+    res = _bf(_mk((M, E), 54)).float()
+    ref = {"dx": dqkv @ W + res, "dW": dqkv.t() @ x, "db": dqkv.sum(0)}
+    out = ops.qkv_bwd(_bf(dqkv).cuda(), _bf(x).cuda(), _bf(W).cuda(), _bf(res).cuda())
+    torch.cuda.synchronize()
+    for k, r in ref.items():
+        assert _rel(out[k].float(), r) < 1e-2, k
+    again = ops.qkv_bwd(_bf(dqkv).cuda(), _bf(x).cuda(), _bf(W).cuda(), _bf(res).cuda())
+    for k in out:
+        assert torch.equal(out[k], again[k]), k
+
+
+def test_qkv_bwd_exact_integers():
+    """Small-integer operands: every product and partial sum is exact, so a wrong fragment layout or slab index is an exact mismatch."""
+    from moleculardiffusion_mivit_amd import ops
+    M = 777
+    ar = torch.arange(M * 3 * E).reshape(M, 3 * E)
+    dqkv = ((ar * 7 + 3) % 5 - 2).float()
+    x = ((torch.arange(M * E).reshape(M, E) * 11 + 1) % 3 - 1).float()
+    aw = torch.arange(3 * E * E).reshape(3 * E, E)
+    W = (((aw * 13 + 5) % 31) == 0).float() * ((aw % 3) - 1.0)
+    res = ((torch.arange(M * E).reshape(M, E) * 3 + 2) % 7 - 3).float()
+    out = ops.qkv_bwd(_bf(dqkv).cuda(), _bf(x).cuda(), _bf(W).cuda(), _bf(res).cuda())
+    torch.cuda.synchronize()
+    dx = dqkv @ W + res
+    assert float(dx.abs().max()) <= 256
+    assert torch.equal(out["dx"].float().cpu(), dx)
+    assert torch.equal(out["dW"].cpu(), dqkv.t() @ x)
+    assert torch.equal(out["db"].cpu(), dqkv.sum(0))

@@ -112,6 +112,8 @@ def _run_everything():
             N.lib.mivit_mlp_block_bwd_set_waves(old)
         for k, v in ops.attn_out_bwd(args[0], args[1], args[2], args[3], args[4], _bf(_randn((Ew, Ew), 31, 0.1))).items():
             out[f"attn_out_bwd_w{Ew}_" + k] = v
+        for k, v in ops.qkv_bwd(_bf(_randn((M, 3 * Ew), 39)), args[4], _bf(_randn((3 * Ew, Ew), 40, 0.1)), args[0]).items():
+            out[f"qkv_bwd_w{Ew}_" + k] = v
         # the attention block's forward: one / two row tiles order their row prefetch with a counted wait (width 64: every tile count)
         for S_ in (31, 61):
             Bq = 2600

@@ -191,7 +191,7 @@ def fused_bwd8(ntiles, pieces):
         w.issue(("st", t), 2)
 
 
-@pytest.mark.parametrize("pieces", [6, 2])
+@pytest.mark.parametrize("pieces", [6, 2, 5])          # (5: qkv_bwd_kernel -- 3 dqkv + x + res pieces, the same two row stores)
 def test_fused_bwd8(pieces):
     for n in range(1, 7):
         fused_bwd8(n, pieces)
