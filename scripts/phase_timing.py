@@ -18,6 +18,7 @@ subprocess.check_call([b._hipcc()] + b.FLAGS + ["-DMIVIT_PHASE_TIMING", "-c", os
                       stderr=subprocess.DEVNULL)
 objs = [os.path.join(b.OBJDIR, s.replace(".hip", ".o")) if s != "fused_bwd.hip" else obj for s in b.SOURCES]
 objs += [os.path.join(b.OBJDIR, s.replace(".hip", ".f16.o")) for s in b.ELEM_SOURCES]          # the IEEE-half builds of the streaming units
+objs += [os.path.join(b.OBJDIR, s.replace(".hip", ext)) for s in b.WIDTH_SOURCES for ext in (".w64.o", ".w64.f16.o")]   # ... and the width-64 builds
 subprocess.check_call([b._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
 
 import torch  # noqa: E402

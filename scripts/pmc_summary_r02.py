@@ -8,7 +8,7 @@ figure is an upper estimate for them).
 import csv, json, sys
 from collections import defaultdict
 
-LAYER_KERNELS = ("attn_block_fwd_kernel", "mlp_block_fwd_kernel", "mlp_block_bwd_kernel", "attn_out_bwd_kernel", "attn_bwd_fast", "attn_fwd_fast",
+LAYER_KERNELS = ("attn_block_fwd_kernel", "mlp_block_fwd_kernel", "mlp_block_bwd_kernel", "mlp_block_bwd8_kernel", "attn_out_bwd_kernel", "qkv_bwd_kernel", "attn_bwd_fast", "attn_fwd_fast",
                  "rowstream_kernel", "wavestream_kernel", "wgrad_dma_kernel", "ln_bwd_vec", "ln_fwd_vec", "slab_reduce",
                  "affine_fixup_kernel")
 
