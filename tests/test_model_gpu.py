@@ -666,3 +666,47 @@ def test_fused_inference_path_matches_training_forward_and_fp32():
         out_eval, out_ref = m16(xb), m32(xb)
     assert rel_err(out_eval, out_train.detach()) < 1e-2
     assert rel_err(out_eval, out_ref) < 5e-2
+
+
+# ---- direct parameter gradients (opt-in: GeneralTransformer.direct_param_grads) ---------------------------------------
+def test_direct_param_grads_train_identically_and_fall_back():
+    """Five AdamW steps with `.grad` set straight from the persistent gradient arena give bitwise the parameters of the ordinary
+    autograd route; a backward that meets a populated `.grad` (accumulation), a hooked or a frozen parameter takes the ordinary
+    route and still produces the right sums."""
+    cfg = orc.MiViTConfig(embedding="linear", patch_size=9, embed_dim=64, num_heads=4, hidden_dim=128, num_layers=2)
+    params = orc.random_params(cfg, seed=5)
+    x, y = torch.rand(16, 10, 9, 9, device="cuda"), torch.rand(16, 1, device="cuda")
+    finals = []
+    for direct in (False, True):
+        m = build_product_model(cfg, "bf16", params).train()
+        m.direct_param_grads(direct)
+        opt = torch.optim.AdamW(m.parameters(), lr=1e-3, fused=True)
+        for _ in range(5):
+            opt.zero_grad()
+            F.mse_loss(m(x), y).backward()
+            if direct:
+                base = m._grad_arena.data_ptr()
+                assert all(p.grad.data_ptr() == base + 4 * off for p, off in zip(m._arena_params, m._plan.param_offsets))
+            opt.step()
+        finals.append({k: v.detach().clone() for k, v in m.named_parameters()})
+    for k in finals[0]:
+        assert torch.equal(finals[0][k], finals[1][k]), k
+    # accumulation: the second backward finds .grad populated -> ordinary route, in-place sum
+    m = build_product_model(cfg, "bf16", params).train().direct_param_grads(True)
+    F.mse_loss(m(x), y).backward()
+    g1 = {k: p.grad.clone() for k, p in m.named_parameters()}
+    F.mse_loss(m(x), y).backward()
+    for k, p in m.named_parameters():
+        assert torch.equal(p.grad, g1[k] + g1[k]), k
+    # a hook or a frozen parameter: ordinary route (the hook fires, the frozen parameter gets no gradient)
+    m = build_product_model(cfg, "bf16", params).train().direct_param_grads(True)
+    fired = []
+    first = next(iter(m.parameters()))
+    first.register_hook(lambda g: fired.append(1))
+    F.mse_loss(m(x), y).backward()
+    assert fired and all(torch.equal(p.grad, g1[k]) for k, p in m.named_parameters())
+    m = build_product_model(cfg, "bf16", params).train().direct_param_grads(True)
+    frozen = list(m.parameters())[-1]
+    frozen.requires_grad_(False)
+    F.mse_loss(m(x), y).backward()
+    assert frozen.grad is None and m._grad_arena is None
