@@ -36,6 +36,10 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
          "-Wno-unused-variable", "-Wno-inline-asm", "-fno-gpu-rdc", "-mllvm", "-amdgpu-mfma-vgpr-form"]
 
 
+# experiments: extra compiler flags for every object (e.g. MIVIT_EXTRA_HIPCC_FLAGS="-DMIVIT_NO_ASM_PF" python build.py --force)
+FLAGS += os.environ.get("MIVIT_EXTRA_HIPCC_FLAGS", "").split()
+
+
 def _hipcc():
     for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
         if cand and (os.path.sep not in cand or os.path.exists(cand)):

@@ -437,7 +437,11 @@ __global__ __launch_bounds__(NW * 64) void attn_block_fwd_kernel(const AttnFwdAr
     // accumulation registers right behind the asm statement -- a copy of registers the memory system has not written yet;
     // scripts/isa_check.py::check_asm_load_window is the guard that found it -- and accumulation-register destinations
     // ("=a") crash this compiler's AGPR rewrite pass.)
+#ifdef MIVIT_NO_ASM_PF          // (A/B builds only: the compiler-visible row prefetch everywhere)
+    constexpr bool ASM_PF = false;
+#else
     constexpr bool ASM_PF = NT <= 2 || E == 64;          // (width 64: 110-200 registers at any tile count, nothing gets parked)
+#endif
     constexpr int NBASE = KS * NT * 2 + ET * NT + NT;                  // ctx (two halves per 32 features and tile) | n | rstd
     constexpr int NSTORE = NBASE + (EXTRAS ? H * NT * 3 * DT : 0);     // + q, k, v (one 8-byte store per 16 head features each)
     constexpr int WAITB = NBASE < 63 ? NBASE : 63, WAITN = NSTORE < 63 ? NSTORE : 63;
@@ -478,82 +482,171 @@ __global__ __launch_bounds__(NW * 64) void attn_block_fwd_kernel(const AttnFwdAr
         }
         bf16x8 cf[KS][NT];                           // context, as the column operand of the out-projection: one fragment per
         f32x4 ot_even[NT];                           // 32 features = one head (head dim 32) or two (head dim 16: the even head waits here)
+        // Weight fragments of a projection block (q, k or v of one head: KS x DT reads of 1 KB) are requested ONE BLOCK AHEAD, as a
+        // batch, into the other of two register sets: written as "read a fragment, use it" the compiler keeps each ds_read_b128
+        // next to its three MFMAs and waits for it (`L2 w M6` through the whole phase: one LDS round trip per 48-96 MFMA cycles,
+        // with one wave per SIMD nobody to cover it -- 220 such reads per sequence).  The accumulators start from the inline
+        // constant 0 and the bias is added in the epilogue (as the C operand it cost four register copies per tile and a wait
+        // for its own LDS read in front of the first MFMA).  The v^T product for the q|k|v store reuses the v block's fragments.
+        constexpr bool WIDE = NW == 4 || E == 64;          // (two waves per SIMD at width 128: 256 registers, the old per-fragment form)
+        bf16x8 wb[2][KS][DT];
+        auto request_w = [&](int buf, int rowbase) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) wb[buf][ks][dt] = lds_frag(Wq + (rowbase + 16 * dt + cq) * LDE + ks * 32 + 8 * g);
+        };
+        int cur = 0;
+        if constexpr (WIDE) request_w(0, 0);         // q of head 0
 #pragma unroll
         for (int h = 0; h < H; ++h) {
-            __builtin_amdgcn_sched_barrier(0);
-            // ---- q^T, k^T (lane = token, registers = 4 head features), one after the other (register budget) ----
-            // (head dim 16: the upper half of the 32-deep contraction is zero on both operands)
-            bf16x8 qf[NT], kf[NT];
-#pragma unroll
-            for (int which = 0; which < 2; ++which) {
-                f32x4 pa[DT][NT];
-#pragma unroll
-                for (int dt = 0; dt < DT; ++dt) {
-                    const f32x4 bb = ld4(bqkv + which * E + h * DH + 16 * dt + 4 * g);
-#pragma unroll
-                    for (int rt = 0; rt < NT; ++rt) pa[dt][rt] = bb;
-                }
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
+            bf16x8 qf[NT], kf[NT], vr[NP][DT];
+            if constexpr (WIDE) {
+                // ---- q^T, k^T (lane = token, registers = 4 head features), one after the other (register budget) ----
+                // (head dim 16: the upper half of the 32-deep contraction is zero on both operands)
+    #pragma unroll
+                for (int which = 0; which < 2; ++which) {
+                    request_w(cur ^ 1, (which + 1) * E + h * DH);          // the next block: k after q, v after k
+                    __builtin_amdgcn_sched_barrier(0);
+                    f32x4 pa[DT][NT];
+    #pragma unroll
+                    for (int ks = 0; ks < KS; ++ks)
+    #pragma unroll
+                        for (int dt = 0; dt < DT; ++dt)
+    #pragma unroll
+                            for (int rt = 0; rt < NT; ++rt) pa[dt][rt] = mma(wb[cur][ks][dt], xf[rt][ks], ks == 0 ? zero : pa[dt][rt]);
+                    cur ^= 1;
+    #pragma unroll
                     for (int dt = 0; dt < DT; ++dt) {
-                        const bf16x8 w = lds_frag(Wq + (which * E + h * DH + 16 * dt + cq) * LDE + ks * 32 + 8 * g);
-#pragma unroll
-                        for (int rt = 0; rt < NT; ++rt) pa[dt][rt] = mma(w, xf[rt][ks], pa[dt][rt]);
+                        const f32x4 bb = ld4(bqkv + which * E + h * DH + 16 * dt + 4 * g);
+    #pragma unroll
+                        for (int rt = 0; rt < NT; ++rt) pa[dt][rt] += bb;
                     }
-#pragma unroll
-                for (int rt = 0; rt < NT; ++rt) {
-                    if (which == 0) qf[rt] = pack8(pa[0][rt], DT == 2 ? pa[DT - 1][rt] : zero);
-                    else kf[rt] = pack8(pa[0][rt], DT == 2 ? pa[DT - 1][rt] : zero);
-                    if (EXTRAS && a.qkvout && rt * 16 + cq < S) {          // (q leaves unscaled, as the reference's q_proj output)
-                        bf16 *dst = a.qkvout + (base + rt * 16 + cq) * (3 * E) + which * E + h * DH + 4 * g;
-                        if (which == 0) {
-                            store4_bf16(dst, pa[0][rt] * (1.f / QSCALE));
-                            if (DT == 2) store4_bf16(dst + 16, pa[DT - 1][rt] * (1.f / QSCALE));
-                        } else if (DT == 2) store_halves(dst, dst + 16, kf[rt]);          // k: exactly the packed operand
-                        else store_lo(dst, kf[rt]);
-                    }
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            // ---- v (lane = head feature, registers = 4 tokens): the operand of P V with keys as contraction index ----
-            bf16x8 vr[NP][DT];
-            {
-                f32x4 va[NT][DT];
-#pragma unroll
-                for (int dt = 0; dt < DT; ++dt) {
-                    const float bv = bqkv[2 * E + h * DH + 16 * dt + cq];
-#pragma unroll
-                    for (int rt = 0; rt < NT; ++rt) va[rt][dt] = f32x4{bv, bv, bv, bv};
-                }
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-                    for (int dt = 0; dt < DT; ++dt) {
-                        const bf16x8 wv = lds_frag(Wq + (2 * E + h * DH + 16 * dt + cq) * LDE + ks * 32 + 8 * g);
-#pragma unroll
-                        for (int rt = 0; rt < NT; ++rt) va[rt][dt] = mma(xf[rt][ks], wv, va[rt][dt]);
-                    }
-#pragma unroll
-                for (int p = 0; p < NP; ++p)
-#pragma unroll
-                    for (int dt = 0; dt < DT; ++dt) vr[p][dt] = pack8(va[2 * p][dt], (2 * p + 1 < NT) ? va[2 * p + 1][dt] : zero);
-                if (EXTRAS && a.qkvout) {         // v^T once more (lane = token): 8-byte row stores instead of 2-byte scatters
-#pragma unroll
-                    for (int dt = 0; dt < DT; ++dt) {
-                        f32x4 vt[NT];
-                        const f32x4 bb = ld4(bqkv + 2 * E + h * DH + 16 * dt + 4 * g);
-#pragma unroll
-                        for (int rt = 0; rt < NT; ++rt) vt[rt] = bb;
-#pragma unroll
-                        for (int ks = 0; ks < KS; ++ks) {
-                            const bf16x8 wv = lds_frag(Wq + (2 * E + h * DH + 16 * dt + cq) * LDE + ks * 32 + 8 * g);
-#pragma unroll
-                            for (int rt = 0; rt < NT; ++rt) vt[rt] = mma(wv, xf[rt][ks], vt[rt]);
+    #pragma unroll
+                    for (int rt = 0; rt < NT; ++rt) {
+                        if (which == 0) qf[rt] = pack8(pa[0][rt], DT == 2 ? pa[DT - 1][rt] : zero);
+                        else kf[rt] = pack8(pa[0][rt], DT == 2 ? pa[DT - 1][rt] : zero);
+                        if (EXTRAS && a.qkvout && rt * 16 + cq < S) {          // (q leaves unscaled, as the reference's q_proj output)
+                            bf16 *dst = a.qkvout + (base + rt * 16 + cq) * (3 * E) + which * E + h * DH + 4 * g;
+                            if (which == 0) {
+                                store4_bf16(dst, pa[0][rt] * (1.f / QSCALE));
+                                if (DT == 2) store4_bf16(dst + 16, pa[DT - 1][rt] * (1.f / QSCALE));
+                            } else if (DT == 2) store_halves(dst, dst + 16, kf[rt]);          // k: exactly the packed operand
+                            else store_lo(dst, kf[rt]);
                         }
-#pragma unroll
-                        for (int rt = 0; rt < NT; ++rt)
-                            if (rt * 16 + cq < S) store4_bf16(a.qkvout + (base + rt * 16 + cq) * (3 * E) + 2 * E + h * DH + 16 * dt + 4 * g, vt[rt]);
+                    }
+                }
+                // ---- v (lane = head feature, registers = 4 tokens): the operand of P V with keys as contraction index ----
+                {
+                    if (h + 1 < H) request_w(cur ^ 1, (h + 1) * DH);          // q of the next head
+                    __builtin_amdgcn_sched_barrier(0);
+                    f32x4 va[NT][DT];
+    #pragma unroll
+                    for (int ks = 0; ks < KS; ++ks)
+    #pragma unroll
+                        for (int dt = 0; dt < DT; ++dt)
+    #pragma unroll
+                            for (int rt = 0; rt < NT; ++rt) va[rt][dt] = mma(xf[rt][ks], wb[cur][ks][dt], ks == 0 ? zero : va[rt][dt]);
+    #pragma unroll
+                    for (int dt = 0; dt < DT; ++dt) {
+                        const float bv = bqkv[2 * E + h * DH + 16 * dt + cq];
+    #pragma unroll
+                        for (int rt = 0; rt < NT; ++rt) va[rt][dt] += f32x4{bv, bv, bv, bv};
+                    }
+    #pragma unroll
+                    for (int p = 0; p < NP; ++p)
+    #pragma unroll
+                        for (int dt = 0; dt < DT; ++dt) vr[p][dt] = pack8(va[2 * p][dt], (2 * p + 1 < NT) ? va[2 * p + 1][dt] : zero);
+                    if (EXTRAS && a.qkvout) {         // v^T once more (lane = token): 8-byte row stores instead of 2-byte scatters
+    #pragma unroll
+                        for (int dt = 0; dt < DT; ++dt) {
+                            f32x4 vt[NT];
+    #pragma unroll
+                            for (int ks = 0; ks < KS; ++ks)
+    #pragma unroll
+                                for (int rt = 0; rt < NT; ++rt) vt[rt] = mma(wb[cur][ks][dt], xf[rt][ks], ks == 0 ? zero : vt[rt]);
+                            const f32x4 bb = ld4(bqkv + 2 * E + h * DH + 16 * dt + 4 * g);
+    #pragma unroll
+                            for (int rt = 0; rt < NT; ++rt)
+                                if (rt * 16 + cq < S) store4_bf16(a.qkvout + (base + rt * 16 + cq) * (3 * E) + 2 * E + h * DH + 16 * dt + 4 * g, vt[rt] + bb);
+                        }
+                    }
+                    cur ^= 1;
+                }
+            } else {
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- q^T, k^T (lane = token, registers = 4 head features), one after the other (register budget) ----
+                // (head dim 16: the upper half of the 32-deep contraction is zero on both operands)
+    #pragma unroll
+                for (int which = 0; which < 2; ++which) {
+                    f32x4 pa[DT][NT];
+    #pragma unroll
+                    for (int dt = 0; dt < DT; ++dt) {
+                        const f32x4 bb = ld4(bqkv + which * E + h * DH + 16 * dt + 4 * g);
+    #pragma unroll
+                        for (int rt = 0; rt < NT; ++rt) pa[dt][rt] = bb;
+                    }
+    #pragma unroll
+                    for (int ks = 0; ks < KS; ++ks)
+    #pragma unroll
+                        for (int dt = 0; dt < DT; ++dt) {
+                            const bf16x8 w = lds_frag(Wq + (which * E + h * DH + 16 * dt + cq) * LDE + ks * 32 + 8 * g);
+    #pragma unroll
+                            for (int rt = 0; rt < NT; ++rt) pa[dt][rt] = mma(w, xf[rt][ks], pa[dt][rt]);
+                        }
+    #pragma unroll
+                    for (int rt = 0; rt < NT; ++rt) {
+                        if (which == 0) qf[rt] = pack8(pa[0][rt], DT == 2 ? pa[DT - 1][rt] : zero);
+                        else kf[rt] = pack8(pa[0][rt], DT == 2 ? pa[DT - 1][rt] : zero);
+                        if (EXTRAS && a.qkvout && rt * 16 + cq < S) {          // (q leaves unscaled, as the reference's q_proj output)
+                            bf16 *dst = a.qkvout + (base + rt * 16 + cq) * (3 * E) + which * E + h * DH + 4 * g;
+                            if (which == 0) {
+                                store4_bf16(dst, pa[0][rt] * (1.f / QSCALE));
+                                if (DT == 2) store4_bf16(dst + 16, pa[DT - 1][rt] * (1.f / QSCALE));
+                            } else if (DT == 2) store_halves(dst, dst + 16, kf[rt]);          // k: exactly the packed operand
+                            else store_lo(dst, kf[rt]);
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- v (lane = head feature, registers = 4 tokens): the operand of P V with keys as contraction index ----
+                {
+                    f32x4 va[NT][DT];
+    #pragma unroll
+                    for (int dt = 0; dt < DT; ++dt) {
+                        const float bv = bqkv[2 * E + h * DH + 16 * dt + cq];
+    #pragma unroll
+                        for (int rt = 0; rt < NT; ++rt) va[rt][dt] = f32x4{bv, bv, bv, bv};
+                    }
+    #pragma unroll
+                    for (int ks = 0; ks < KS; ++ks)
+    #pragma unroll
+                        for (int dt = 0; dt < DT; ++dt) {
+                            const bf16x8 wv = lds_frag(Wq + (2 * E + h * DH + 16 * dt + cq) * LDE + ks * 32 + 8 * g);
+    #pragma unroll
+                            for (int rt = 0; rt < NT; ++rt) va[rt][dt] = mma(xf[rt][ks], wv, va[rt][dt]);
+                        }
+    #pragma unroll
+                    for (int p = 0; p < NP; ++p)
+    #pragma unroll
+                        for (int dt = 0; dt < DT; ++dt) vr[p][dt] = pack8(va[2 * p][dt], (2 * p + 1 < NT) ? va[2 * p + 1][dt] : zero);
+                    if (EXTRAS && a.qkvout) {         // v^T once more (lane = token): 8-byte row stores instead of 2-byte scatters
+    #pragma unroll
+                        for (int dt = 0; dt < DT; ++dt) {
+                            f32x4 vt[NT];
+                            const f32x4 bb = ld4(bqkv + 2 * E + h * DH + 16 * dt + 4 * g);
+    #pragma unroll
+                            for (int rt = 0; rt < NT; ++rt) vt[rt] = bb;
+    #pragma unroll
+                            for (int ks = 0; ks < KS; ++ks) {
+                                const bf16x8 wv = lds_frag(Wq + (2 * E + h * DH + 16 * dt + cq) * LDE + ks * 32 + 8 * g);
+    #pragma unroll
+                                for (int rt = 0; rt < NT; ++rt) vt[rt] = mma(wv, xf[rt][ks], vt[rt]);
+                            }
+    #pragma unroll
+                            for (int rt = 0; rt < NT; ++rt)
+                                if (rt * 16 + cq < S) store4_bf16(a.qkvout + (base + rt * 16 + cq) * (3 * E) + 2 * E + h * DH + 16 * dt + 4 * g, vt[rt]);
+                        }
                     }
                 }
             }
@@ -606,22 +699,50 @@ __global__ __launch_bounds__(NW * 64) void attn_block_fwd_kernel(const AttnFwdAr
         __builtin_amdgcn_sched_barrier(0);
         // ---- out-projection (+ bias) + residual (identity product on the input fragments), LayerNorm ----
         f32x4 oa[ET][NT];
+        if constexpr (WIDE) {
+            // the same one-block-ahead batches for the out-projection's fragments (ET reads per 32-feature block); the residual's
+            // bias / gamma vectors as one batch in front of the identity products they scale
+            bf16x8 wo[2][ET];
+            auto request_wo = [&](int buf, int kb) {
 #pragma unroll
-        for (int nt = 0; nt < ET; ++nt) {
-            const f32x4 bv = ld4(bo + 16 * nt + 4 * g), gv = ld4(gin + 16 * nt + 4 * g);
+                for (int nt = 0; nt < ET; ++nt) wo[buf][nt] = lds_frag(Wo + (16 * nt + cq) * LDE + kb * 32 + 8 * g);
+            };
+            f32x4 bvs[ET], gvs[ET];
 #pragma unroll
-            for (int rt = 0; rt < NT; ++rt) oa[nt][rt] = bv + gv * mma((nt & 1) ? id1 : id0, xf[rt][nt >> 1], zero);
-        }
-        __builtin_amdgcn_sched_barrier(0);
+            for (int nt = 0; nt < ET; ++nt) { bvs[nt] = ld4(bo + 16 * nt + 4 * g); gvs[nt] = ld4(gin + 16 * nt + 4 * g); }
+            request_wo(0, 0);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int kb = 0; kb < KS; ++kb) {
+            for (int nt = 0; nt < ET; ++nt)
+#pragma unroll
+                for (int rt = 0; rt < NT; ++rt) oa[nt][rt] = bvs[nt] + gvs[nt] * mma((nt & 1) ? id1 : id0, xf[rt][nt >> 1], zero);
+#pragma unroll
+            for (int kb = 0; kb < KS; ++kb) {
+                if (kb + 1 < KS) request_wo((kb + 1) & 1, kb + 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int nt = 0; nt < ET; ++nt)
+#pragma unroll
+                    for (int rt = 0; rt < NT; ++rt) oa[nt][rt] = mma(wo[kb & 1][nt], cf[kb][rt], oa[nt][rt]);
+            }
+        } else {
 #pragma unroll
             for (int nt = 0; nt < ET; ++nt) {
-                const bf16x8 w = lds_frag(Wo + (16 * nt + cq) * LDE + kb * 32 + 8 * g);
+                const f32x4 bv = ld4(bo + 16 * nt + 4 * g), gv = ld4(gin + 16 * nt + 4 * g);
 #pragma unroll
-                for (int rt = 0; rt < NT; ++rt) oa[nt][rt] = mma(w, cf[kb][rt], oa[nt][rt]);
+                for (int rt = 0; rt < NT; ++rt) oa[nt][rt] = bv + gv * mma((nt & 1) ? id1 : id0, xf[rt][nt >> 1], zero);
             }
-            __builtin_amdgcn_sched_barrier(0);      // keeps the weight-fragment reads of later heads from piling up
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kb = 0; kb < KS; ++kb) {
+#pragma unroll
+                for (int nt = 0; nt < ET; ++nt) {
+                    const bf16x8 w = lds_frag(Wo + (16 * nt + cq) * LDE + kb * 32 + 8 * g);
+#pragma unroll
+                    for (int rt = 0; rt < NT; ++rt) oa[nt][rt] = mma(w, cf[kb][rt], oa[nt][rt]);
+                }
+                __builtin_amdgcn_sched_barrier(0);      // keeps the weight-fragment reads of later heads from piling up
+            }
         }
 #pragma unroll
         for (int rt = 0; rt < NT; ++rt) {
