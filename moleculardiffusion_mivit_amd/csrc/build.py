@@ -25,7 +25,7 @@ LIB = os.path.join(PKG, "libmivit_hip.so")
 # TEST INFRASTRUCTURE ONLY: tests/test_strict_waits_gpu.py runs the bench-scale shapes through both and requires bitwise-equal
 # results; the product (_native.py) never loads it.  Only the sources that call wait_vm are compiled twice.
 LIB_STRICT = os.path.join(PKG, "libmivit_hip_strict.so")
-WAIT_SOURCES = ["embed.hip", "rowstream.hip", "gemm_dma.hip", "wgrad_dma.hip", "fused_bwd.hip", "fused_fwd.hip"]
+WAIT_SOURCES = ["embed.hip", "rowstream.hip", "gemm_dma.hip", "wgrad_dma.hip", "fused_bwd.hip"]
 OBJDIR = os.path.join(HERE, "build")
 # -amdgpu-mfma-vgpr-form: MFMA results in arch VGPRs where they fit.  By default the accumulators go to AGPRs and every value a
 # VALU instruction consumes afterwards (softmax, bias, packing, stores) costs a v_accvgpr_read first: attention_fast.hip 23 k

@@ -142,24 +142,6 @@ __device__ __forceinline__ void load_raw(uint4 (&raw)[KS], const bf16 *nin, int6
     }
 }
 __device__ __forceinline__ bf16x8 as_frag(const uint4 &u) { return __builtin_bit_cast(bf16x8, u); }
-// The same four loads WRITTEN OUT (inline asm, immediate offsets): invisible to the compiler's waitcnt pass, which therefore
-// cannot put `vmcnt(0)` -- a wait for every row store issued since -- in front of their first use.  The caller orders them with
-// an explicit counted wait (attn_block_fwd: prefetch at the top of an iteration, wait at the top of the next).  The row is
-// clamped by the caller (always a valid address); rows that do not exist are zeroed after the wait (frag_if).
-typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void load_raw_asm(u32x4_t (&raw)[KS], const bf16 *rowptr) {
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(raw[0]) : "v"(rowptr) : "memory");
-    asm volatile("global_load_dwordx4 %0, %1, off offset:64" : "=v"(raw[1]) : "v"(rowptr) : "memory");
-    if constexpr (KS > 2) {
-        asm volatile("global_load_dwordx4 %0, %1, off offset:128" : "=v"(raw[KS > 2 ? 2 : 0]) : "v"(rowptr) : "memory");
-        asm volatile("global_load_dwordx4 %0, %1, off offset:192" : "=v"(raw[KS > 2 ? 3 : 0]) : "v"(rowptr) : "memory");
-    }
-}
-__device__ __forceinline__ bf16x8 frag_if(const u32x4_t &u, bool valid) {
-    const unsigned m = valid ? 0xffffffffu : 0u;
-    const u32x4_t v = {u[0] & m, u[1] & m, u[2] & m, u[3] & m};
-    return __builtin_bit_cast(bf16x8, v);
-}
 // The producing LayerNorm's affine is FOLDED into the consuming weights while they are staged (once per workgroup):
 //   (gamma * n + beta) W^T + b  =  n (W * gamma)^T + (b + W beta)
 // so the projections run on the raw normalised rows exactly as loaded -- no per-element affine, no copy.
@@ -423,63 +405,29 @@ __global__ __launch_bounds__(NW * 64) void attn_block_fwd_kernel(const AttnFwdAr
     const bf16x8 id0 = idfrag(0, cq, g), id1 = idfrag(1, cq, g);
     const int bstride = gridDim.x * NW;
     int b = blockIdx.x * NW + wave;
-    // Next sequence's rows.  One or two row tiles (ASM_PF): requested at the TOP of an iteration -- before any of the iteration's
-    // row stores -- into registers the compiler never sees a load for, and waited for at the top of the next one.
-    // VM program order of a wave:   L(b) | stores of sequence b-stride ... wait | L(b+stride) | stores of sequence b | wait | ...
-    // i.e. younger than L(b) at its wait are exactly the row stores of the iteration before: at least NSTORE instructions (the
-    // launcher picks NT = ceil(S / 16): every row tile has a valid row, so every (tile, head, output) store is issued; optional
-    // outputs only add more).  vmcnt counts to 63: with NSTORE >= 63 the wait is vmcnt(63) -- the 63 youngest stores stay in
-    // flight, L(b) is older than all of them.
-    // (Requested after the attention phase with ordinary loads -- round 2, and still the form for three and four row tiles --
-    // the compiler puts vmcnt(0) in front of their first use: the row stores sit under per-row validity branches it cannot
-    // count.  Every iteration then drains ~50 (inference) to ~125 (training: + q|k|v) store acknowledgements: 237 -> 301 us per
-    // layer for the q|k|v store alone.  With three or four tiles in flight the allocator parks written-out destinations in
-    // accumulation registers right behind the asm statement -- a copy of registers the memory system has not written yet;
-    // scripts/isa_check.py::check_asm_load_window is the guard that found it -- and accumulation-register destinations
-    // ("=a") crash this compiler's AGPR rewrite pass.)
-#ifdef MIVIT_NO_ASM_PF          // (A/B builds only: the compiler-visible row prefetch everywhere)
-    constexpr bool ASM_PF = false;
-#else
-    constexpr bool ASM_PF = NT <= 2 || E == 64;          // (width 64: 110-200 registers at any tile count, nothing gets parked)
-#endif
-    constexpr int NBASE = KS * NT * 2 + ET * NT + NT;                  // ctx (two halves per 32 features and tile) | n | rstd
-    constexpr int NSTORE = NBASE + (EXTRAS ? H * NT * 3 * DT : 0);     // + q, k, v (one 8-byte store per 16 head features each)
-    constexpr int WAITB = NBASE < 63 ? NBASE : 63, WAITN = NSTORE < 63 ? NSTORE : 63;
-    const bool qkv_stored = EXTRAS && a.qkvout != nullptr;             // (the launcher picks EXTRAS exactly then)
-    u32x4_t nx[NT][KS];
+    // Next sequence's rows: requested after the attention phase (into the registers the input fragments are read from: dead by
+    // then), in flight under the out-projection and the epilogue.
+    // (Round 3 built and measured a WRITTEN-OUT form -- inline-asm loads at the top of the iteration, before the iteration's row
+    //  stores, and a counted `vmcnt(min(63, stores per iteration))` at the top of the next one -- on the theory that the compiler's
+    //  vmcnt(0) in front of the first use drains ~50-170 store acknowledgements per iteration.  It does drain them, and it does not
+    //  matter: with the q|k|v store the written-out form was SLOWER at every shape (33 tokens: not applicable, see below; 31
+    //  tokens: 256 against 245 us at four waves, 311 against 284 at eight; 16 tokens: 143 against 132), without it within noise
+    //  except 31 tokens at four waves (155 against 169); width 64: noise.  It also needed a build-time ISA rule of its own: at three
+    //  and four row tiles the allocator parks the asm destinations in accumulation registers right behind the statement -- a copy
+    //  of registers the memory system has not written yet.  Removed; scripts/ab_asm_pf.sh and DESIGN.md section 4c keep the numbers.)
     uint4 nxc[NT][KS];
     auto request = [&](int seq) {
 #pragma unroll
-        for (int rt = 0; rt < NT; ++rt) {
-            if constexpr (ASM_PF) load_raw_asm(nx[rt], a.nin + ((int64_t)seq * S + min(rt * 16 + cq, S - 1)) * E + 8 * g);
-            else load_raw(nxc[rt], a.nin, (int64_t)seq * S + rt * 16 + cq, rt * 16 + cq < S, g);
-        }
+        for (int rt = 0; rt < NT; ++rt) load_raw(nxc[rt], a.nin, (int64_t)seq * S + rt * 16 + cq, rt * 16 + cq < S, g);
     };
     if (b < a.B) request(b);
-    bool first = true;
     for (; b < a.B; b += bstride) {
         const int64_t base = (int64_t)b * S;
         bf16x8 xf[NT][KS];
-        if constexpr (ASM_PF) {
-            if (first) wait_vm<0>();
-            else if (EXTRAS && !qkv_stored) wait_vm<WAITB>();
-            else wait_vm<WAITN>();
-            first = false;
 #pragma unroll
-            for (int rt = 0; rt < NT; ++rt) {
-                if constexpr (KS > 2) asm volatile("" : "+v"(nx[rt][0]), "+v"(nx[rt][1]), "+v"(nx[rt][KS > 2 ? 2 : 0]), "+v"(nx[rt][KS > 2 ? 3 : 0]));
-                else asm volatile("" : "+v"(nx[rt][0]), "+v"(nx[rt][1]));      // (ordered after the wait)
+        for (int rt = 0; rt < NT; ++rt)
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) xf[rt][ks] = frag_if(nx[rt][ks], rt * 16 + cq < S);
-            }
-            asm volatile("" ::: "memory");
-            request(min(b + bstride, a.B - 1));      // (a clamped re-read on the last round: never consumed, drained before the kernel ends)
-        } else {
-#pragma unroll
-            for (int rt = 0; rt < NT; ++rt)
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) xf[rt][ks] = as_frag(nxc[rt][ks]);
-        }
+            for (int ks = 0; ks < KS; ++ks) xf[rt][ks] = as_frag(nxc[rt][ks]);
         bf16x8 cf[KS][NT];                           // context, as the column operand of the out-projection: one fragment per
         f32x4 ot_even[NT];                           // 32 features = one head (head dim 32) or two (head dim 16: the even head waits here)
         // Weight fragments of a projection block (q, k or v of one head: KS x DT reads of 1 KB) are requested ONE BLOCK AHEAD, as a
@@ -695,7 +643,7 @@ __global__ __launch_bounds__(NW * 64) void attn_block_fwd_kernel(const AttnFwdAr
                 }
             }
         }
-        if constexpr (!ASM_PF) request(min(b + bstride, a.B - 1));      // in flight under the out-projection and the epilogue
+        request(min(b + bstride, a.B - 1));      // (unconditional: a clamped re-read on the last round)
         __builtin_amdgcn_sched_barrier(0);
         // ---- out-projection (+ bias) + residual (identity product on the input fragments), LayerNorm ----
         f32x4 oa[ET][NT];
@@ -752,7 +700,6 @@ __global__ __launch_bounds__(NW * 64) void attn_block_fwd_kernel(const AttnFwdAr
             ln_store(z, base + rt * 16 + cq, rt * 16 + cq < S, gout, bout, a.o, g);
         }
     }
-    if constexpr (ASM_PF) wait_vm<0>();            // the clamped request of the last round
 }
 
 bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -828,7 +775,10 @@ int launch_attn_block_fwd(const void *nin, const float *gin, const float *bin, c
     a.qkvout = static_cast<bf16 *>(qkvout);
     const int nt = ceil_div(S, 16);
     static const int nw_env = [] { const char *e = getenv("MIVIT_ATTN_BLOCK_WAVES"); return e ? atoi(e) : 0; }();
-    const int nw = nw_env == 8 || nw_env == 4 ? nw_env : (nt >= 3 && E == 128 ? 4 : 8);
+    // waves per workgroup (measured, scripts/bench_fused.py): width 128 -- four (one per SIMD, 242-386 registers) for three and four
+    // row tiles and for every training launch (with the q|k|v store, 31 tokens: 245 against 284 us; 16 tokens: 132 against 163),
+    // eight for the lean forward of one or two tiles (151 against 169 us); width 64 -- eight throughout
+    const int nw = nw_env == 8 || nw_env == 4 ? nw_env : (E == 128 && (nt >= 3 || qkvout) ? 4 : 8);
     const int grid = std::min(256, ceil_div(B, nw));
     ProfScope prof(s);
 #define ATT_LAUNCH3(NT_, EX_, NW_)                                                               \

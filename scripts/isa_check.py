@@ -182,62 +182,6 @@ def check_inflight(name, lines):
     return errs
 
 
-def check_asm_load_window(name, lines):
-    """attn_block_fwd (fused_fwd.hip): the next sequence's rows are requested by WRITTEN-OUT loads (inline asm) at the top of an
-    iteration and ordered by the written-out wait at the top of the next one.  Between a written-out load and the next
-    written-out `s_waitcnt vmcnt` (file order, once around the persistent loop) no instruction may read or write the load's
-    destination registers -- the compiler believes they hold their value from the asm statement on, so a copy, a spill or an
-    AGPR move of one of them would read registers the memory system has not written yet."""
-    errs = []
-    flagged = []                                  # (line, text, in_asm) of every instruction
-    in_asm = False
-    for i, l in enumerate(lines):
-        t = l.strip()
-        if t.startswith(";;#ASMSTART"):
-            in_asm = True
-        elif t.startswith(";;#ASMEND"):
-            in_asm = False
-        flagged.append(in_asm)
-    hdr = None
-    for h in loop_headers(lines):
-        _, loop, _ = split_loop(lines, h)
-        if any(flagged[i] and t.startswith("global_load_dwordx4") for i, t in loop):
-            hdr = h
-    if hdr is None:
-        return [f"{name}: no loop with written-out row loads found"]
-    before, loop, after = split_loop(lines, hdr)
-    inflight, pending_clear, nload, nwait = set(), False, 0, 0
-    for i, t in before + loop + loop + after:
-        op = t.split()[0]
-        if flagged[i] and op == "s_waitcnt" and "vmcnt" in t:
-            pending_clear = True
-            nwait += 1
-            continue
-        if op.startswith("s_"):
-            continue                              # (the alternative waits of the first / steady-state diamond: scalar code between)
-        if pending_clear:
-            inflight, pending_clear = set(), False
-        if flagged[i] and op.startswith("global_load_dwordx4"):
-            ops = t[len(op):].split(",")
-            if vregs(",".join(ops[1:]), True) & inflight or vregs(ops[0], True) & inflight:
-                errs.append(f"{name}:{i}: `{t}` overlaps a row load in flight")
-            inflight |= vregs(ops[0], True)
-            nload += 1
-            continue
-        hit = vregs(t, True) & inflight
-        if hit:
-            errs.append(f"{name}:{i}: `{t}` touches {sorted(hit)[:4]} (a = 1000+) while its row load may still be in flight")
-    if inflight:
-        errs.append(f"{name}: written-out loads not waited for before the kernel ends")
-    if nload == 0 or nwait == 0:
-        errs.append(f"{name}: written-out loads / waits not recognised ({nload}, {nwait})")
-    waits = [int(re.search(r"vmcnt\((\d+)\)", t).group(1)) for i, t in loop if flagged[i] and t.startswith("s_waitcnt") and "vmcnt" in t]
-    nst = sum(1 for _, t in loop if t.startswith("global_store"))
-    if waits and max(waits) > nst:
-        errs.append(f"{name}: wait_vm<{max(waits)}> with only {nst} store instructions in the loop")
-    return errs
-
-
 def check_asm_reads_mfma(src, kdict):
     """An inline-asm VALU instruction must never be the FIRST reader of an MFMA result: the hazard recogniser cannot see inside
     an asm string, so no wait states are inserted behind the MFMA (round 3: a hand-written v_max3_f32 in the attention block's
@@ -309,12 +253,7 @@ def main():
         for extra in ((), ("-DMIVIT_ELEM_F16",), ("-DMIVIT_WIDTH64",), ("-DMIVIT_WIDTH64", "-DMIVIT_ELEM_F16")):
             if src == "attention_fast.hip" and "-DMIVIT_WIDTH64" in extra:
                 continue
-            kd = kernels(device_asm(src, extra))
-            errs += check_asm_reads_mfma(src, kd)
-            for n, (lines, meta) in kd.items():
-                # (width 128: one or two row tiles use the written-out form; width 64: every tile count)
-                if re.search(r"attn_block_fwd_kernelILi[12]E" if "-DMIVIT_WIDTH64" not in extra else r"attn_block_fwd_kernel", n):
-                    errs += check_asm_load_window(n, lines)
+            errs += check_asm_reads_mfma(src, kernels(device_asm(src, extra)))
     for src, extra in (("rowstream.hip", ()), ("gemm_dma.hip", ()), ("wgrad_dma.hip", ()), ("fused_bwd.hip", ()),
                        ("fused_bwd.hip", ("-DMIVIT_WIDTH64",))):
         kd = kernels(device_asm(src, extra))

@@ -114,7 +114,7 @@ def _run_everything():
             out[f"attn_out_bwd_w{Ew}_" + k] = v
         for k, v in ops.qkv_bwd(_bf(_randn((M, 3 * Ew), 39)), args[4], _bf(_randn((3 * Ew, Ew), 40, 0.1)), args[0]).items():
             out[f"qkv_bwd_w{Ew}_" + k] = v
-        # the attention block's forward: one / two row tiles order their row prefetch with a counted wait (width 64: every tile count)
+        # the attention block's forward (no counted waits of its own: rides along as a repeatability check at this scale)
         for S_ in (31, 61):
             Bq = 2600
             o = ops.attn_block_fwd(_bf(_randn((Bq, S_, Ew), 32)), None, None, _bf(_randn((3 * Ew, Ew), 33, 0.1)), 0.1 * _randn((3 * Ew,), 34),

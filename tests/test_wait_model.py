@@ -197,38 +197,6 @@ def test_fused_bwd8(pieces):
         fused_bwd8(n, pieces)
 
 
-# ---------------------------------------------------------------- attn_block_fwd (one / two row tiles) ------------------
-def attn_block_fwd(nseq, NT, extras, optional=0, H=4):
-    """fused_fwd.hip::attn_block_fwd_kernel, NT <= 2: the next sequence's rows (4 NT written-out loads) are requested at the top
-    of an iteration, before its row stores; the wait at the top of the next iteration counts on the guaranteed stores of one
-    iteration (ctx 2 H NT, n 8 NT, rstd NT; q|k|v 6 H NT when compiled in) and saturates at the counter's 63."""
-    nstore = H * NT * 2 + 8 * NT + NT + (6 * H * NT if extras else 0)
-    w = Wave()
-    w.issue(("L", 0), 4 * NT)
-    for t in range(nseq):
-        w.wait(0 if t == 0 else min(63, nstore))
-        w.need(("L", t))
-        if t > 0:
-            assert w.in_flight(("st", t - 1))                 # the stores of the iteration before are not drained
-        w.issue(("L", t + 1), 4 * NT)                         # (clamped to the last sequence on the final round)
-        w.issue(("st", t), nstore + optional)
-    w.wait(0)
-
-
-@pytest.mark.parametrize("NT", [1, 2])
-@pytest.mark.parametrize("extras", [False, True])
-def test_attn_block_fwd(NT, extras):
-    for n in range(1, 6):
-        attn_block_fwd(n, NT, extras)
-        attn_block_fwd(n, NT, extras, optional=17 * NT)       # xout / zout / mean: more stores than counted, still safe
-    with pytest.raises(AssertionError):                       # counting the optional q|k|v stores without issuing them
-        w = Wave()
-        w.issue(("L", 0), 8)
-        w.wait(0); w.issue(("L", 1), 8); w.issue(("st", 0), 34)
-        w.wait(63)
-        w.need(("L", 1))
-
-
 # ---------------------------------------------------------------- gemm_pers_kernel --------------------------------------
 def gemm_pers(ntile, nst, D, per_stage, epi_ops=5):
     w = Wave()
