@@ -87,6 +87,40 @@ __device__ __forceinline__ void store4_bf16(bf16 *p, const f32x4 v) {
     *reinterpret_cast<bf16x4 *>(p) = o;
 }
 
+// ---- rows of one tile / one sequence as a RAW BUFFER (buffer_load / buffer_store with a resource descriptor in SGPRs) ----
+// The hardware range check does what per-row branches did: an access at or past `bytes` is dropped (stores) or returns zero
+// (loads).  Rows that do not exist (past the end of the sequence / of the last tile) start exactly at `bytes`, so every row access
+// is issued unconditionally, with a 32-bit lane offset that is loop-invariant plus an immediate: no 64-bit address arithmetic
+// (232 vector instructions per sequence in attn_block_fwd), no exec-mask branches around the stores (~340 scalar instructions), and
+// straight-line code the compiler can schedule across and count its vmcnt through.
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t rows_of(const void *first_row_uniform, int bytes) {          // (base must be wave-uniform)
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(first_row_uniform), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ void bst4_bf16(rsrc_t r, int off, const f32x4 v) {
+    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+    const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};      // two v_cvt_pk_bf16_f32
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, o), r, off, 0, 0);
+}
+__device__ __forceinline__ void bst_halves(rsrc_t r, int off, const bf16x8 f) {          // the two 8-byte halves, 32 bytes apart
+    struct H { u32x2_t lo, hi; };
+    const H h = __builtin_bit_cast(H, f);
+    __builtin_amdgcn_raw_buffer_store_b64(h.lo, r, off, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(h.hi, r, off + 32, 0, 0);
+}
+__device__ __forceinline__ void bst_lo(rsrc_t r, int off, const bf16x8 f) {
+    struct H { u32x2_t lo, hi; };
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(H, f).lo, r, off, 0, 0);
+}
+__device__ __forceinline__ void bst_f32(rsrc_t r, int off, float v) { __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, off, 0, 0); }
+__device__ __forceinline__ uint4 bld16(rsrc_t r, int off) {
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+    return make_uint4(v[0], v[1], v[2], v[3]);
+}
+constexpr int OOB = 0x7ffffff0;          // a lane offset past any descriptor: that lane's access is dropped
+
 // natural [rows][K] bf16 weight block (row pitch ldw elements) -> LDS operand image with pitch LD
 // The staging loops issue SU iterations' loads before the first store: with one load -> wait -> store per iteration (what a
 // loop with a run-time trip count compiles to) a workgroup spent 24 + 8 + ... serialised L2 round trips on its weights.
@@ -134,12 +168,10 @@ __device__ __forceinline__ void stage_vec(float *dst, const float *src, int n, f
 
 // column-operand fragments of 16 activation rows: lane (row = lane & 15, g) holds k = 32 ks + 8 g + 0..7.
 // load_raw issues the KS 16-byte loads (zeros for rows that do not exist); the registers ARE the MFMA operands.
-__device__ __forceinline__ void load_raw(uint4 (&raw)[KS], const bf16 *nin, int64_t row, bool valid, int g) {
+// (off = the lane's row offset inside the descriptor + 16 g)
+__device__ __forceinline__ void load_raw(uint4 (&raw)[KS], rsrc_t rows, int off) {
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-        raw[ks] = make_uint4(0u, 0u, 0u, 0u);
-        if (valid) raw[ks] = *reinterpret_cast<const uint4 *>(nin + row * E + ks * 32 + 8 * g);
-    }
+    for (int ks = 0; ks < KS; ++ks) raw[ks] = bld16(rows, off + ks * 64);
 }
 __device__ __forceinline__ bf16x8 as_frag(const uint4 &u) { return __builtin_bit_cast(bf16x8, u); }
 // The producing LayerNorm's affine is FOLDED into the consuming weights while they are staged (once per workgroup):
@@ -207,8 +239,21 @@ struct LnOut {
     bf16 *xout;                       // optional: gamma * nhat + beta
     bf16 *zout; float *mean;          // optional: pre-norm sum and mean (unfused backward)
 };
-__device__ __forceinline__ void ln_store(f32x4 (&z)[ET], int64_t row, bool valid, const float *gout, const float *bout,
-                                         const LnOut &o, int g) {
+// the same for `rows` rows starting at `first_row` (wave-uniform), as raw buffers
+struct LnDst { rsrc_t n, rstd, x, z, mean; bool hx, hz, hm; };
+__device__ __forceinline__ LnDst ln_dst(const LnOut &o, int64_t first_row, int rows) {
+    LnDst d;
+    d.n = rows_of(o.nout + first_row * E, rows * E * 2);
+    d.rstd = rows_of(o.rstd + first_row, rows * 4);
+    d.hx = o.xout != nullptr; d.hz = o.zout != nullptr; d.hm = o.mean != nullptr;
+    d.x = rows_of(d.hx ? o.xout + first_row * E : nullptr, d.hx ? rows * E * 2 : 0);
+    d.z = rows_of(d.hz ? o.zout + first_row * E : nullptr, d.hz ? rows * E * 2 : 0);
+    d.mean = rows_of(d.hm ? o.mean + first_row : nullptr, d.hm ? rows * 4 : 0);
+    return d;
+}
+// voe: the lane's byte offset of (its row, feature 4 g) in an [*, E] 16-bit row buffer; vor: its row's offset in a per-row fp32
+// buffer for the lanes g == 0, OOB for the others
+__device__ __forceinline__ void ln_store(f32x4 (&z)[ET], const LnDst &d, int voe, int vor, const float *gout, const float *bout) {
     float s = 0.f;
 #pragma unroll
     for (int et = 0; et < ET; ++et) s += z[et][0] + z[et][1] + z[et][2] + z[et][3];
@@ -217,23 +262,23 @@ __device__ __forceinline__ void ln_store(f32x4 (&z)[ET], int64_t row, bool valid
 #pragma unroll
     for (int et = 0; et < ET; ++et)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { const float d = z[et][j] - mu; q += d * d; }
+        for (int j = 0; j < 4; ++j) { const float dd = z[et][j] - mu; q += dd * dd; }
     const float rs = rsqrtf(x4_sum(q) * (1.f / E) + 1e-5f);
-    if (!valid) return;
 #pragma unroll
     for (int et = 0; et < ET; ++et) {
-        const int c = 16 * et + 4 * g;
-        if (o.zout) store4_bf16(o.zout + row * E + c, z[et]);
+        const int c = 16 * et;          // (+ 4 g: in voe)
+        if (d.hz) bst4_bf16(d.z, voe + 2 * c, z[et]);
         f32x4 nh;
 #pragma unroll
         for (int j = 0; j < 4; ++j) nh[j] = (z[et][j] - mu) * rs;
-        store4_bf16(o.nout + row * E + c, nh);
-        if (o.xout) store4_bf16(o.xout + row * E + c, nh * ld4(gout + c) + ld4(bout + c));
+        bst4_bf16(d.n, voe + 2 * c, nh);
+        if (d.hx) {
+            const int cg = c + (voe & 31) / 2;          // = 16 et + 4 g  (rows are multiples of 32 bytes)
+            bst4_bf16(d.x, voe + 2 * c, nh * ld4(gout + cg) + ld4(bout + cg));
+        }
     }
-    if (g == 0) {
-        o.rstd[row] = rs;
-        if (o.mean) o.mean[row] = mu;
-    }
+    bst_f32(d.rstd, vor, rs);
+    if (d.hm) bst_f32(d.mean, vor, mu);
 }
 
 // ================================================================================================================
@@ -277,15 +322,22 @@ __global__ __launch_bounds__(NWV * 64) void mlp_block_fwd_kernel(const MlpFwdArg
     const int ntiles = (a.M + 16 * NR - 1) / (16 * NR);
     const bf16x8 id0 = idfrag(0, cq, g), id1 = idfrag(1, cq, g);
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    int tile = blockIdx.x * NWV + wave;
+    int tile = blockIdx.x * NWV + __builtin_amdgcn_readfirstlane(wave);          // (scalar: the tile's buffer descriptors live in SGPRs)
     const int tstride = gridDim.x * NWV;
+    // lane offsets inside a tile's row buffers (loop-invariant): [*, E] 16-bit rows for loads (+ 16 g) and stores (+ 8 g), [*, F]
+    // rows, per-row fp32 values (lanes g == 0)
+    int vo_l[NR], vo_e[NR], vo_f[NR], vo_r[NR];
+#pragma unroll
+    for (int rb = 0; rb < NR; ++rb) {
+        vo_l[rb] = (rb * 16 + cq) * E * 2 + 16 * g; vo_e[rb] = (rb * 16 + cq) * E * 2 + 8 * g;
+        vo_f[rb] = (rb * 16 + cq) * F * 2 + 8 * g;  vo_r[rb] = g == 0 ? (rb * 16 + cq) * 4 : OOB;
+    }
+    auto rows_in = [&](int t) { return min(16 * NR, a.M - t * 16 * NR); };          // (valid rows of tile t)
     uint4 nx[NR][KS];
     if (tile < ntiles) {
+        const rsrc_t rin = rows_of(a.nin + (int64_t)tile * 16 * NR * E, rows_in(tile) * E * 2);
 #pragma unroll
-        for (int rb = 0; rb < NR; ++rb) {
-            const int64_t row = (int64_t)tile * 16 * NR + rb * 16 + cq;
-            load_raw(nx[rb], a.nin, row, row < a.M, g);
-        }
+        for (int rb = 0; rb < NR; ++rb) load_raw(nx[rb], rin, vo_l[rb]);
     }
     for (; tile < ntiles; tile += tstride) {
         const int64_t row0 = (int64_t)tile * 16 * NR;
@@ -296,12 +348,14 @@ __global__ __launch_bounds__(NWV * 64) void mlp_block_fwd_kernel(const MlpFwdArg
             for (int ks = 0; ks < KS; ++ks) xf[rb][ks] = as_frag(nx[rb][ks]);
         {                                        // next tile's rows: in flight while this one computes (unconditional --
             const int nxt = min(tile + tstride, ntiles - 1);          // a clamped re-read on the last round -- so the
-#pragma unroll                                                       // registers are dead until here)
-            for (int rb = 0; rb < NR; ++rb) {
-                const int64_t row = (int64_t)nxt * 16 * NR + rb * 16 + cq;
-                load_raw(nx[rb], a.nin, row, row < a.M, g);
-            }
+            const rsrc_t rin = rows_of(a.nin + (int64_t)nxt * 16 * NR * E, rows_in(nxt) * E * 2);      // registers are dead until here)
+#pragma unroll
+            for (int rb = 0; rb < NR; ++rb) load_raw(nx[rb], rin, vo_l[rb]);
         }
+        const LnDst dst = ln_dst(a.o, row0, rows_in(tile));
+        const bool has_u = EXTRAS && a.uout != nullptr, has_h = EXTRAS && a.hout != nullptr;
+        const rsrc_t ru = rows_of(has_u ? a.uout + row0 * F : nullptr, has_u ? rows_in(tile) * F * 2 : 0);
+        const rsrc_t rh = rows_of(has_h ? a.hout + row0 * F : nullptr, has_h ? rows_in(tile) * F * 2 : 0);
         f32x4 fa[ET][NR];
 #pragma unroll
         for (int et = 0; et < ET; ++et) {
@@ -330,13 +384,12 @@ __global__ __launch_bounds__(NWV * 64) void mlp_block_fwd_kernel(const MlpFwdArg
             bf16x8 hf[NR];
 #pragma unroll
             for (int rb = 0; rb < NR; ++rb) {
-                const int64_t row = row0 + rb * 16 + cq;
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    if (EXTRAS && a.uout && row < a.M) store4_bf16(a.uout + row * F + 32 * p + 16 * t + 4 * g, ha[t][rb]);
+                    if (has_u) bst4_bf16(ru, vo_f[rb] + (32 * p + 16 * t) * 2, ha[t][rb]);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) ha[t][rb][j] = act_fwd(ACT, ha[t][rb][j]);
-                    if (EXTRAS && a.hout && row < a.M) store4_bf16(a.hout + row * F + 32 * p + 16 * t + 4 * g, ha[t][rb]);
+                    if (has_h) bst4_bf16(rh, vo_f[rb] + (32 * p + 16 * t) * 2, ha[t][rb]);
                 }
                 hf[rb] = pack8(ha[0][rb], ha[1][rb]);
             }
@@ -350,11 +403,10 @@ __global__ __launch_bounds__(NWV * 64) void mlp_block_fwd_kernel(const MlpFwdArg
         }
 #pragma unroll
         for (int rb = 0; rb < NR; ++rb) {
-            const int64_t row = row0 + rb * 16 + cq;
             f32x4 z[ET];
 #pragma unroll
             for (int et = 0; et < ET; ++et) z[et] = fa[et][rb];
-            ln_store(z, row, row < a.M, gout, bout, a.o, g);
+            ln_store(z, dst, vo_e[rb], vo_r[rb], gout, bout);
         }
     }
 }
@@ -404,7 +456,15 @@ __global__ __launch_bounds__(NW * 64) void attn_block_fwd_kernel(const AttnFwdAr
 
     const bf16x8 id0 = idfrag(0, cq, g), id1 = idfrag(1, cq, g);
     const int bstride = gridDim.x * NW;
-    int b = blockIdx.x * NW + wave;
+    int b = blockIdx.x * NW + __builtin_amdgcn_readfirstlane(wave);          // (scalar: a sequence's buffer descriptors live in SGPRs)
+    // lane offsets inside a sequence's row buffers (loop-invariant): [S, E] rows for loads (+ 16 g) and stores (+ 8 g), [S, 3E]
+    // rows of the q|k|v output, per-row fp32 values (lanes g == 0)
+    int vo_l[NT], vo_e[NT], vo_q[NT], vo_r[NT];
+#pragma unroll
+    for (int rt = 0; rt < NT; ++rt) {
+        vo_l[rt] = (rt * 16 + cq) * E * 2 + 16 * g; vo_e[rt] = (rt * 16 + cq) * E * 2 + 8 * g;
+        vo_q[rt] = (rt * 16 + cq) * 3 * E * 2 + 8 * g; vo_r[rt] = g == 0 ? (rt * 16 + cq) * 4 : OOB;
+    }
     // Next sequence's rows: requested after the attention phase (into the registers the input fragments are read from: dead by
     // then), in flight under the out-projection and the epilogue.
     // (Round 3 built and measured a WRITTEN-OUT form -- inline-asm loads at the top of the iteration, before the iteration's row
@@ -417,12 +477,17 @@ __global__ __launch_bounds__(NW * 64) void attn_block_fwd_kernel(const AttnFwdAr
     //  of registers the memory system has not written yet.  Removed; scripts/ab_asm_pf.sh and DESIGN.md section 4c keep the numbers.)
     uint4 nxc[NT][KS];
     auto request = [&](int seq) {
+        const rsrc_t rin = rows_of(a.nin + (int64_t)seq * S * E, S * E * 2);
 #pragma unroll
-        for (int rt = 0; rt < NT; ++rt) load_raw(nxc[rt], a.nin, (int64_t)seq * S + rt * 16 + cq, rt * 16 + cq < S, g);
+        for (int rt = 0; rt < NT; ++rt) load_raw(nxc[rt], rin, vo_l[rt]);
     };
     if (b < a.B) request(b);
     for (; b < a.B; b += bstride) {
         const int64_t base = (int64_t)b * S;
+        const rsrc_t rctx = rows_of(a.ctx + base * E, S * E * 2);
+        const bool has_qkv = EXTRAS && a.qkvout != nullptr;          // (the launcher picks EXTRAS exactly then; a null pointer: everything dropped)
+        const rsrc_t rqkv = rows_of(has_qkv ? a.qkvout + base * 3 * E : nullptr, has_qkv ? S * 3 * E * 2 : 0);
+        const LnDst dst = ln_dst(a.o, base, S);
         bf16x8 xf[NT][KS];
 #pragma unroll
         for (int rt = 0; rt < NT; ++rt)
@@ -474,13 +539,13 @@ __global__ __launch_bounds__(NW * 64) void attn_block_fwd_kernel(const AttnFwdAr
                     for (int rt = 0; rt < NT; ++rt) {
                         if (which == 0) qf[rt] = pack8(pa[0][rt], DT == 2 ? pa[DT - 1][rt] : zero);
                         else kf[rt] = pack8(pa[0][rt], DT == 2 ? pa[DT - 1][rt] : zero);
-                        if (EXTRAS && a.qkvout && rt * 16 + cq < S) {          // (q leaves unscaled, as the reference's q_proj output)
-                            bf16 *dst = a.qkvout + (base + rt * 16 + cq) * (3 * E) + which * E + h * DH + 4 * g;
+                        if (EXTRAS) {          // (q leaves unscaled, as the reference's q_proj output)
+                            const int off = vo_q[rt] + (which * E + h * DH) * 2;
                             if (which == 0) {
-                                store4_bf16(dst, pa[0][rt] * (1.f / QSCALE));
-                                if (DT == 2) store4_bf16(dst + 16, pa[DT - 1][rt] * (1.f / QSCALE));
-                            } else if (DT == 2) store_halves(dst, dst + 16, kf[rt]);          // k: exactly the packed operand
-                            else store_lo(dst, kf[rt]);
+                                bst4_bf16(rqkv, off, pa[0][rt] * (1.f / QSCALE));
+                                if (DT == 2) bst4_bf16(rqkv, off + 32, pa[DT - 1][rt] * (1.f / QSCALE));
+                            } else if (DT == 2) bst_halves(rqkv, off, kf[rt]);          // k: exactly the packed operand
+                            else bst_lo(rqkv, off, kf[rt]);
                         }
                     }
                 }
@@ -505,7 +570,7 @@ __global__ __launch_bounds__(NW * 64) void attn_block_fwd_kernel(const AttnFwdAr
                     for (int p = 0; p < NP; ++p)
     #pragma unroll
                         for (int dt = 0; dt < DT; ++dt) vr[p][dt] = pack8(va[2 * p][dt], (2 * p + 1 < NT) ? va[2 * p + 1][dt] : zero);
-                    if (EXTRAS && a.qkvout) {         // v^T once more (lane = token): 8-byte row stores instead of 2-byte scatters
+                    if (EXTRAS) {         // v^T once more (lane = token): 8-byte row stores instead of 2-byte scatters
     #pragma unroll
                         for (int dt = 0; dt < DT; ++dt) {
                             f32x4 vt[NT];
@@ -516,7 +581,7 @@ __global__ __launch_bounds__(NW * 64) void attn_block_fwd_kernel(const AttnFwdAr
                             const f32x4 bb = ld4(bqkv + 2 * E + h * DH + 16 * dt + 4 * g);
     #pragma unroll
                             for (int rt = 0; rt < NT; ++rt)
-                                if (rt * 16 + cq < S) store4_bf16(a.qkvout + (base + rt * 16 + cq) * (3 * E) + 2 * E + h * DH + 16 * dt + 4 * g, vt[rt] + bb);
+                                bst4_bf16(rqkv, vo_q[rt] + (2 * E + h * DH + 16 * dt) * 2, vt[rt] + bb);
                         }
                     }
                     cur ^= 1;
@@ -546,13 +611,13 @@ __global__ __launch_bounds__(NW * 64) void attn_block_fwd_kernel(const AttnFwdAr
                     for (int rt = 0; rt < NT; ++rt) {
                         if (which == 0) qf[rt] = pack8(pa[0][rt], DT == 2 ? pa[DT - 1][rt] : zero);
                         else kf[rt] = pack8(pa[0][rt], DT == 2 ? pa[DT - 1][rt] : zero);
-                        if (EXTRAS && a.qkvout && rt * 16 + cq < S) {          // (q leaves unscaled, as the reference's q_proj output)
-                            bf16 *dst = a.qkvout + (base + rt * 16 + cq) * (3 * E) + which * E + h * DH + 4 * g;
+                        if (EXTRAS) {          // (q leaves unscaled, as the reference's q_proj output)
+                            const int off = vo_q[rt] + (which * E + h * DH) * 2;
                             if (which == 0) {
-                                store4_bf16(dst, pa[0][rt] * (1.f / QSCALE));
-                                if (DT == 2) store4_bf16(dst + 16, pa[DT - 1][rt] * (1.f / QSCALE));
-                            } else if (DT == 2) store_halves(dst, dst + 16, kf[rt]);          // k: exactly the packed operand
-                            else store_lo(dst, kf[rt]);
+                                bst4_bf16(rqkv, off, pa[0][rt] * (1.f / QSCALE));
+                                if (DT == 2) bst4_bf16(rqkv, off + 32, pa[DT - 1][rt] * (1.f / QSCALE));
+                            } else if (DT == 2) bst_halves(rqkv, off, kf[rt]);          // k: exactly the packed operand
+                            else bst_lo(rqkv, off, kf[rt]);
                         }
                     }
                 }
@@ -578,7 +643,7 @@ __global__ __launch_bounds__(NW * 64) void attn_block_fwd_kernel(const AttnFwdAr
                     for (int p = 0; p < NP; ++p)
     #pragma unroll
                         for (int dt = 0; dt < DT; ++dt) vr[p][dt] = pack8(va[2 * p][dt], (2 * p + 1 < NT) ? va[2 * p + 1][dt] : zero);
-                    if (EXTRAS && a.qkvout) {         // v^T once more (lane = token): 8-byte row stores instead of 2-byte scatters
+                    if (EXTRAS) {         // v^T once more (lane = token): 8-byte row stores instead of 2-byte scatters
     #pragma unroll
                         for (int dt = 0; dt < DT; ++dt) {
                             f32x4 vt[NT];
@@ -593,7 +658,7 @@ __global__ __launch_bounds__(NW * 64) void attn_block_fwd_kernel(const AttnFwdAr
                             }
     #pragma unroll
                             for (int rt = 0; rt < NT; ++rt)
-                                if (rt * 16 + cq < S) store4_bf16(a.qkvout + (base + rt * 16 + cq) * (3 * E) + 2 * E + h * DH + 16 * dt + 4 * g, vt[rt]);
+                                bst4_bf16(rqkv, vo_q[rt] + (2 * E + h * DH + 16 * dt) * 2, vt[rt]);
                         }
                     }
                 }
@@ -637,10 +702,7 @@ __global__ __launch_bounds__(NW * 64) void attn_block_fwd_kernel(const AttnFwdAr
                 if (DT == 1 && (h & 1) == 0) { ot_even[it] = ot[0]; continue; }        // (stored with its odd neighbour)
                 const int kb = h / HB;                                               // the 32-feature block this head completes
                 cf[kb][it] = DT == 2 ? pack8(ot[0], ot[DT - 1]) : pack8(ot_even[it], ot[0]);
-                if (it * 16 + cq < S) {
-                    bf16 *dst = a.ctx + (base + it * 16 + cq) * E + kb * 32 + 4 * g;
-                    store_halves(dst, dst + 16, cf[kb][it]);
-                }
+                bst_halves(rctx, vo_e[it] + kb * 64, cf[kb][it]);
             }
         }
         request(min(b + bstride, a.B - 1));      // (unconditional: a clamped re-read on the last round)
@@ -697,7 +759,7 @@ __global__ __launch_bounds__(NW * 64) void attn_block_fwd_kernel(const AttnFwdAr
             f32x4 z[ET];
 #pragma unroll
             for (int nt = 0; nt < ET; ++nt) z[nt] = oa[nt][rt];
-            ln_store(z, base + rt * 16 + cq, rt * 16 + cq < S, gout, bout, a.o, g);
+            ln_store(z, dst, vo_e[rt], vo_r[rt], gout, bout);
         }
     }
 }
