@@ -77,6 +77,16 @@ size_t mivit_embed_wgrad_bf16_workspace_bytes(int M, int K, int E);
 int mivit_embed_wgrad_bf16(const void *dy_bf16, const float *x, int M, int K, int E, float *dW, void *workspace,
                            size_t workspace_bytes, void *stream);
 
+/* The same two launches for SMALL frames (patch sizes up to 16 x 16 pixels; the shipped configurations use 9 x 9 = 81 and
+ * 13 x 13 = 169): x[M, K] fp32 with ANY K <= 256 -- rows are only 4-byte aligned --, E = 64 or 128, M >= 256, M * K * 4 < 2^32.
+ * csrc/wavestream.hip (AF32) / csrc/wgrad_small.hip (XF32): the frames are read through a raw buffer at dword alignment and
+ * converted in registers.  db (optional) = column sums of dy.  Return 3 outside these constraints. */
+int mivit_embed_small_supported(int M, int K, int E);
+int mivit_embed_small_fwd(const float *x, const void *W_bf16, const float *bias, int M, int K, int E, void *y_bf16, void *stream);
+size_t mivit_embed_small_wgrad_workspace_bytes(int M, int K, int E);
+int mivit_embed_small_wgrad(const void *dy_bf16, const float *x, int M, int K, int E, float *dW, float *db, void *workspace,
+                            size_t workspace_bytes, void *stream);
+
 /* bf16-mode streaming kernels of the encoder-layer projections (csrc/rowstream.hip, csrc/wgrad_dma.hip): weights are
  * given as bf16 copies, activations are bf16, M = all tokens of the batch.  Return 3 when the shape is outside the
  * kernels' constraints (then use mivit_linear_*).

@@ -124,6 +124,10 @@ SYMBOLS = {
     "mivit_render_frames": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "mivit_attn_out_bwd_workspace_bytes": (c_size_t, [c_int]),
     "mivit_attn_out_bwd": (c_int, [c_void_p] * 6 + [c_int] + [c_void_p] * 7 + [c_size_t, c_void_p]),
+    "mivit_embed_small_supported": (c_int, [c_int, c_int, c_int]),
+    "mivit_embed_small_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "mivit_embed_small_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "mivit_embed_small_wgrad": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "mivit_qkv_bwd_workspace_bytes": (c_size_t, [c_int]),
     "mivit_qkv_bwd": (c_int, [c_void_p] * 4 + [c_int] + [c_void_p] * 4 + [c_size_t, c_void_p]),
     "mivit_qkv_bwd_workspace_bytes_w64": (c_size_t, [c_int]),

@@ -346,6 +346,23 @@ size_t wgrad_small_ws_bytes(int M, int N, int K);
 int launch_wgrad_small(const void *dy, int64_t lddy, const void *x, int64_t ldx, int M, int N, int K, float *dW, float *db,
                        void *ws, size_t ws_bytes, hipStream_t s);
 
+
+// linear frame embedding of SMALL frames (patch sizes up to 16 x 16, any row length: wavestream.hip / wgrad_small.hip, AF32 / XF32)
+bool embed_small_fwd_supported(int M, int K, int E, const void *X, const void *Y);
+int launch_embed_small_fwd(const float *X, const void *W_bf16, const float *bias, void *Y, int M, int K, int E, hipStream_t s);
+bool embed_small_wgrad_supported(int M, int N, int K, int64_t lddy, const void *dy, const void *x);
+size_t embed_small_wgrad_ws_bytes(int M, int N, int K);
+int launch_embed_small_wgrad(const void *dy, int64_t lddy, const float *x, int M, int N, int K, float *dW, float *db, void *ws,
+                             size_t ws_bytes, hipStream_t s);
+
+// ... and their IEEE-half builds
+bool embed_small_fwd_supported_f16(int M, int K, int E, const void *X, const void *Y);
+int launch_embed_small_fwd_f16(const float *X, const void *W_bf16, const float *bias, void *Y, int M, int K, int E, hipStream_t s);
+bool embed_small_wgrad_supported_f16(int M, int N, int K, int64_t lddy, const void *dy, const void *x);
+size_t embed_small_wgrad_ws_bytes_f16(int M, int N, int K);
+int launch_embed_small_wgrad_f16(const void *dy, int64_t lddy, const float *x, int M, int N, int K, float *dW, float *db, void *ws,
+                             size_t ws_bytes, hipStream_t s);
+
 // the same seven units compiled with -DMIVIT_ELEM_F16 (elem.h): IEEE-half operands and stored activations, same contracts
 bool attention_fast_supported_f16(int dtype, int S, int Dh);
 int launch_attention_fwd_fast_f16(const void *qkv, int B, int S, int H, int Dh, void *ctx, hipStream_t s);

@@ -25,6 +25,11 @@
 #define wgrad_dma_supported wgrad_dma_supported_f16
 #define wgrad_dma_ws_bytes wgrad_dma_ws_bytes_f16
 #define launch_wgrad_dma launch_wgrad_dma_f16
+#define embed_small_fwd_supported embed_small_fwd_supported_f16
+#define launch_embed_small_fwd launch_embed_small_fwd_f16
+#define embed_small_wgrad_supported embed_small_wgrad_supported_f16
+#define embed_small_wgrad_ws_bytes embed_small_wgrad_ws_bytes_f16
+#define launch_embed_small_wgrad launch_embed_small_wgrad_f16
 #define wgrad_small_supported wgrad_small_supported_f16
 #define wgrad_small_ws_bytes wgrad_small_ws_bytes_f16
 #define launch_wgrad_small launch_wgrad_small_f16

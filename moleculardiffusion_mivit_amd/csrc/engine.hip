@@ -178,6 +178,7 @@ Ws make_ws(const mivit_plan *p, int B, int T, bool bwd) {
             // (the bf16 and f16 builds of the weight-gradient kernels size their workspaces identically)
             if (c.dtype != MIVIT_F32 && n % 128 == 0 && k % 128 == 0 && m >= 256) b += wgrad_dma_ws_bytes(m, n, k);
             if (c.dtype != MIVIT_F32 && m >= 256) b = std::max(b, wgrad_small_ws_bytes(m, n, k));
+            if (c.dtype != MIVIT_F32 && m >= 256) b = std::max(b, embed_small_wgrad_ws_bytes(m, n, k));      // (the embedding's shape only)
             if (b > wg) wg = b;
         };
         mx((int)M, 3 * E, E); mx((int)M, E, E); mx((int)M, F, E); mx((int)M, E, F);
@@ -225,14 +226,23 @@ struct StreamOps {
     decltype(&launch_embed_fwd_dma) embed_fwd;
     decltype(&embed_wgrad_dma_ws_bytes) embed_wgrad_ws;
     decltype(&launch_embed_wgrad_dma) embed_wgrad;
+    decltype(&embed_small_fwd_supported) embed_small_fwd_ok;          // small frames (any row length <= 256 pixels)
+    decltype(&launch_embed_small_fwd) embed_small_fwd;
+    decltype(&embed_small_wgrad_supported) embed_small_wgrad_ok;
+    decltype(&embed_small_wgrad_ws_bytes) embed_small_wgrad_ws;
+    decltype(&launch_embed_small_wgrad) embed_small_wgrad;
 };
 static const StreamOps kStreamBf16 = {rowstream_supported, wavestream_supported, launch_rowstream, wgrad_dma_supported, wgrad_dma_ws_bytes,
                                       launch_wgrad_dma, wgrad_small_supported, wgrad_small_ws_bytes, launch_wgrad_small,
-                                      embed_dma_supported, launch_embed_fwd_dma, embed_wgrad_dma_ws_bytes, launch_embed_wgrad_dma};
+                                      embed_dma_supported, launch_embed_fwd_dma, embed_wgrad_dma_ws_bytes, launch_embed_wgrad_dma,
+                                      embed_small_fwd_supported, launch_embed_small_fwd, embed_small_wgrad_supported,
+                                      embed_small_wgrad_ws_bytes, launch_embed_small_wgrad};
 static const StreamOps kStreamF16 = {rowstream_supported_f16, wavestream_supported_f16, launch_rowstream_f16, wgrad_dma_supported_f16,
                                      wgrad_dma_ws_bytes_f16, launch_wgrad_dma_f16, wgrad_small_supported_f16, wgrad_small_ws_bytes_f16,
                                      launch_wgrad_small_f16, embed_dma_supported_f16, launch_embed_fwd_dma_f16,
-                                     embed_wgrad_dma_ws_bytes_f16, launch_embed_wgrad_dma_f16};
+                                     embed_wgrad_dma_ws_bytes_f16, launch_embed_wgrad_dma_f16, embed_small_fwd_supported_f16,
+                                     launch_embed_small_fwd_f16, embed_small_wgrad_supported_f16, embed_small_wgrad_ws_bytes_f16,
+                                     launch_embed_small_wgrad_f16};
 static const StreamOps *stream_ops(int dtype) {
     static const bool f16_off = getenv("MIVIT_NO_F16_STREAM") != nullptr;        // (A/B: fp16 on the general kernels, as in rounds 1-2)
     return dtype == MIVIT_BF16 ? &kStreamBf16 : (dtype == MIVIT_F16 && !f16_off ? &kStreamF16 : nullptr);
@@ -256,6 +266,11 @@ int lin_fwd(int dtype, const void *x, int x_f32, int64_t ldx, const void *W, con
                                       reinterpret_cast<uintptr_t>(resid) | reinterpret_cast<uintptr_t>(pre)) & 15) == 0) {
         prof_set_tag(MIVIT_PROF_LINEAR_FWD);
         return launch_gemm_dma_fwd(x, ldx, W, b, M, N, K, act, resid, ldr, y, ldy, pre, s);
+    }
+    if (so && x_f32 && !y_f32 && ldx == K && ldy == N && act == MIVIT_ACT_NONE && !resid && !pre &&
+        so->embed_small_fwd_ok(M, K, N, x, y)) {          // the linear embedding of small frames (fp32 rows of any length)
+        prof_set_tag(MIVIT_PROF_EMBED_FWD);
+        return so->embed_small_fwd(static_cast<const float *>(x), W, b, y, M, K, N, s);
     }
     LinearFwdArgs a = {};
     a.dtype = dtype; a.x = x; a.x_is_f32 = x_f32 || dtype == MIVIT_F32; a.ldx = ldx; a.W = W;
@@ -300,6 +315,10 @@ int lin_wgrad(int dtype, const void *dy, int64_t lddy, const void *x, int x_f32,
         wsb >= so->wgrad_small_ws(M, N, K) && wsb >= linear_wgrad_ws_bytes(M, N, K)) {
         prof_set_tag(MIVIT_PROF_LINEAR_WGRAD);
         return so->wgrad_small(dy, lddy, x, ldx, M, N, K, dW, db, ws, wsb, s);      // db (optional) from the same pass
+    }
+    if (so && x_f32 && dW && ldx == K && so->embed_small_wgrad_ok(M, N, K, lddy, dy, x) && wsb >= so->embed_small_wgrad_ws(M, N, K)) {
+        prof_set_tag(MIVIT_PROF_EMBED_WGRAD);
+        return so->embed_small_wgrad(dy, lddy, static_cast<const float *>(x), M, N, K, dW, db, ws, wsb, s);
     }
     LinearWgradArgs a = {};
     a.dtype = dtype; a.dy = dy; a.dy_is_f32 = dtype == MIVIT_F32; a.lddy = lddy; a.x = x;

@@ -10,6 +10,13 @@
 //   * the epilogue is wave-private (fp32 scratch of 16 x 128 per wave, row statistics of the LayerNorm by 2 shuffles),
 //     so waves never wait for each other: no ring, no barrier, no DMA bookkeeping on the streaming path;
 //   * dgrad reads the natural [n][k] weight image with ds_read_b64_tr_b16.
+//
+// AF32 (round 3): the forward kernel as the LINEAR FRAME EMBEDDING of small frames (reference helpers/models.py:146-164; patch
+// sizes up to 16 x 16: 9 x 9 = 81 and 13 x 13 = 169 pixels in the shipped configurations; wider frames use embed.hip): A is the
+// fp32 frame matrix [M, Kt] with ANY Kt <= K -- rows are only 4-byte aligned --, read through a raw buffer (16-byte loads at dword
+// alignment; the range check returns zero past the end of the tensor), converted to the 16-bit element type in registers with
+// the pixels past Kt (the next row's) zeroed; the weight slice [BN, Kt] is copied element-wise into a zero-padded image.  These
+// shapes ran on the general register-staged GEMM with fp32 A before: 65 us of the 1.55 ms Framerate-shape step.
 #include "common.h"
 #include "stream_prims.h"
 #include <stdlib.h>
@@ -30,6 +37,7 @@ struct WsArgs {
     bf16 *C2;                      // optional pre-activation copy (same ld as C)
     const float *gamma, *beta;     // fused LayerNorm (N == 128 only)
     bf16 *Y; int64_t ldy; float *mean, *rstd;
+    int Kt;                        // AF32 only: the true row length of the fp32 A (= ldw of W), <= K
 };
 
 
@@ -50,7 +58,8 @@ struct WsCfg {
 
 
 // E_KIND: 0 none, 1 residual add (forward), 2 activation-derivative multiply (dgrad), 3 residual add of a gradient
-template <int K, int BN, bool DGRAD, bool LN, int E_KIND>
+typedef unsigned int ws_u32x4 __attribute__((ext_vector_type(4)));
+template <int K, int BN, bool DGRAD, bool LN, int E_KIND, bool AF32 = false>
 __global__ __launch_bounds__((K == 64 ? 16 : (K == 128 ? 12 : 8)) * 64) void wavestream_kernel(const WsArgs a) {
     using C = WsCfg<K, BN, DGRAD>;
     constexpr int LDC = C::LDC, TN = BN / 16, NCH = BN / 32;
@@ -72,7 +81,14 @@ __global__ __launch_bounds__((K == 64 ? 16 : (K == 128 ? 12 : 8)) * 64) void wav
     }
 
     // ---- weight slice -> LDS, once ----
-    if (!DGRAD) {       // rows n0 .. n0+127 of W [N, K]: k-contiguous
+    if (AF32) {         // W [N, Kt], rows 2-byte aligned: element-wise into the zero-padded image
+        for (int i = tid; i < BN * K; i += NT) {
+            const int n = i / K, k = i - n * K;
+            bf16 w; w.v = 0;
+            if (k < a.Kt) w = a.W[(int64_t)(n0 + n) * a.ldw + k];
+            Wimg[n * C::W_LD + k] = w;
+        }
+    } else if (!DGRAD) {       // rows n0 .. n0+127 of W [N, K]: k-contiguous
         for (int i = tid; i < BN * (K / 8); i += NT) {
             const int n = i / (K / 8), c = i - n * (K / 8);
             *reinterpret_cast<uint4 *>(Wimg + n * C::W_LD + c * 8) = *reinterpret_cast<const uint4 *>(a.W + (int64_t)(n0 + n) * a.ldw + c * 8);
@@ -99,23 +115,44 @@ __global__ __launch_bounds__((K == 64 ? 16 : (K == 128 ? 12 : 8)) * 64) void wav
     const bf16 *E = E_KIND == 2 ? a.dact : a.resid;
     const int64_t lde = E_KIND == 2 ? a.ldd : a.ldr;
 
-    bf16x8 nx[PF][KS];
-    auto load_tile = [&](int t, bf16x8 (&dst)[KS]) {
-        const bf16 *ap = a.A + (int64_t)min(t * 16 + cq, a.M - 1) * a.lda + 8 * g;
+    bf16x8 nx[PF][AF32 ? 2 * KS : KS];          // (AF32: the raw fp32 pixels, two 16-byte halves per fragment)
+    // AF32: the frames as one raw buffer (the launcher checks M * Kt * 4 < 2^32)
+    const __amdgpu_buffer_rsrc_t arows = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16 *>(a.A), 0, AF32 ? a.M * a.Kt * 4 : 0, 0x00020000);
+    auto load_tile = [&](int t, bf16x8 (&dst)[AF32 ? 2 * KS : KS]) {
+        if constexpr (AF32) {
+            const int off = (min(t * 16 + cq, a.M - 1) * a.Kt + 8 * g) * 4;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) dst[ks] = *reinterpret_cast<const bf16x8 *>(ap + ks * 32);
+            for (int ks = 0; ks < KS; ++ks) {
+                dst[2 * ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(arows, off + ks * 128, 0, 0));
+                dst[2 * ks + 1] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(arows, off + ks * 128 + 16, 0, 0));
+            }
+        } else {
+            const bf16 *ap = a.A + (int64_t)min(t * 16 + cq, a.M - 1) * a.lda + 8 * g;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) dst[ks] = *reinterpret_cast<const bf16x8 *>(ap + ks * 32);
+        }
     };
 #pragma unroll
     for (int i = 0; i < PF; ++i) load_tile(min(tile + i * stride, ntiles - 1), nx[i]);
 
     for (; tile < ntiles; tile += stride) {
         bf16x8 cur[KS];
+        if constexpr (AF32) {          // fp32 pixels -> element type; pixels past Kt (the next row's) are zeroed
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) cur[ks] = nx[0][ks];
+            for (int ks = 0; ks < KS; ++ks) {
+                const ws_u32x4 lo = __builtin_bit_cast(ws_u32x4, nx[0][2 * ks]), hi = __builtin_bit_cast(ws_u32x4, nx[0][2 * ks + 1]);
+                const uint32_t w[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) cur[ks][e] = (__bf16)(ks * 32 + 8 * g + e < a.Kt ? __uint_as_float(w[e]) : 0.f);
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) cur[ks] = nx[0][ks];
+        }
 #pragma unroll
         for (int i = 0; i + 1 < PF; ++i)
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) nx[i][ks] = nx[i + 1][ks];
+            for (int ks = 0; ks < (AF32 ? 2 * KS : KS); ++ks) nx[i][ks] = nx[i + 1][ks];
         load_tile(min(tile + PF * stride, ntiles - 1), nx[PF - 1]);
 
         f32x4 acc[TN];
@@ -192,10 +229,10 @@ __global__ __launch_bounds__((K == 64 ? 16 : (K == 128 ? 12 : 8)) * 64) void wav
     }
 }
 
-template <int K, int BN, bool DGRAD, bool LN, int E_KIND>
+template <int K, int BN, bool DGRAD, bool LN, int E_KIND, bool AF32 = false>
 int ws_launch(const WsArgs &a, hipStream_t s) {
     using C = WsCfg<K, BN, DGRAD>;
-    auto kern = wavestream_kernel<K, BN, DGRAD, LN, E_KIND>;
+    auto kern = wavestream_kernel<K, BN, DGRAD, LN, E_KIND, AF32>;
     MIVIT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
     const int ntn = a.N / BN, ntiles = ceil_div(a.M, 16);
     int gy = 256 / ntn;                                       // one resident workgroup per CU, no tail round
@@ -266,7 +303,44 @@ int launch_wavestream(bool dgrad, const void *A, int64_t lda, const void *W_bf16
     return ws_dispatch<128, 64>(a, dgrad, ln, s);
 }
 
+// ---- linear frame embedding of small frames: Y [M, E] = X [M, K] (fp32, any K <= 256) W^T + b ----
+static int frame_kp(int K) { return K <= 64 ? 64 : K <= 96 ? 96 : K <= 128 ? 128 : K <= 192 ? 192 : K <= 256 ? 256 : 0; }
+bool embed_small_fwd_supported(int M, int K, int E, const void *X, const void *Y) {
+    static const bool off = getenv("MIVIT_NO_EMBED_SMALL") != nullptr;
+    return !off && frame_kp(K) != 0 && (E == 64 || E == 128) && M >= 256 && (int64_t)M * K * 4 < (1ll << 32) &&
+           (reinterpret_cast<uintptr_t>(X) & 3) == 0 && aligned16(Y);
+}
+int launch_embed_small_fwd(const float *X, const void *W_bf16, const float *bias, void *Y, int M, int K, int E, hipStream_t s) {
+    WsArgs a = {};
+    a.A = reinterpret_cast<const bf16 *>(X); a.lda = K; a.W = static_cast<const bf16 *>(W_bf16); a.ldw = K;
+    a.M = M; a.N = E; a.K = frame_kp(K); a.Kt = K; a.bias = bias; a.act = MIVIT_ACT_NONE;
+    a.C = static_cast<bf16 *>(Y); a.ldc = E;
+#define EMB_SMALL(KP_)                                                                            \
+    do {                                                                                          \
+        if (E == 64) return ws_launch<KP_, 64, false, false, 0, true>(a, s);                      \
+        return ws_launch<KP_, 128, false, false, 0, true>(a, s);                                  \
+    } while (0)
+    switch (a.K) {
+        case 64: EMB_SMALL(64);
+        case 96: EMB_SMALL(96);
+        case 128: EMB_SMALL(128);
+        case 192: EMB_SMALL(192);
+        case 256: EMB_SMALL(256);
+    }
+#undef EMB_SMALL
+    MIVIT_FAIL("embed_small_fwd: unsupported frame size %d", K);
+}
+
 #ifndef MIVIT_ELEM_F16      // operator-level C-ABI: declared for bf16 (include/mivit_hip.h)
+extern "C" int mivit_embed_small_supported(int M, int K, int E) {
+    return frame_kp(K) != 0 && (E == 64 || E == 128) && M >= 256 && (int64_t)M * K * 4 < (1ll << 32) && !getenv("MIVIT_NO_EMBED_SMALL");
+}
+extern "C" int mivit_embed_small_fwd(const float *X, const void *W_bf16, const float *bias, int M, int K, int E, void *Y, void *stream) {
+    MIVIT_CHECK(X && W_bf16 && Y, "embed_small_fwd: null pointer");
+    if (!embed_small_fwd_supported(M, K, E, X, Y)) { mivit_set_error("embed_small_fwd: unsupported shape"); return 3; }
+    prof_set_tag(MIVIT_PROF_OP);
+    return launch_embed_small_fwd(X, W_bf16, bias, Y, M, K, E, static_cast<hipStream_t>(stream));
+}
 extern "C" int mivit_wavestream_fwd(const void *x, int64_t ldx, const void *W_bf16, const float *bias, int M, int N, int K,
                                     int act, const void *resid, int64_t ldr, void *y, int64_t ldy, void *y_preact,
                                     const float *ln_gamma, const float *ln_beta, void *ln_out, float *mean, float *rstd,

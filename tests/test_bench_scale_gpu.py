@@ -112,6 +112,49 @@ def test_embed_wgrad_exact_bench_scale():
     assert torch.equal(dW, ref.float())
 
 
+# small frames (patch sizes up to 16 x 16: the shipped 9 x 9 and 13 x 13 among them): fp32 rows of ANY length, csrc/wavestream.hip (AF32)
+# and csrc/wgrad_small.hip (XF32).  122 911 rows = the Framerate shape at 4096 sequences (+ a ragged tail), every persistent wave
+# walks several tiles / chunks; 300 rows: one partial pass.
+@pytest.mark.parametrize("M", [122880 + 31, 300])
+@pytest.mark.parametrize("K,Ed", [(81, 64), (169, 64), (169, 128), (25, 64), (121, 64), (225, 64), (256, 128), (96, 64)])
+def test_embed_small_frames_exact(M, K, Ed):
+    """emb = X W^T + b and dW = dY^T X, db = colsum(dY) on small integers (reference models.py:153-164 and its autograd): exact."""
+    from moleculardiffusion_mivit_amd import _native as N
+    assert N.lib.mivit_embed_small_supported(M, K, Ed)
+    x = _ints((M, K), -3, 3, M + K)
+    W = _ints((Ed, K), -2, 2, M + K + 1)
+    b = _ints((Ed,), -4, 4, M + K + 2)
+    y = torch.empty(M, Ed, dtype=torch.bfloat16, device="cuda")
+    Wb = _bf(W)
+    N.check(N.lib.mivit_embed_small_fwd(_p(x), _p(Wb), _p(b), M, K, Ed, _p(y), _st()), "embed_small_fwd")
+    ref = x.double() @ W.double().t() + b.double()
+    assert torch.equal(y.float(), ref.float().bfloat16().float())
+    dy = _ints((M, Ed), -2, 2, M + K + 3)
+    ws = torch.empty(max(N.lib.mivit_embed_small_wgrad_workspace_bytes(M, K, Ed), 16), dtype=torch.uint8, device="cuda")
+    dW, db = torch.empty(Ed, K, device="cuda"), torch.empty(Ed, device="cuda")
+    dyb = _bf(dy)
+    N.check(N.lib.mivit_embed_small_wgrad(_p(dyb), _p(x), M, K, Ed, _p(dW), _p(db), _p(ws), ws.numel(), _st()), "embed_small_wgrad")
+    refw = dy.double().t() @ x.double()
+    assert float(refw.abs().max()) < 2 ** 24
+    assert torch.equal(dW, refw.float())
+    assert torch.equal(db, dy.double().sum(0).float())
+
+
+def test_embed_small_frames_do_not_leak_across_rows():
+    """The contraction is padded past the end of a row (the loads there return the NEXT row's pixels): a NaN frame must poison its
+    own token only, and the last row must not read past the tensor."""
+    from moleculardiffusion_mivit_amd import _native as N
+    M, K, Ed = 1000, 81, 64
+    x = _ints((M, K), -3, 3, 7)
+    x[501] = float("nan")
+    W, b = _ints((Ed, K), -2, 2, 8), _ints((Ed,), -4, 4, 9)
+    y = torch.empty(M, Ed, dtype=torch.bfloat16, device="cuda")
+    Wb = _bf(W)
+    N.check(N.lib.mivit_embed_small_fwd(_p(x), _p(Wb), _p(b), M, K, Ed, _p(y), _st()), "embed_small_fwd")
+    bad = torch.isnan(y.float()).any(dim=1)
+    assert bool(bad[501]) and int(bad.sum()) == 1
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # row-stream GEMMs at >= 140 000 rows: every workgroup walks >= 2 row tiles (grid <= 512 workgroups), ragged last tile
 # ---------------------------------------------------------------------------------------------------------------------
