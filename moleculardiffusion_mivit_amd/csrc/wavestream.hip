@@ -117,10 +117,10 @@ __global__ __launch_bounds__((K == 64 ? 16 : (K == 128 ? 12 : 8)) * 64) void wav
 
     bf16x8 nx[PF][AF32 ? 2 * KS : KS];          // (AF32: the raw fp32 pixels, two 16-byte halves per fragment)
     // AF32: the frames as one raw buffer (the launcher checks M * Kt * 4 < 2^32)
-    const __amdgpu_buffer_rsrc_t arows = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16 *>(a.A), 0, AF32 ? a.M * a.Kt * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t arows = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16 *>(a.A), 0, AF32 ? (int)((unsigned)a.M * (unsigned)a.Kt * 4u) : 0, 0x00020000);
     auto load_tile = [&](int t, bf16x8 (&dst)[AF32 ? 2 * KS : KS]) {
         if constexpr (AF32) {
-            const int off = (min(t * 16 + cq, a.M - 1) * a.Kt + 8 * g) * 4;
+            const int off = (int)(((unsigned)min(t * 16 + cq, a.M - 1) * (unsigned)a.Kt + 8u * g) * 4u);          // (< 2^32: unsigned arithmetic)
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 dst[2 * ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(arows, off + ks * 128, 0, 0));

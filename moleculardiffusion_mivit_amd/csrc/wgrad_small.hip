@@ -64,7 +64,7 @@ __global__ __launch_bounds__(NW * 64) void wgrad_small_kernel(const WsmArgs a) {
     const int nchunks = (a.M + CH - 1) / CH, stride = gridDim.x * NW;
     uint4 ra[VA], rb[XF32 ? 2 * VB : VB];
     // XF32: the frames as one raw buffer (the launcher checks M * K * 4 < 2^32)
-    const __amdgpu_buffer_rsrc_t xrows = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16 *>(a.X), 0, XF32 ? a.M * a.K * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xrows = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16 *>(a.X), 0, XF32 ? (int)((unsigned)a.M * (unsigned)a.K * 4u) : 0, 0x00020000);
     auto load_chunk = [&](int c) {
 #pragma unroll
         for (int v = 0; v < VA; ++v) {
@@ -75,7 +75,9 @@ __global__ __launch_bounds__(NW * 64) void wgrad_small_kernel(const WsmArgs a) {
         for (int v = 0; v < VB; ++v) {
             const int idx = v * 64 + lane, r = idx / (KB / 8), col = (idx % (KB / 8)) * 8, row = c * CH + r;
             if constexpr (XF32) {
-                const int off = (row * a.K + col) * 4;          // (rows past M: past the end of the buffer -> zeros)
+                // (rows past M: at or past the end of the buffer -> zeros; < 2^32 by the launcher's check, unsigned arithmetic:
+                //  a row index past M can wrap only for M * K * 4 within 32 rows of 2^32 -- excluded there)
+                const int off = (int)(((unsigned)row * (unsigned)a.K + (unsigned)col) * 4u);
                 const u32x4_t lo = __builtin_amdgcn_raw_buffer_load_b128(xrows, off, 0, 0), hi = __builtin_amdgcn_raw_buffer_load_b128(xrows, off + 16, 0, 0);
                 rb[2 * v] = make_uint4(lo[0], lo[1], lo[2], lo[3]); rb[2 * v + 1] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
             } else {
@@ -202,7 +204,7 @@ int frame_nb(int N, int K) {
 
 bool embed_small_wgrad_supported(int M, int N, int K, int64_t lddy, const void *dy, const void *x) {
     static const bool off = getenv("MIVIT_NO_EMBED_SMALL") != nullptr;
-    return !off && frame_nb(N, K) != 0 && M >= 256 && (int64_t)M * K * 4 < (1ll << 32) && lddy % 8 == 0 &&
+    return !off && frame_nb(N, K) != 0 && M >= 256 && ((int64_t)M + 2 * CH) * K * 4 < (1ll << 32) && lddy % 8 == 0 &&
            (reinterpret_cast<uintptr_t>(dy) & 15) == 0 && (reinterpret_cast<uintptr_t>(x) & 3) == 0;
 }
 size_t embed_small_wgrad_ws_bytes(int M, int N, int K) {
