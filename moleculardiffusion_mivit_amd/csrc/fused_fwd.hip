@@ -363,7 +363,10 @@ __global__ __launch_bounds__(NWV * 64) void mlp_block_fwd_kernel(const MlpFwdArg
 #pragma unroll
             for (int rb = 0; rb < NR; ++rb) fa[et][rb] = bv + gv * mma((et & 1) ? id1 : id0, xf[rb][et >> 1], zero);   // bias + residual
         }
-#pragma unroll 2
+#ifndef MIVIT_MLP_P_UNROLL          // (A/B, scripts/ab_rebuild.sh, us per layer / ms per step: 1 -> 94.1 / 0.499, 2 -> 93.0 / 0.498, 4 -> 102.3 / 0.527, 8 -> 97.3 / 0.540)
+#define MIVIT_MLP_P_UNROLL 2
+#endif
+#pragma unroll MIVIT_MLP_P_UNROLL
         for (int p = 0; p < F / 32; ++p) {
             // h^T for hidden units 32p .. 32p+31 (two feature tiles), all NR row blocks
             f32x4 ha[2][NR];
