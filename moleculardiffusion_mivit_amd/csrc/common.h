@@ -395,6 +395,10 @@ int launch_wgrad_small_f16(const void *dy, int64_t lddy, const void *x, int64_t 
 // out[n] (+)= sum_p part[p*n_stride + n]   (deterministic slab reduce)
 int launch_slab_reduce(const float *part, int nparts, int64_t n, float *out, int accumulate, hipStream_t s);
 int launch_slab_reduce_strided(const float *part, int nparts, int64_t stride, int64_t n, float *out, hipStream_t s);
+// queue the strided reductions issued from here on (their slabs must stay untouched) / run the queue as one launch
+void slab_defer_begin();
+void slab_defer_cancel();
+int slab_defer_flush(hipStream_t s);
 // up to three (slab, output) pairs of the same shape in one launch; pass null outputs from the end
 int launch_slab_reduce3(const float *p0, float *o0, const float *p1, float *o1, const float *p2, float *o2, int nparts,
                         int n, int accumulate, hipStream_t s);

@@ -184,7 +184,8 @@ Ws make_ws(const mivit_plan *p, int B, int T, bool bwd) {
         mx((int)M, 3 * E, E); mx((int)M, E, E); mx((int)M, F, E); mx((int)M, E, F);
         if (fused) {
             const FusedOps *fo = fused_ops(c.dtype, E);
-            wg = std::max(std::max(wg, fo->mlp_bwd_ws((int)M)), std::max(fo->attn_out_bwd_ws((int)M), fo->qkv_bwd_ws((int)M)));
+            // (one region each: their slab reductions are deferred to one launch per layer, so the three slab sets coexist)
+            wg = std::max(wg, fo->mlp_bwd_ws((int)M) + fo->attn_out_bwd_ws((int)M) + fo->qkv_bwd_ws((int)M));
         }
         if (c.embedding != MIVIT_EMBED_EXTERNAL) {
             mx((int)Mt, E, c.patch_size * c.patch_size);
@@ -671,6 +672,7 @@ static int backward_impl(const mivit_plan *plan, const float *params, const floa
                                 : static_cast<const void *>(P + off);
     };
 
+    slab_defer_cancel();          // (a queue left behind by a call that failed mid-layer)
     for (int st = stage_begin; st < stage_end; ++st) {
         if (st == 0) {
             // ---- head + final norm ----
@@ -724,6 +726,20 @@ static int backward_impl(const mivit_plan *plan, const float *params, const floa
             n2.ws = at(ws, w.ln); n2.ws_bytes = w.ln_bytes;
             bool cs = false;
             void *dx1 = at(ws, w.dxa), *dz1 = at(ws, w.dxb);      // where d(x1) arrives / where LayerNorm-1's backward puts d(z1)
+            // fused path: the three blocks' slab reductions run as ONE launch at the end of the layer (misc.hip: slab_defer_*);
+            // each block then needs its own slab region.  MIVIT_NO_SLAB_DEFER=1: one reduction behind every block (A/B runs)
+            static const bool no_defer = getenv("MIVIT_NO_SLAB_DEFER") != nullptr || getenv("MIVIT_NO_QKV_BWD") != nullptr;
+            size_t ws_mlp = 0, ws_ao = 0;
+            bool defer = false;
+            if (fz) {
+                const FusedOps *fo = fused_ops(dt, E);
+                ws_mlp = fo->mlp_bwd_ws(M); ws_ao = fo->attn_out_bwd_ws(M);
+                defer = !no_defer && wgb >= ws_mlp + ws_ao + fo->qkv_bwd_ws(M);
+            }
+            uint8_t *wg_ao = defer ? static_cast<uint8_t *>(wg) + ws_mlp : static_cast<uint8_t *>(wg);
+            uint8_t *wg_qkv = defer ? wg_ao + ws_ao : static_cast<uint8_t *>(wg);
+            const size_t wgb_ao = defer ? wgb - ws_mlp : wgb, wgb_qkv = defer ? wgb - ws_mlp - ws_ao : wgb;
+            if (defer) slab_defer_begin();
             if (fz) {
                 // feed-forward block in one launch (fused_bwd.hip): d(x2) -> d(x1), all six parameter gradients
                 dx1 = at(ws, w.dxb); dz1 = at(ws, w.dF);
@@ -746,7 +762,7 @@ static int backward_impl(const mivit_plan *plan, const float *params, const floa
                 prof_set_tag(MIVIT_PROF_ATTN_OUT_BWD);
                 RC(fused_ops(dt, E)->attn_out_bwd(dx1, at(ws, b.z1), static_cast<const float *>(at(ws, b.rstd1)), P + lp.n1_w, at(ws, b.ctx),
                                        WT(lp.out_w), M, dz1, at(ws, w.dctx), G + lp.out_w, G + lp.out_b, G + lp.n1_w, G + lp.n1_b,
-                                       wg, wgb, s));
+                                       wg_ao, wgb_ao, s));
             } else {
             LayerNormBwdArgs n1 = n2;
             n1.dy = dx1; n1.z = at(ws, b.z1); n1.gamma = P + lp.n1_w;
@@ -765,7 +781,9 @@ static int backward_impl(const mivit_plan *plan, const float *params, const floa
             int rc_q = 0;
             if (fz && !qkv_split) {
                 prof_pin_tag(MIVIT_PROF_QKV_BWD);
-                rc_q = fused_ops(dt, E)->qkv_bwd(at(ws, w.dqkv), xin, WT(lp.qkv_w), dz1, M, at(ws, w.dxa), G + lp.qkv_w, G + lp.qkv_b, wg, wgb, s);
+                rc_q = fused_ops(dt, E)->qkv_bwd(at(ws, w.dqkv), xin, WT(lp.qkv_w), dz1, M, at(ws, w.dxa), G + lp.qkv_w, G + lp.qkv_b, wg_qkv,
+                                                 wgb_qkv, s);
+                if (defer) { const int rc_f = slab_defer_flush(s); if (!rc_q) rc_q = rc_f; }          // (the fix-up below reads the reduced sums)
                 if (!rc_q && l > 0)
                     rc_q = launch_affine_fixup(G + lp.qkv_w, G + lp.qkv_b, P + plan->layers[l - 1].n2_w, P + plan->layers[l - 1].n2_b, 3 * E, E, s);
             } else {

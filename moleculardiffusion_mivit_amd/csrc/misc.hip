@@ -99,11 +99,11 @@ namespace {
 
 // out[i] (+)= sum_p part[p * n + i].  Block = 32 element-threads (one float4 each) x 8 part-lanes; every part-lane
 // sums its parts in a fixed order, the 8 lanes are combined through LDS in a fixed order: deterministic.
-__global__ __launch_bounds__(256) void slab_reduce_kernel(const float *part, int nparts, int64_t n, int64_t ps, float *out,
-                                                          int accumulate, int vec_ok) {      // ps = distance between parts
+__device__ __forceinline__ void slab_reduce_block(const float *part, int nparts, int64_t n, int64_t ps, float *out, int accumulate,
+                                                  int vec_ok, int block) {      // ps = distance between parts
     __shared__ float4 red[8][32];
     const int ex = threadIdx.x & 31, pl = threadIdx.x >> 5;
-    const int64_t e0 = ((int64_t)blockIdx.x * 32 + ex) * 4;
+    const int64_t e0 = ((int64_t)block * 32 + ex) * 4;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (e0 < n) {
         if (vec_ok) {
@@ -153,6 +153,24 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float *part, int
         for (int i = 0; i < 4; ++i)
             if (e0 + i < n) o[i] = accumulate ? o[i] + v[i] : v[i];
     }
+}
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float *part, int nparts, int64_t n, int64_t ps, float *out,
+                                                          int accumulate, int vec_ok) {
+    slab_reduce_block(part, nparts, n, ps, out, accumulate, vec_ok, blockIdx.x);
+}
+// several queued reductions in ONE launch (slab_defer_begin / slab_defer_flush below): block b belongs to the job whose block
+// range contains it; the arithmetic of a job is slab_reduce_kernel's
+constexpr int MAX_SLAB_JOBS = 8;
+struct SlabJobs {
+    const float *part[MAX_SLAB_JOBS]; float *out[MAX_SLAB_JOBS];
+    int nparts[MAX_SLAB_JOBS], n[MAX_SLAB_JOBS], stride[MAX_SLAB_JOBS], vec_ok[MAX_SLAB_JOBS], blk_end[MAX_SLAB_JOBS];
+    int njobs;
+};
+__global__ __launch_bounds__(256) void slab_reduce_multi_kernel(const SlabJobs j) {
+    int k = 0;
+    while (k + 1 < j.njobs && (int)blockIdx.x >= j.blk_end[k]) ++k;          // (uniform per block)
+    const int b0 = k ? j.blk_end[k - 1] : 0;
+    slab_reduce_block(j.part[k], j.nparts[k], j.n[k], j.stride[k], j.out[k], 0, j.vec_ok[k], (int)blockIdx.x - b0);
 }
 
 template <typename T>
@@ -380,10 +398,37 @@ int launch_slab_reduce(const float *part, int nparts, int64_t n, float *out, int
     MIVIT_LAUNCH_CHECK();
     return 0;
 }
+// Deferred reductions: the fused backward blocks of one encoder layer (mlp_block_bwd, attn_out_bwd, qkv_bwd) each end in a slab
+// reduction whose result nothing in the layer's backward reads -- three dependent 5-7 us launches per layer on the critical path
+// (24 of the ~85 launches of a 64-wide model's step).  Between slab_defer_begin() and slab_defer_flush(s) the strided
+// reductions are queued (their slabs must stay untouched until the flush: the engine gives each block its own workspace region)
+// and run as ONE launch.
+static thread_local bool t_slab_defer = false;
+static thread_local SlabJobs t_slab_jobs = {};
+void slab_defer_begin() { t_slab_defer = true; t_slab_jobs.njobs = 0; }
+void slab_defer_cancel() { t_slab_defer = false; t_slab_jobs.njobs = 0; }          // (a call that failed between begin and flush)
+int slab_defer_flush(hipStream_t s) {
+    t_slab_defer = false;
+    const int nj = t_slab_jobs.njobs;
+    t_slab_jobs.njobs = 0;
+    if (nj == 0) return 0;
+    SlabJobs j = t_slab_jobs;
+    j.njobs = nj;
+    hipLaunchKernelGGL(slab_reduce_multi_kernel, dim3(j.blk_end[nj - 1]), dim3(256), 0, s, j);
+    MIVIT_LAUNCH_CHECK();
+    return 0;
+}
 // the same for parts that are `stride` floats apart (one field of a per-workgroup record)
 int launch_slab_reduce_strided(const float *part, int nparts, int64_t stride, int64_t n, float *out, hipStream_t s) {
     const int blocks = (int)((n + 127) / 128);
     const int vec_ok = (n % 4 == 0) && (stride % 4 == 0) && ((reinterpret_cast<uintptr_t>(part) & 15) == 0);
+    if (t_slab_defer && t_slab_jobs.njobs < MAX_SLAB_JOBS && n < (1ll << 31) && stride < (1ll << 31)) {
+        SlabJobs &q = t_slab_jobs;
+        const int k = q.njobs++;
+        q.part[k] = part; q.out[k] = out; q.nparts[k] = nparts; q.n[k] = (int)n; q.stride[k] = (int)stride; q.vec_ok[k] = vec_ok;
+        q.blk_end[k] = (k ? q.blk_end[k - 1] : 0) + blocks;
+        return 0;
+    }
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, s, part, nparts, n, stride, out, 0, vec_ok);
     MIVIT_LAUNCH_CHECK();
     return 0;
