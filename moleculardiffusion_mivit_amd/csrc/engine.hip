@@ -32,7 +32,7 @@
                                   float *dbeta2, void *ws, size_t ws_bytes, hipStream_t s);                                        \
     size_t qkv_bwd_ws_bytes##SFX(int M);                                                                                           \
     int launch_qkv_bwd##SFX(const void *dqkv, const void *x, const void *Wqkv, const void *res, int M, void *dx, float *dW,        \
-                            float *db, void *ws, size_t ws_bytes, hipStream_t s);
+                            float *db, const float *fix_gamma, const float *fix_beta, void *ws, size_t ws_bytes, hipStream_t s);
 MIVIT_FUSED_DECLS()
 MIVIT_FUSED_DECLS(_f16)
 MIVIT_FUSED_DECLS(_w64)
@@ -781,11 +781,12 @@ static int backward_impl(const mivit_plan *plan, const float *params, const floa
             int rc_q = 0;
             if (fz && !qkv_split) {
                 prof_pin_tag(MIVIT_PROF_QKV_BWD);
-                rc_q = fused_ops(dt, E)->qkv_bwd(at(ws, w.dqkv), xin, WT(lp.qkv_w), dz1, M, at(ws, w.dxa), G + lp.qkv_w, G + lp.qkv_b, wg_qkv,
-                                                 wgb_qkv, s);
-                if (defer) { const int rc_f = slab_defer_flush(s); if (!rc_q) rc_q = rc_f; }          // (the fix-up below reads the reduced sums)
-                if (!rc_q && l > 0)
-                    rc_q = launch_affine_fixup(G + lp.qkv_w, G + lp.qkv_b, P + plan->layers[l - 1].n2_w, P + plan->layers[l - 1].n2_b, 3 * E, E, s);
+                // (x_in of layers l > 0 is the normalised output of the layer below: the affine fix-up of the weight gradient,
+                //  dW diag(gamma) + db (x) beta, rides on the kernel's slab writes)
+                rc_q = fused_ops(dt, E)->qkv_bwd(at(ws, w.dqkv), xin, WT(lp.qkv_w), dz1, M, at(ws, w.dxa), G + lp.qkv_w, G + lp.qkv_b,
+                                                 l > 0 ? P + plan->layers[l - 1].n2_w : nullptr, l > 0 ? P + plan->layers[l - 1].n2_b : nullptr,
+                                                 wg_qkv, wgb_qkv, s);
+                if (defer) { const int rc_f = slab_defer_flush(s); if (!rc_q) rc_q = rc_f; }
             } else {
                 if (fz) prof_pin_tag(MIVIT_PROF_QKV_WGRAD);
                 rc_q = lin_wgrad(dt, at(ws, w.dqkv), 3 * E, xin, 0, E, M, 3 * E, E, G + lp.qkv_w, G + lp.qkv_b, wg, wgb, s);

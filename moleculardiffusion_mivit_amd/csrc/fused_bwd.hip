@@ -937,6 +937,10 @@ struct QkvBwdArgs {
     int M;
     bf16 *dx;
     float *slabs;          // [gridDim.x][QB_SL_TOTAL]
+    // optional: x is the normalised output of a LayerNorm whose affine (gamma, beta) belongs to the projection's true input
+    // gamma * x + beta: the weight gradient against that input is dW * diag(gamma) + db (x) beta -- linear in (dW, db), so it is
+    // applied to this workgroup's partial sums on their way into the slab (it was a launch of its own behind the reduction)
+    const float *fix_gamma, *fix_beta;
 };
 
 __global__ __launch_bounds__(NTQ) void qkv_bwd_kernel(const QkvBwdArgs a) {
@@ -1036,12 +1040,16 @@ __global__ __launch_bounds__(NTQ) void qkv_bwd_kernel(const QkvBwdArgs a) {
     }
     // ---- partial gradients -> this workgroup's slab ----
     float *sl = a.slabs + (int64_t)blockIdx.x * QB_SL_TOTAL;
+    const bool fix = a.fix_gamma != nullptr;
 #pragma unroll
     for (int nt = 0; nt < 3; ++nt) {
 #pragma unroll
-        for (int ct = 0; ct < ET; ++ct)
+        for (int ct = 0; ct < ET; ++ct) {
+            const float gk = fix ? a.fix_gamma[16 * ct + cq] : 1.f, bk = fix ? a.fix_beta[16 * ct + cq] : 0.f;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) sl[QB_SL_W + (48 * wave + 16 * nt + 4 * g + j) * E + 16 * ct + cq] = dW[nt][ct][j];
+            for (int j = 0; j < 4; ++j)          // (dbv[nt][j]: every column of the ones-product holds the row's sum)
+                sl[QB_SL_W + (48 * wave + 16 * nt + 4 * g + j) * E + 16 * ct + cq] = fix ? dW[nt][ct][j] * gk + dbv[nt][j] * bk : dW[nt][ct][j];
+        }
         if (cq == 0) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) sl[QB_SL_B + 48 * wave + 16 * nt + 4 * g + j] = dbv[nt][j];
@@ -1057,14 +1065,15 @@ int qkv_grid_for(int M) { return std::min(256 * QB_WGPC, ceil_div(M, R)); }
 
 size_t qkv_bwd_ws_bytes(int M) { return align_up((size_t)qkv_grid_for(std::max(M, 1)) * QB_SL_TOTAL * sizeof(float), 256); }
 
-// dx [M,E]; dW [3E,E], db [3E] fp32 (overwritten)
-int launch_qkv_bwd(const void *dqkv, const void *x, const void *Wqkv, const void *res, int M, void *dx, float *dW, float *db, void *ws,
-                   size_t ws_bytes, hipStream_t s) {
+// dx [M,E]; dW [3E,E], db [3E] fp32 (overwritten); fix_gamma / fix_beta [E] optional (see QkvBwdArgs)
+int launch_qkv_bwd(const void *dqkv, const void *x, const void *Wqkv, const void *res, int M, void *dx, float *dW, float *db,
+                   const float *fix_gamma, const float *fix_beta, void *ws, size_t ws_bytes, hipStream_t s) {
     MIVIT_CHECK(dqkv && x && Wqkv && res && dx && dW && db && ws && M > 0, "qkv_bwd: null pointer / empty problem");
     MIVIT_CHECK(aligned16(dqkv) && aligned16(x) && aligned16(res) && aligned16(dx), "qkv_bwd: pointers must be 16-byte aligned");
     MIVIT_CHECK(ws_bytes >= qkv_bwd_ws_bytes(M), "qkv_bwd: workspace too small");
     QkvBwdArgs a{static_cast<const bf16 *>(dqkv), static_cast<const bf16 *>(x), static_cast<const bf16 *>(Wqkv), static_cast<const bf16 *>(res),
-                 M, static_cast<bf16 *>(dx), static_cast<float *>(ws)};
+                 M, static_cast<bf16 *>(dx), static_cast<float *>(ws), fix_gamma, fix_gamma ? fix_beta : nullptr};
+    MIVIT_CHECK((fix_gamma == nullptr) == (fix_beta == nullptr), "qkv_bwd: the input affine needs both gamma and beta");
     const int grid = qkv_grid_for(M);
     {
         ProfScope prof(s);
@@ -1227,7 +1236,7 @@ extern "C" size_t mivit_qkv_bwd_workspace_bytes(int M) { return qkv_bwd_ws_bytes
 extern "C" int mivit_qkv_bwd(const void *dqkv, const void *x, const void *Wqkv_bf16, const void *res, int M, void *dx, float *dW, float *db,
                              void *workspace, size_t workspace_bytes, void *stream) {
     prof_set_tag(MIVIT_PROF_OP);
-    return launch_qkv_bwd(dqkv, x, Wqkv_bf16, res, M, dx, dW, db, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+    return launch_qkv_bwd(dqkv, x, Wqkv_bf16, res, M, dx, dW, db, nullptr, nullptr, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
 }
 extern "C" size_t mivit_attn_out_bwd_workspace_bytes(int M) { return attn_out_bwd_ws_bytes(M); }
 extern "C" int mivit_attn_out_bwd(const void *dy, const void *n1, const float *rstd1, const float *gamma1, const void *ctx,
