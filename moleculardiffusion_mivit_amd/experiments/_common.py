@@ -77,6 +77,12 @@ class DataParallel:
         self.world = dist.get_world_size() if self.on else 1
 
     def prepare(self, models):
+        # the experiment loops step at the reference's batch sizes (1 ... 256 sequences: launch-bound, host time decides) and follow
+        # the pattern direct parameter gradients are made for -- optimizer.zero_grad() (grads set to None), backward, step --, so
+        # every native model gets them (bitwise the same training trajectory; any other pattern falls back by itself)
+        for model in models.values():
+            if model is not None and hasattr(model, "direct_param_grads"):
+                model.direct_param_grads(True)
         if not self.on:
             return
         from .. import dp
